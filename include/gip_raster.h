@@ -1,0 +1,188 @@
+/*
+ * gip_raster.h — C-ABI of the MI355X-native differentiable 3D-Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for the rasterizer half of GaussianIP's hot path.  Every entry point
+ * replaces one binding of the (un-vendored) `diff_gaussian_rasterization._C` module that the
+ * reference calls through its Python package:
+ *
+ *   gip_raster_forward   <->  _C.rasterize_gaussians            (called from GaussianRasterizer.forward;
+ *                              reference call sites gaussiansplatting/gaussian_renderer/__init__.py:85-93,
+ *                              :175-183, :240-248 and gs_renderer.py:992-1001)
+ *   gip_raster_backward  <->  _C.rasterize_gaussians_backward   (autograd backward of the same call;
+ *                              grads consumed at threestudio/systems/GaussianIP.py:452-457 and by Adam)
+ *   gip_raster_mark_visible <-> _C.mark_visible                 (GaussianRasterizer.markVisible; unused by
+ *                              the reference but part of the package surface)
+ *
+ * Contract:
+ *   - plain C, no torch / pybind types; every pointer is a raw DEVICE pointer unless marked [host];
+ *   - the caller owns every buffer (inputs, outputs, state, scratch); the library never allocates,
+ *     frees, or keeps a pointer after return, and has no global mutable state (re-entrant, one
+ *     process per GPU safe);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); the calls never synchronise
+ *     with the host.  The reference's one blocking D2H per forward (`num_rendered`) is replaced by a
+ *     caller-chosen `capacity` and a device-side status header the caller may read back whenever it
+ *     likes (gip_raster_read_header);
+ *   - integer status codes, no exceptions.
+ *
+ * Batched views: the reference renders its 4 cameras one after another (GaussianIP.py:154-173).
+ * Here a call renders V >= 1 views of the SAME Gaussians in one launch set; V = 1 reproduces the
+ * reference's per-camera call exactly.  Per-view arrays are laid out view-major: [V, ...].
+ */
+#ifndef GIP_RASTER_H
+#define GIP_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIP_ABI_VERSION 1
+#define GIP_TILE 16            /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16 in the reference's rasterizer) */
+#define GIP_MAX_VIEWS 16       /* views per call */
+#define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
+#define GIP_PARTIAL_FLOATS 16  /* per-(tile, Gaussian) gradient partial row, 64 bytes */
+
+/* status codes */
+enum {
+  GIP_OK = 0,
+  GIP_ERR_BAD_ARGUMENT = 1,    /* null pointer / inconsistent optional inputs / bad sizes */
+  GIP_ERR_BUFFER_TOO_SMALL = 2,/* state or scratch smaller than gip_raster_*_bytes() says */
+  GIP_ERR_HIP = 3,             /* a HIP runtime call or launch failed */
+  GIP_ERR_UNSUPPORTED = 4      /* e.g. sh_degree > 3, V > GIP_MAX_VIEWS */
+};
+
+/* Per-call constants: the fields of GaussianRasterizationSettings
+ * (gaussian_renderer/__init__.py:36-49) plus sizes. */
+typedef struct GipRasterConfig {
+  int32_t P;              /* number of Gaussians */
+  int32_t V;              /* number of views rendered by this call (1..GIP_MAX_VIEWS) */
+  int32_t H, W;           /* image_height, image_width (shared by all views) */
+  int32_t sh_degree;      /* active SH degree 0..3 */
+  int32_t sh_coeffs;      /* M: SH coefficients per channel stored in `shs` ([P, M, 3]); 0 if colors_precomp */
+  int32_t prefiltered;    /* settings.prefiltered (always False in the reference) */
+  int32_t debug;          /* settings.debug: synchronise + check after every launch */
+  float scale_modifier;   /* settings.scale_modifier */
+  float tanfovx[GIP_MAX_VIEWS]; /* [host] per view */
+  float tanfovy[GIP_MAX_VIEWS]; /* [host] per view */
+  uint64_t capacity;      /* max number of (tile, Gaussian) instances (= num_rendered summed over views)
+                             the state buffers can hold; overflow is flagged in the header */
+} GipRasterConfig;
+
+/* Device inputs.  Exactly one of (shs, colors_precomp) and one of (scales+rotations, cov3D_precomp)
+ * must be non-null — same rule as GaussianRasterizer.forward. */
+typedef struct GipRasterInputs {
+  const float* means3D;        /* [P,3] */
+  const float* shs;            /* [P,M,3] or null */
+  const float* colors_precomp; /* [P,3]  or null */
+  const float* opacities;      /* [P,1]  (post-sigmoid) */
+  const float* scales;         /* [P,3]  (post-exp) or null */
+  const float* rotations;      /* [P,4]  (w,x,y,z) or null */
+  const float* cov3D_precomp;  /* [P,6]  (xx,xy,xz,yy,yz,zz) or null */
+  const float* viewmatrix;     /* [V,16] world_view_transform, row-vector convention as stored by cameras.py:48 */
+  const float* projmatrix;     /* [V,16] full_proj_transform, cameras.py:50 */
+  const float* campos;         /* [V,3]  camera_center */
+  const float* bg;             /* [3]    background colour */
+} GipRasterInputs;
+
+typedef struct GipRasterOutputs {
+  float*   color;  /* [V,3,H,W] */
+  int32_t* radii;  /* [V,P]     */
+  float*   depth;  /* [V,1,H,W] */
+  float*   alpha;  /* [V,1,H,W] */
+} GipRasterOutputs;
+
+/* Upstream gradients (any may be null = zero) and saved forward output needed by backward. */
+typedef struct GipRasterGradsIn {
+  const float* dL_dcolor; /* [V,3,H,W] */
+  const float* dL_ddepth; /* [V,1,H,W] */
+  const float* dL_dalpha; /* [V,1,H,W] */
+  const float* alpha;     /* [V,1,H,W] forward output `alpha` (final T = 1 - alpha) */
+} GipRasterGradsIn;
+
+/* Gradients w.r.t. the inputs, summed over the V views (means2D is per view).  Null = not wanted.
+ * All are fully overwritten (no pre-zeroing needed). */
+typedef struct GipRasterGradsOut {
+  float* dL_dmeans3D;        /* [P,3] */
+  float* dL_dmeans2D;        /* [V,P,3] screen-space grad carrier (xy in NDC units, z = 0) */
+  float* dL_dshs;            /* [P,M,3] */
+  float* dL_dcolors_precomp; /* [P,3] */
+  float* dL_dopacities;      /* [P,1] */
+  float* dL_dscales;         /* [P,3] */
+  float* dL_drotations;      /* [P,4] */
+  float* dL_dcov3D_precomp;  /* [P,6] */
+} GipRasterGradsOut;
+
+/* Status header written by forward at the start of the state buffer (16 x u32). */
+typedef struct GipRasterHeader {
+  uint32_t abi_version;
+  uint32_t num_rendered;   /* total (tile, Gaussian) instances required, over all views */
+  uint32_t overflow;       /* 1 if num_rendered > capacity: outputs are invalid, re-run with more */
+  uint32_t max_tile_count; /* longest per-tile list */
+  uint32_t num_visible;    /* Gaussians with radii > 0, over all views */
+  uint32_t reserved[11];
+} GipRasterHeader;
+
+/* Byte offsets of the sub-buffers inside `state` (for tests, debugging and parity checks of the
+ * tile / index buffers).  All offsets are 256-byte aligned. */
+typedef struct GipRasterStateLayout {
+  size_t header;       /* GipRasterHeader */
+  size_t records;      /* [V,P] x GIP_RECORD_BYTES */
+  size_t inst_offset;  /* [V,P] u32: exclusive prefix sum of tiles_touched (view-major, global) */
+  size_t tile_count;   /* [V,T] u32: entries per tile */
+  size_t tile_start;   /* [V*T+1] u32: exclusive scan of tile_count == ranges[tile].x, ranges[tile].y = next */
+  size_t tile_cursor;  /* [V,T] u32 scratch for bucket fill */
+  size_t block_sums;   /* [V,ceil(P/256)] u32 */
+  size_t block_offset; /* [V*ceil(P/256)+1] u32 */
+  size_t keys;         /* [capacity] u64 sorted per tile: (depth_bits << 32) | gaussian_index */
+  size_t n_contrib;    /* [V,H,W] u32 */
+  size_t total;        /* total bytes */
+  uint32_t tiles_x, tiles_y, num_blocks, reserved;
+} GipRasterStateLayout;
+
+/* Per-(view,Gaussian) record (GIP_RECORD_BYTES = 64), written by preprocess:
+ *   float  x, y        pixel-space centre (points_xy_image)
+ *   float  depth       view-space z
+ *   float  opacity
+ *   float  conic_a, conic_b, conic_c
+ *   uint32 tiles_touched
+ *   float  r, g, b     colour after SH / clamp
+ *   int32  radius
+ *   uint32 rect_min    (x | y << 16) in tiles
+ *   uint32 rect_max    (x | y << 16) in tiles, exclusive
+ *   uint32 clamped     bit0..2 = colour channel clamped at 0
+ *   uint32 pad
+ */
+
+int gip_abi_version(void);
+const char* gip_status_string(int status);
+
+/* Sizes.  Return 0 on invalid config. */
+size_t gip_raster_state_bytes(const GipRasterConfig* cfg);
+size_t gip_raster_scratch_bytes(const GipRasterConfig* cfg); /* backward scratch: capacity x 64 B partial rows */
+int    gip_raster_state_layout(const GipRasterConfig* cfg, GipRasterStateLayout* out);
+
+/* Forward: preprocess -> tile binning -> per-tile depth sort -> front-to-back blend.
+ * `state` (>= gip_raster_state_bytes) must be kept by the caller until backward has run. */
+int gip_raster_forward(const GipRasterConfig* cfg, const GipRasterInputs* in, const GipRasterOutputs* out,
+                       void* state, size_t state_bytes, void* stream);
+
+/* Backward: per-pixel reverse-order replay with wave/LDS segmented reduction into per-(tile,Gaussian)
+ * partial rows, then a deterministic per-Gaussian gather fused with the cov2D / projection / SH /
+ * cov3D backward.  No float atomics: results are bitwise reproducible. */
+int gip_raster_backward(const GipRasterConfig* cfg, const GipRasterInputs* in, const GipRasterGradsIn* gin,
+                        const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
+                        const GipRasterGradsOut* gout, void* stream);
+
+/* Asynchronously copies the header to `host_header` ([host], ideally pinned) on `stream`. */
+int gip_raster_read_header(const void* state, GipRasterHeader* host_header, void* stream);
+
+/* mark_visible: present[i] = view-space z of means3D[i] > 0.2 (the rasterizer's frustum test). */
+int gip_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                            uint8_t* present, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIP_RASTER_H */
