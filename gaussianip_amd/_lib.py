@@ -1,0 +1,116 @@
+"""ctypes binding of libgip_raster.so / libgip_knn.so (the C-ABI declared in include/gip_raster.h, include/gip_knn.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, loading raises ImportError with build
+instructions (`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+GIP_MAX_VIEWS = 16
+GIP_RECORD_BYTES = 64
+GIP_PARTIAL_FLOATS = 16
+GIP_OK = 0
+
+_vp = ctypes.c_void_p
+
+
+class GipRasterConfig(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_int32), ("V", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32), ("prefiltered", ctypes.c_int32),
+                ("debug", ctypes.c_int32), ("scale_modifier", ctypes.c_float),
+                ("tanfovx", ctypes.c_float * GIP_MAX_VIEWS), ("tanfovy", ctypes.c_float * GIP_MAX_VIEWS),
+                ("capacity", ctypes.c_uint64)]
+
+
+class GipRasterInputs(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
+                                   "cov3D_precomp", "viewmatrix", "projmatrix", "campos", "bg")]
+
+
+class GipRasterOutputs(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("color", "radii", "depth", "alpha")]
+
+
+class GipRasterGradsIn(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("dL_dcolor", "dL_ddepth", "dL_dalpha", "alpha")]
+
+
+class GipRasterGradsOut(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("dL_dmeans3D", "dL_dmeans2D", "dL_dshs", "dL_dcolors_precomp", "dL_dopacities",
+                                   "dL_dscales", "dL_drotations", "dL_dcov3D_precomp")]
+
+
+class GipRasterStateLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_size_t) for n in ("header", "records", "inst_offset", "tile_count", "tile_start",
+                                                "tile_cursor", "block_sums", "block_offset", "keys", "n_contrib",
+                                                "total")] + \
+               [(n, ctypes.c_uint32) for n in ("tiles_x", "tiles_y", "num_blocks", "reserved")]
+
+
+_raster = None
+_knn = None
+
+
+def _missing(name):
+    return ImportError(
+        "gaussianip_amd: %s not found in %s. The HIP extension must be built for gfx950 first "
+        "(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gaussianip_amd/csrc`). "
+        "There is no CPU fallback for the product path." % (name, LIB_DIR))
+
+
+def raster_lib():
+    global _raster
+    if _raster is None:
+        path = os.path.join(LIB_DIR, "libgip_raster.so")
+        if not os.path.exists(path):
+            raise _missing("libgip_raster.so")
+        lib = ctypes.CDLL(path)
+        lib.gip_abi_version.restype = ctypes.c_int
+        lib.gip_status_string.restype = ctypes.c_char_p
+        lib.gip_status_string.argtypes = [ctypes.c_int]
+        lib.gip_raster_state_bytes.restype = ctypes.c_size_t
+        lib.gip_raster_state_bytes.argtypes = [ctypes.POINTER(GipRasterConfig)]
+        lib.gip_raster_scratch_bytes.restype = ctypes.c_size_t
+        lib.gip_raster_scratch_bytes.argtypes = [ctypes.POINTER(GipRasterConfig)]
+        lib.gip_raster_state_layout.restype = ctypes.c_int
+        lib.gip_raster_state_layout.argtypes = [ctypes.POINTER(GipRasterConfig), ctypes.POINTER(GipRasterStateLayout)]
+        lib.gip_raster_forward.restype = ctypes.c_int
+        lib.gip_raster_forward.argtypes = [ctypes.POINTER(GipRasterConfig), ctypes.POINTER(GipRasterInputs),
+                                           ctypes.POINTER(GipRasterOutputs), _vp, ctypes.c_size_t, _vp]
+        lib.gip_raster_backward.restype = ctypes.c_int
+        lib.gip_raster_backward.argtypes = [ctypes.POINTER(GipRasterConfig), ctypes.POINTER(GipRasterInputs),
+                                            ctypes.POINTER(GipRasterGradsIn), _vp, ctypes.c_size_t, _vp,
+                                            ctypes.c_size_t, ctypes.POINTER(GipRasterGradsOut), _vp]
+        lib.gip_raster_read_header.restype = ctypes.c_int
+        lib.gip_raster_read_header.argtypes = [_vp, _vp, _vp]
+        lib.gip_raster_mark_visible.restype = ctypes.c_int
+        lib.gip_raster_mark_visible.argtypes = [ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]
+        _raster = lib
+    return _raster
+
+
+def knn_lib():
+    global _knn
+    if _knn is None:
+        path = os.path.join(LIB_DIR, "libgip_knn.so")
+        if not os.path.exists(path):
+            raise _missing("libgip_knn.so")
+        lib = ctypes.CDLL(path)
+        lib.gip_knn_workspace_bytes.restype = ctypes.c_size_t
+        lib.gip_knn_workspace_bytes.argtypes = [ctypes.c_int32]
+        lib.gip_knn_mean_dist2.restype = ctypes.c_int
+        lib.gip_knn_mean_dist2.argtypes = [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_size_t, _vp]
+        _knn = lib
+    return _knn
+
+
+def status_string(rc):
+    return raster_lib().gip_status_string(int(rc)).decode()
+
+
+RASTER_SYMBOLS = ["gip_abi_version", "gip_status_string", "gip_raster_state_bytes", "gip_raster_scratch_bytes",
+                  "gip_raster_state_layout", "gip_raster_forward", "gip_raster_backward", "gip_raster_read_header",
+                  "gip_raster_mark_visible"]

@@ -1,0 +1,87 @@
+// gip_internal.h — shared declarations of the HIP rasterizer (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gip_raster.h"
+
+#define GIP_BLOCK 256           // threads per workgroup everywhere (4 x wave64)
+#define GIP_WAVE 64
+#define GIP_NEAR 0.2f           // view-space z cull (in_frustum)
+#define GIP_ALPHA_MIN (1.0f / 255.0f)
+#define GIP_ALPHA_MAX 0.99f
+#define GIP_T_MIN 0.0001f
+
+// Per-(view, Gaussian) projected record, 64 bytes = four 16-byte quads so a lane fetches it with
+// global_load_dwordx4.  Layout documented in include/gip_raster.h.
+struct __attribute__((aligned(16))) GipRecord {
+  float x, y, depth, opacity;           // q0
+  float ca, cb, cc; uint32_t tiles;     // q1
+  float r, g, b; int32_t radius;        // q2
+  uint32_t rmin, rmax, clamped, pad;    // q3  (rect in tiles: x | y << 16; max exclusive)
+};
+static_assert(sizeof(GipRecord) == GIP_RECORD_BYTES, "record size");
+
+struct GipViewConst {           // per-view host scalars, passed by value in kernel args
+  float tanfovx, tanfovy, focal_x, focal_y;
+};
+
+struct GipKernelParams {
+  int P, V, H, W;
+  int tiles_x, tiles_y, T;      // T = tiles_x * tiles_y
+  int nblk;                     // ceil(P / 256)
+  int D, M;
+  float scale_modifier;
+  uint32_t capacity;
+  GipViewConst view[GIP_MAX_VIEWS];
+};
+
+struct GipStatePtrs {
+  GipRasterHeader* header;
+  GipRecord* records;       // [V,P]
+  uint32_t* inst_offset;    // [V,P]
+  uint32_t* tile_count;     // [V*T]
+  uint32_t* tile_start;     // [V*T+1]
+  uint32_t* tile_cursor;    // [V*T]
+  uint32_t* block_sums;     // [V*nblk]
+  uint32_t* block_offset;   // [V*nblk+1]
+  unsigned long long* keys; // [capacity]
+  uint32_t* n_contrib;      // [V,H,W]
+};
+
+// --- launchers implemented in the .hip translation units -----------------------------------------
+void gip_launch_preprocess(const GipKernelParams& kp, const GipRasterInputs& in, int32_t* radii, GipStatePtrs st, hipStream_t s);
+void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s);
+void gip_launch_scatter(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s);
+void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s);
+void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth, float* alpha, hipStream_t s);
+void gip_launch_render_backward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, const GipRasterGradsIn& gin, float* partial, hipStream_t s);
+void gip_launch_gather_backward(const GipKernelParams& kp, const GipRasterInputs& in, GipStatePtrs st, const float* partial, const GipRasterGradsOut& gout, hipStream_t s);
+void gip_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+
+// --- device helpers ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+// Wave64 inclusive sum via DPP row shifts + row broadcasts (no LDS traffic).
+__device__ __forceinline__ uint32_t gip_wave_incl_scan_u32(uint32_t v) {
+  // log-step scan with shuffles; hipcc lowers constant-offset __shfl_up to DPP / ds_bpermute
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Sum over the 64 lanes of a wave, result valid in every lane.
+__device__ __forceinline__ float gip_wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t gip_wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+  return v;
+}
+#endif

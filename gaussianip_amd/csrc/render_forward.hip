@@ -1,0 +1,101 @@
+// render_forward.hip — per-tile front-to-back alpha compositing (colour, depth, alpha) for gfx950.
+//
+// Replaces the fork's forward renderCUDA<3> (SURVEY.md §2.1 "fwd 6"); outputs are the 4-tuple the
+// reference unpacks at gaussian_renderer/__init__.py:85: color [3,H,W], depth [1,H,W] = sum z a T,
+// alpha [1,H,W] = sum a T, plus n_contrib for the backward replay.
+//
+// One workgroup (4 x wave64) per 16x16 tile; wave w owns the 8x8 quadrant (w&1, w>>1) so that a wave
+// whose 64 pixels have all terminated drops out of the inner loop early.  The tile's depth-sorted list
+// is consumed in batches of 256: each lane fetches one key, gathers that Gaussian's 64-byte record with
+// dwordx4 loads and stages the 40 bytes the blend needs into LDS; the inner loop then reads each entry
+// as wave-uniform LDS broadcasts.
+#include "gip_internal.h"
+
+__global__ void __launch_bounds__(GIP_BLOCK)
+gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_start,
+                          const unsigned long long* __restrict__ keys, const GipRecord* __restrict__ records,
+                          const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
+                          float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
+  const uint32_t vt = blockIdx.x;            // view * T + tile
+  const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
+  const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
+  const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
+  const bool inside = px < kp.W && py < kp.H;
+  const float pxf = (float)px, pyf = (float)py;
+
+  const uint32_t start = tile_start[vt];
+  uint32_t end = tile_start[vt + 1];
+  if (end > kp.capacity) end = kp.capacity;
+  if (end < start) end = start;
+  const GipRecord* recs = records + (size_t)v * kp.P;
+
+  __shared__ float2 s_xy[GIP_BLOCK];
+  __shared__ float4 s_con[GIP_BLOCK];   // conic a,b,c + opacity
+  __shared__ float4 s_col[GIP_BLOCK];   // r,g,b + depth
+
+  bool done = !inside;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, Dp = 0.f;
+  uint32_t last_contributor = 0;
+
+  for (uint32_t base = start; base < end; base += GIP_BLOCK) {
+    if (__syncthreads_count(done) == GIP_BLOCK) break;
+    const uint32_t k = base + threadIdx.x;
+    if (k < end) {
+      const uint32_t g = (uint32_t)keys[k];
+      const float4* rp = reinterpret_cast<const float4*>(recs + g);
+      const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+      s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
+      s_con[threadIdx.x] = make_float4(q1.x, q1.y, q1.z, q0.w);
+      s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
+    }
+    __syncthreads();
+    const int cnt = min((uint32_t)GIP_BLOCK, end - base);
+    for (int j = 0; j < cnt; j++) {
+      // wave-uniform early out (checked in converged control flow, every 8 entries)
+      if ((j & 7) == 0 && __all(done)) break;
+      if (!done) {
+        const float2 xy = s_xy[j];
+        const float4 co = s_con[j];
+        const float dx = xy.x - pxf, dy = xy.y - pyf;
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        if (power <= 0.0f) {
+          const float alpha = fminf(GIP_ALPHA_MAX, co.w * __expf(power));
+          if (alpha >= GIP_ALPHA_MIN) {
+            const float test_T = T * (1.f - alpha);
+            if (test_T < GIP_T_MIN) {
+              done = true;
+            } else {
+              const float4 cl = s_col[j];
+              const float w = alpha * T;
+              C0 += cl.x * w; C1 += cl.y * w; C2 += cl.z * w;
+              Wt += w;
+              Dp += cl.w * w;
+              T = test_T;
+              last_contributor = (base - start) + j + 1;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (inside) {
+    const size_t HW = (size_t)kp.H * kp.W;
+    const size_t pix = (size_t)py * kp.W + px;
+    float* oc = out_color + (size_t)v * 3 * HW;
+    oc[pix] = C0 + T * bg[0];
+    oc[HW + pix] = C1 + T * bg[1];
+    oc[2 * HW + pix] = C2 + T * bg[2];
+    out_depth[(size_t)v * HW + pix] = Dp;
+    out_alpha[(size_t)v * HW + pix] = Wt;
+    n_contrib[(size_t)v * HW + pix] = last_contributor;
+  }
+}
+
+void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth,
+                               float* alpha, hipStream_t s) {
+  hipLaunchKernelGGL(gip_render_forward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_start, st.keys,
+                     st.records, bg, color, depth, alpha, st.n_contrib);
+}

@@ -1,0 +1,362 @@
+"""Host-side mirror of the `diff_gaussian_rasterization` package surface, on top of the C-ABI HIP library.
+
+Reference interface reproduced (the package is an un-vendored dependency; the contract is its call sites):
+  * GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
+    projmatrix, sh_degree, campos, prefiltered, debug)          gaussian_renderer/__init__.py:36-49
+  * GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+    cov3D_precomp) -> (color [3,H,W], radii [P] int32, depth [1,H,W], alpha [1,H,W])      :51, :85-93
+  * GaussianRasterizer.markVisible(positions)
+Error behaviour: "Please provide exactly one of either SHs or precomputed colors!" /
+"Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!" (Exception), as the fork.
+
+Beyond the reference: `rasterize_views` renders V views of the same Gaussians in ONE launch set (the reference
+loops over its 4 cameras, threestudio/systems/GaussianIP.py:154-173); V = 1 is exactly the reference call.
+
+No host synchronisation on the training path: the reference's blocking read of `num_rendered` is replaced by a
+capacity hint + a device-side overflow flag that is checked when backward starts.
+"""
+import ctypes
+import os
+from typing import NamedTuple, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---------------------------------------------------------------------------------------------
+# capacity policy (replaces the reference's per-call D2H of num_rendered)
+# ---------------------------------------------------------------------------------------------
+_MIN_CAPACITY = 1 << 20
+_capacity_hint = {}     # (device index, P bucket, V, H, W) -> last observed num_rendered
+_pending_checks = []    # (event, pinned header, key, capacity) of no-grad-free calls not yet verified
+
+
+def _strict():
+    return os.environ.get("GIP_RASTER_SYNC", "0") == "1"
+
+
+def _hint_key(dev, P, V, H, W):
+    return (dev.index if dev.index is not None else torch.cuda.current_device(), V, H, W)
+
+
+def _pick_capacity(key, P, V):
+    last = _capacity_hint.get(key)
+    if last is None:
+        return None  # unknown: first call learns it synchronously
+    return int(max(_MIN_CAPACITY, 3 * last + 65536))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t, name, shape_last=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("%s must be a CUDA/HIP tensor (the rasterizer has no CPU path)" % name)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+class _Plan:
+    """Everything one forward/backward pair shares."""
+    pass
+
+
+def _make_config(P, V, H, W, sh_degree, M, scale_modifier, tanfovx, tanfovy, capacity, prefiltered, debug):
+    cfg = _lib.GipRasterConfig()
+    cfg.P, cfg.V, cfg.H, cfg.W = int(P), int(V), int(H), int(W)
+    cfg.sh_degree, cfg.sh_coeffs = int(sh_degree), int(M)
+    cfg.prefiltered, cfg.debug = int(bool(prefiltered)), int(bool(debug))
+    cfg.scale_modifier = float(scale_modifier)
+    for v in range(V):
+        cfg.tanfovx[v] = float(tanfovx[v])
+        cfg.tanfovy[v] = float(tanfovy[v])
+    cfg.capacity = int(capacity)
+    return cfg
+
+
+def _check(rc, what):
+    if rc != _lib.GIP_OK:
+        msg = "%s failed: %s (status %d)" % (what, _lib.status_string(rc), rc)
+        if rc == 1:
+            raise ValueError(msg)
+        raise RuntimeError(msg)
+
+
+def _run_forward(plan, capacity):
+    lib = _lib.raster_lib()
+    dev = plan.means3D.device
+    cfg = _make_config(plan.P, plan.V, plan.H, plan.W, plan.sh_degree, plan.M, plan.scale_modifier, plan.tanfovx,
+                       plan.tanfovy, capacity, plan.prefiltered, plan.debug)
+    nbytes = lib.gip_raster_state_bytes(ctypes.byref(cfg))
+    if nbytes == 0:
+        raise ValueError("invalid rasterizer configuration (P=%d V=%d H=%d W=%d sh_degree=%d)" %
+                         (plan.P, plan.V, plan.H, plan.W, plan.sh_degree))
+    state = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    V, P, H, W = plan.V, plan.P, plan.H, plan.W
+    color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
+    alpha = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    ins = _lib.GipRasterInputs(_ptr(plan.means3D), _ptr(plan.shs), _ptr(plan.colors_precomp), _ptr(plan.opacities),
+                               _ptr(plan.scales), _ptr(plan.rotations), _ptr(plan.cov3D_precomp),
+                               _ptr(plan.viewmatrix), _ptr(plan.projmatrix), _ptr(plan.campos), _ptr(plan.bg))
+    outs = _lib.GipRasterOutputs(_ptr(color), _ptr(radii), _ptr(depth), _ptr(alpha))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.gip_raster_forward(ctypes.byref(cfg), ctypes.byref(ins), ctypes.byref(outs), _ptr(state), nbytes, stream)
+    _check(rc, "gip_raster_forward")
+    plan.cfg, plan.state, plan.capacity = cfg, state, capacity
+    return color, radii, depth, alpha
+
+
+def _read_header_async(plan):
+    host = torch.empty(16, dtype=torch.int32).pin_memory()
+    host.copy_(plan.state[:64].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(plan.means3D.device))
+    return ev, host
+
+
+def _forward_with_policy(plan, need_backward):
+    key = _hint_key(plan.means3D.device, plan.P, plan.V, plan.H, plan.W)
+    cap = _pick_capacity(key, plan.P, plan.V)
+    sync_now = _strict() or cap is None or not need_backward
+    if cap is None:
+        cap = max(_MIN_CAPACITY, 8 * plan.P * plan.V)
+    while True:
+        outs = _run_forward(plan, cap)
+        ev, host = _read_header_async(plan)
+        if not sync_now:
+            plan.pending = (ev, host, key, cap)
+            return outs
+        ev.synchronize()
+        num_rendered, overflow = int(host[1]), int(host[2])
+        _capacity_hint[key] = max(num_rendered, 1)
+        if not overflow:
+            plan.pending = None
+            plan.num_rendered = num_rendered
+            return outs
+        cap = int(num_rendered * 1.25) + 65536  # exact requirement is known: re-run once
+
+
+def _verify_pending(plan):
+    """Deferred overflow check, run when backward starts (the copy finished long ago: no stall)."""
+    if getattr(plan, "pending", None) is None:
+        return
+    ev, host, key, cap = plan.pending
+    ev.synchronize()
+    plan.pending = None
+    num_rendered, overflow = int(host[1]), int(host[2])
+    _capacity_hint[key] = max(num_rendered, 1)
+    plan.num_rendered = num_rendered
+    if overflow:
+        raise RuntimeError(
+            "gaussianip_amd rasterizer: %d tile instances exceeded the capacity hint %d; the forward outputs of this "
+            "call are invalid. The hint has been raised — re-run the step, or set GIP_RASTER_SYNC=1 to size "
+            "buffers synchronously like the reference does." % (num_rendered, cap))
+
+
+def _run_backward(plan, alpha, g_color, g_depth, g_alpha, want):
+    lib = _lib.raster_lib()
+    dev = plan.means3D.device
+    V, P, M = plan.V, plan.P, plan.M
+    cfg = plan.cfg
+    sbytes = lib.gip_raster_scratch_bytes(ctypes.byref(cfg))
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+
+    def mk(flag, shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev) if flag else None
+
+    g = dict(means3D=mk(True, (P, 3)), means2D=mk(True, (V, P, 3)),
+             shs=mk(plan.shs is not None, (P, max(M, 1), 3)),
+             colors_precomp=mk(plan.colors_precomp is not None, (P, 3)), opacities=mk(True, (P, 1)),
+             scales=mk(plan.scales is not None, (P, 3)), rotations=mk(plan.rotations is not None, (P, 4)),
+             cov3D_precomp=mk(plan.cov3D_precomp is not None, (P, 6)))
+    ins = _lib.GipRasterInputs(_ptr(plan.means3D), _ptr(plan.shs), _ptr(plan.colors_precomp), _ptr(plan.opacities),
+                               _ptr(plan.scales), _ptr(plan.rotations), _ptr(plan.cov3D_precomp),
+                               _ptr(plan.viewmatrix), _ptr(plan.projmatrix), _ptr(plan.campos), _ptr(plan.bg))
+    gin = _lib.GipRasterGradsIn(_ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(alpha))
+    gout = _lib.GipRasterGradsOut(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]),
+                                  _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]),
+                                  _ptr(g["cov3D_precomp"]))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.gip_raster_backward(ctypes.byref(cfg), ctypes.byref(ins), ctypes.byref(gin), _ptr(plan.state),
+                                 plan.state.numel(), _ptr(scratch), sbytes, ctypes.byref(gout), stream)
+    _check(rc, "gip_raster_backward")
+    return g
+
+
+def _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list):
+    s0 = settings_list[0]
+    V = len(settings_list)
+    if V > _lib.GIP_MAX_VIEWS:
+        raise ValueError("at most %d views per call" % _lib.GIP_MAX_VIEWS)
+    plan = _Plan()
+    plan.means3D = _f32c(means3D, "means3D")
+    plan.shs = _f32c(shs, "shs")
+    plan.colors_precomp = _f32c(colors_precomp, "colors_precomp")
+    plan.opacities = _f32c(opacities, "opacities")
+    plan.scales = _f32c(scales, "scales")
+    plan.rotations = _f32c(rotations, "rotations")
+    plan.cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp")
+    dev = plan.means3D.device
+    plan.P, plan.V = int(plan.means3D.shape[0]), V
+    plan.H, plan.W = int(s0.image_height), int(s0.image_width)
+    plan.sh_degree = int(s0.sh_degree)
+    plan.M = 0 if plan.shs is None else int(plan.shs.shape[1])
+    plan.scale_modifier = float(s0.scale_modifier)
+    plan.prefiltered, plan.debug = bool(s0.prefiltered), bool(s0.debug)
+    for s in settings_list[1:]:
+        if (int(s.image_height), int(s.image_width), int(s.sh_degree), float(s.scale_modifier)) != \
+                (plan.H, plan.W, plan.sh_degree, plan.scale_modifier):
+            raise ValueError("all views of one call must share image size, sh_degree and scale_modifier")
+    plan.tanfovx = [float(s.tanfovx) for s in settings_list]
+    plan.tanfovy = [float(s.tanfovy) for s in settings_list]
+    if V == 1:
+        plan.viewmatrix = _f32c(s0.viewmatrix, "viewmatrix").reshape(1, 16)
+        plan.projmatrix = _f32c(s0.projmatrix, "projmatrix").reshape(1, 16)
+        plan.campos = _f32c(s0.campos, "campos").reshape(1, 3)
+    else:
+        plan.viewmatrix = torch.stack([s.viewmatrix.float().reshape(16) for s in settings_list]).to(dev).contiguous()
+        plan.projmatrix = torch.stack([s.projmatrix.float().reshape(16) for s in settings_list]).to(dev).contiguous()
+        plan.campos = torch.stack([s.campos.float().reshape(3) for s in settings_list]).to(dev).contiguous()
+    plan.bg = _f32c(s0.bg, "bg")
+    return plan
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Differentiable V-view rasterization.  Inputs that are None are passed as None (the fork passes empty tensors)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list):
+        plan = _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list)
+        need_bwd = any(t is not None and t.requires_grad for t in
+                       (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
+        color, radii, depth, alpha = _forward_with_policy(plan, need_bwd and torch.is_grad_enabled())
+        ctx.plan = plan
+        ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
+        ctx.save_for_backward(alpha)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        plan = ctx.plan
+        (alpha,) = ctx.saved_tensors
+        _verify_pending(plan)
+
+        def prep(g):
+            if g is None:
+                return None
+            return g.float().contiguous()
+
+        g = _run_backward(plan, alpha, prep(g_color), prep(g_depth), prep(g_alpha), None)
+        g2d = None if ctx.means2D_shape is None else g["means2D"].reshape(ctx.means2D_shape)
+        return (g["means3D"], g2d, g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"],
+                g["cov3D_precomp"], None)
+
+
+def _validate(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    """Single view; returns the reference 4-tuple with the reference shapes."""
+    color, radii, depth, alpha = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                                           rotations, cov3Ds_precomp, [raster_settings])
+    return color[0], radii[0], depth[0], alpha[0]
+
+
+def rasterize_views(means3D, means2D, opacities, settings_list: Sequence[GaussianRasterizationSettings], shs=None,
+                    colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+    """V views in one launch set.  means2D: [V,P,3] zero grad carrier (or None).
+    Returns color [V,3,H,W], radii [V,P], depth [V,1,H,W], alpha [V,1,H,W]."""
+    _validate(shs, colors_precomp, scales, rotations, cov3D_precomp)
+    return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                     cov3D_precomp, list(settings_list))
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            pos = _f32c(positions, "positions")
+            out = torch.empty(pos.shape[0], dtype=torch.uint8, device=pos.device)
+            vm = _f32c(rs.viewmatrix, "viewmatrix")
+            pm = _f32c(rs.projmatrix, "projmatrix")
+            rc = _lib.raster_lib().gip_raster_mark_visible(
+                int(pos.shape[0]), _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out),
+                ctypes.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream))
+            _check(rc, "gip_raster_mark_visible")
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        _validate(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)
+
+
+# ---------------------------------------------------------------------------------------------
+# state inspection (tests / parity of the tile & index buffers)
+# ---------------------------------------------------------------------------------------------
+def state_views(plan):
+    """Decode a forward's state buffer into named torch views (no copies)."""
+    lib = _lib.raster_lib()
+    L = _lib.GipRasterStateLayout()
+    _check(lib.gip_raster_state_layout(ctypes.byref(plan.cfg), ctypes.byref(L)), "gip_raster_state_layout")
+    st = plan.state
+    V, P, H, W = plan.V, plan.P, plan.H, plan.W
+    T = L.tiles_x * L.tiles_y
+
+    def view(off, count, dtype, shape):
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return st[off:off + nbytes].view(dtype).reshape(shape)
+
+    return dict(
+        header=view(L.header, 16, torch.int32, (16,)),
+        records=view(L.records, V * P * 16, torch.float32, (V, P, 16)),
+        records_u32=view(L.records, V * P * 16, torch.int32, (V, P, 16)),
+        inst_offset=view(L.inst_offset, V * P, torch.int32, (V, P)),
+        tile_count=view(L.tile_count, V * T, torch.int32, (V, T)),
+        tile_start=view(L.tile_start, V * T + 1, torch.int32, (V * T + 1,)),
+        keys=view(L.keys, int(plan.capacity), torch.int64, (int(plan.capacity),)),
+        n_contrib=view(L.n_contrib, V * H * W, torch.int32, (V, H, W)),
+        tiles_x=L.tiles_x, tiles_y=L.tiles_y)
+
+
+def forward_with_state(means3D, opacities, settings_list, shs=None, colors_precomp=None, scales=None, rotations=None,
+                       cov3D_precomp=None):
+    """No-grad forward that also returns the plan (for state_views); used by the parity tests."""
+    _validate(shs, colors_precomp, scales, rotations, cov3D_precomp)
+    plan = _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, list(settings_list))
+    outs = _forward_with_policy(plan, False)
+    return outs, plan

@@ -175,6 +175,17 @@ int gip_raster_backward(const GipRasterConfig* cfg, const GipRasterInputs* in, c
                         const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
                         const GipRasterGradsOut* gout, void* stream);
 
+/* Measurement variants: identical work, but a hipEvent pair brackets every stage on `stream` and the call
+ * synchronises at the end to fill `times_ms` ([host]).  Used by bench.py for the live per-kernel durations the
+ * roofline figure is computed from; never used on the training path. */
+enum { GIP_STAGE_CLEAR = 0, GIP_STAGE_PREPROCESS, GIP_STAGE_SCAN, GIP_STAGE_SCATTER, GIP_STAGE_TILE_SORT,
+       GIP_STAGE_RENDER_FWD, GIP_STAGE_RENDER_BWD, GIP_STAGE_GATHER_BWD, GIP_NUM_STAGES };
+int gip_raster_forward_profiled(const GipRasterConfig* cfg, const GipRasterInputs* in, const GipRasterOutputs* out,
+                                void* state, size_t state_bytes, void* stream, float* times_ms /* [GIP_NUM_STAGES] */);
+int gip_raster_backward_profiled(const GipRasterConfig* cfg, const GipRasterInputs* in, const GipRasterGradsIn* gin,
+                                 const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
+                                 const GipRasterGradsOut* gout, void* stream, float* times_ms /* [GIP_NUM_STAGES] */);
+
 /* Asynchronously copies the header to `host_header` ([host], ideally pinned) on `stream`. */
 int gip_raster_read_header(const void* state, GipRasterHeader* host_header, void* stream);
 
