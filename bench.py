@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — the hot-path benchmark (contract: one JSON line from rank 0).
+
+A "step" is one pass of the rasterizer hot path over one batch: V = 4 views of the SAME P = 100k Gaussians at
+1024x1024, forward + backward (BASELINE.json configs[1]; batch of 4 cameras per step as configs/exp.yaml:59-61 and
+threestudio/systems/GaussianIP.py:154-173), inputs resident in HBM, synthetic data (seed 42):
+a 100k-point human-shaped surface (SMPL-X weights are licensed and absent), isotropic 3-NN scales, opacity 0.1, SH
+degree 0 — the shipped init (gaussian_model.py:113-136) — and 4 cameras from the training ranges.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own 4 views of the replicated
+Gaussian state (weak scaling, view-sharded data parallelism) and the per-step exchange of SURVEY.md §8e runs inside the
+timed region over RCCL: all_reduce(sum) of the parameter gradients (one flat 14*P-float bucket), all_reduce(sum) of the
+view-space gradient norms and all_reduce(max) of the radii.
+
+Extra objects: "roofline" (dominant kernel, live hipEvent durations on the launch stream) and "cpu_baseline" (the CPU
+oracle = "port" of the reference algorithm, timed on this box's host cores on a bounded sample: 1 view fwd+bwd).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(P, K, R, T, N):
+    """SURVEY.md §8d, per view: forward B_f and backward B_b."""
+    b_f = P * (92 + 12 * K) + 88 * R + 8 * T + 24 * N
+    b_b = 44 * R + 28 * N + P * (211 + 24 * K)
+    return b_f, b_b
+
+
+def stage_bytes(stage, P, K, R, T, N):
+    """The same §8d terms split by kernel stage (per view); DESIGN.md §Kernels lists the derivation."""
+    return {
+        "preprocess": P * (44 + 12 * K) + 48 * P,
+        "scan": 8 * T,
+        "scatter": 12 * R,
+        "tile_sort": 24 * R + 8 * R,
+        "render_fwd": 44 * R + 24 * N,
+        "render_bwd": 44 * R + 28 * N,
+        "gather_bwd": P * (211 + 24 * K),
+    }[stage]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=100000)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import scenes
+    from gaussianip_amd import GaussianRasterizationSettings, rasterize_views
+    from gaussianip_amd import rasterizer as R
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    P, H, W, V = args.gaussians, args.size, args.size, args.views
+    K = 1  # SH coefficients per channel at the shipped sh_degree 0
+    sc = scenes.make_scene("human", P, seed=42, sh_degree=0)
+    cams = scenes.train_cameras(V, seed=42 + rank, H=H, W=W)   # each rank (= view shard) gets its own cameras
+    bg = torch.zeros(3, device=dev)
+    sts = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+        viewmatrix=torch.from_numpy(c["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(c["projmatrix"]).to(dev),
+        sh_degree=0, campos=torch.from_numpy(c["campos"]).to(dev), prefiltered=False, debug=False) for c in cams]
+    t = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in sc.items()}
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    gC = torch.randn((V, 3, H, W), device=dev, generator=gen) * 1e-3
+    gD = torch.randn((V, 1, H, W), device=dev, generator=gen) * 1e-3
+    names = ["means3D", "shs", "opacities", "scales", "rotations"]
+    flat_n = sum(t[n].numel() for n in names)
+    bucket = torch.empty(flat_n, device=dev)
+
+    def step():
+        m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], sts, shs=t["shs"],
+                                                     scales=t["scales"], rotations=t["rotations"])
+        grads = torch.autograd.grad([color, depth], [t[n] for n in names] + [m2d], [gC, gD])
+        if world > 1:
+            torch.cat([g.reshape(-1) for g in grads[:-1]], out=bucket)
+            dist.all_reduce(bucket)
+            vs = grads[-1][..., :2].norm(dim=-1).sum(0)
+            dist.all_reduce(vs)
+            rmax = radii.max(dim=0).values
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+        return color
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    views_total = world * V * args.steps
+    mpix_s = views_total * H * W / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        # ---- roofline: live per-kernel durations (hipEvents on the launch stream) ----
+        stages, num_rendered = R.profile_stages(
+            t["means3D"].detach(), t["opacities"].detach(), sts, gC, gD, None, shs=t["shs"].detach(),
+            scales=t["scales"].detach(), rotations=t["rotations"].detach(), iters=args.profile_iters)
+        Rv = num_rendered / V
+        T = ((H + 15) // 16) * ((W + 15) // 16)
+        N = H * W
+        b_f, b_b = algorithmic_bytes(P, K, Rv, T, N)
+        kernel_stages = [s for s in stages if s != "clear"]
+        dom = max(kernel_stages, key=lambda s: stages[s])
+        dom_bytes = stage_bytes(dom, P, K, Rv, T, N) * V
+        achieved = dom_bytes / (stages[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "gip_%s_kernel" % dom, "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": int(dom_bytes),
+                    "avg_launch_ms": round(stages[dom], 4),
+                    "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                    "whole_step_GBs": round((b_f + b_b) * V / (ms_per_step * 1e-3) / 1e9, 2),
+                    "whole_step_frac": round((b_f + b_b) * V / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "pair_evals_per_s_fwd": round(Rv * V * 256 / (stages["render_fwd"] * 1e-3), 0)}
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            orc.build()
+            ncores = os.cpu_count() or 1
+            orc.set_threads(ncores)
+            c0 = cams[0]
+            ro = orc.RasterOracle()
+            kw = dict(image_height=H, image_width=W, tanfovx=c0["tanfovx"], tanfovy=c0["tanfovy"],
+                      bg=np.zeros(3, np.float32), scale_modifier=1.0, viewmatrix=c0["viewmatrix"],
+                      projmatrix=c0["projmatrix"], sh_degree=0, campos=c0["campos"], means3D=sc["means3D"],
+                      opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+            gc_h, gd_h = gC[0].cpu().numpy(), gD[0].cpu().numpy()
+            ro.forward(**kw)  # warm-up (page-in)
+            reps, tt = 0, 0.0
+            while reps < 1 or (tt < 10.0 and reps < 20):
+                c1 = time.perf_counter()
+                ro.forward(**kw)
+                ro.backward(gc_h, gd_h, None)
+                tt += time.perf_counter() - c1
+                reps += 1
+            cpu = {"value": round(reps * H * W / tt / 1e6, 3), "unit": "Mpix/s", "cores": ncores, "kind": "port",
+                   "sample": "%d x (1 view fwd+bwd, P=%d, %dx%d) on the C oracle, OpenMP over tiles" % (reps, P, H, W)}
+
+        out = {"metric": "raster_fwd_bwd_mpix_per_s", "value": round(mpix_s, 2), "unit": "Mpix/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]: %d Gaussians (synthetic human surface, SMPL-X-style "
+                                      "init), %dx%d, %d views/step per GPU, raster forward+backward" % (P, H, W, V),
+                          "gaussians": P, "height": H, "width": W, "views_per_step_per_gpu": V,
+                          "num_rendered_per_view": int(Rv), "sh_degree": 0,
+                          "parallelism": "view-sharded dp%d" % world},
+               "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

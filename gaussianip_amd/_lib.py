@@ -84,6 +84,10 @@ def raster_lib():
         lib.gip_raster_backward.argtypes = [ctypes.POINTER(GipRasterConfig), ctypes.POINTER(GipRasterInputs),
                                             ctypes.POINTER(GipRasterGradsIn), _vp, ctypes.c_size_t, _vp,
                                             ctypes.c_size_t, ctypes.POINTER(GipRasterGradsOut), _vp]
+        lib.gip_raster_forward_profiled.restype = ctypes.c_int
+        lib.gip_raster_forward_profiled.argtypes = lib.gip_raster_forward.argtypes + [ctypes.POINTER(ctypes.c_float)]
+        lib.gip_raster_backward_profiled.restype = ctypes.c_int
+        lib.gip_raster_backward_profiled.argtypes = lib.gip_raster_backward.argtypes + [ctypes.POINTER(ctypes.c_float)]
         lib.gip_raster_read_header.restype = ctypes.c_int
         lib.gip_raster_read_header.argtypes = [_vp, _vp, _vp]
         lib.gip_raster_mark_visible.restype = ctypes.c_int
@@ -113,4 +117,4 @@ def status_string(rc):
 
 RASTER_SYMBOLS = ["gip_abi_version", "gip_status_string", "gip_raster_state_bytes", "gip_raster_scratch_bytes",
                   "gip_raster_state_layout", "gip_raster_forward", "gip_raster_backward", "gip_raster_read_header",
-                  "gip_raster_mark_visible"]
+                  "gip_raster_mark_visible", "gip_raster_forward_profiled", "gip_raster_backward_profiled"]

@@ -360,3 +360,51 @@ def forward_with_state(means3D, opacities, settings_list, shs=None, colors_preco
     plan = _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, list(settings_list))
     outs = _forward_with_policy(plan, False)
     return outs, plan
+
+
+# ---------------------------------------------------------------------------------------------
+# measurement helper (bench.py): live per-stage durations via the *_profiled C-ABI entry points
+# ---------------------------------------------------------------------------------------------
+STAGE_NAMES = ["clear", "preprocess", "scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "gather_bwd"]
+
+
+def profile_stages(means3D, opacities, settings_list, g_color, g_depth=None, g_alpha=None, shs=None,
+                   colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, iters=10):
+    """Runs forward+backward `iters` times with hipEvent pairs around every kernel stage (on the stream the kernels
+    are launched on) and returns ({stage: mean ms}, num_rendered).  Synchronises; not for the training path."""
+    lib = _lib.raster_lib()
+    _validate(shs, colors_precomp, scales, rotations, cov3D_precomp)
+    plan = _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, list(settings_list))
+    (color, radii, depth, alpha) = _forward_with_policy(plan, False)   # sizes the capacity synchronously
+    dev = plan.means3D.device
+    cfg = plan.cfg
+    V, P, M = plan.V, plan.P, plan.M
+    sbytes = lib.gip_raster_scratch_bytes(ctypes.byref(cfg))
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    g = dict(means3D=f(P, 3), means2D=f(V, P, 3), shs=f(P, max(M, 1), 3) if plan.shs is not None else None,
+             colors=f(P, 3) if plan.colors_precomp is not None else None, opac=f(P, 1),
+             scales=f(P, 3) if plan.scales is not None else None, rots=f(P, 4) if plan.rotations is not None else None,
+             cov=f(P, 6) if plan.cov3D_precomp is not None else None)
+    ins = _lib.GipRasterInputs(_ptr(plan.means3D), _ptr(plan.shs), _ptr(plan.colors_precomp), _ptr(plan.opacities),
+                               _ptr(plan.scales), _ptr(plan.rotations), _ptr(plan.cov3D_precomp),
+                               _ptr(plan.viewmatrix), _ptr(plan.projmatrix), _ptr(plan.campos), _ptr(plan.bg))
+    outs = _lib.GipRasterOutputs(_ptr(color), _ptr(radii), _ptr(depth), _ptr(alpha))
+    gin = _lib.GipRasterGradsIn(_ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(alpha))
+    gout = _lib.GipRasterGradsOut(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), _ptr(g["colors"]),
+                                  _ptr(g["opac"]), _ptr(g["scales"]), _ptr(g["rots"]), _ptr(g["cov"]))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    times = (ctypes.c_float * len(STAGE_NAMES))()
+    acc = [0.0] * len(STAGE_NAMES)
+    for it in range(iters + 1):
+        for i in range(len(STAGE_NAMES)):
+            times[i] = 0.0
+        _check(lib.gip_raster_forward_profiled(ctypes.byref(cfg), ctypes.byref(ins), ctypes.byref(outs),
+                                               _ptr(plan.state), plan.state.numel(), stream, times), "forward_profiled")
+        _check(lib.gip_raster_backward_profiled(ctypes.byref(cfg), ctypes.byref(ins), ctypes.byref(gin),
+                                                _ptr(plan.state), plan.state.numel(), _ptr(scratch), sbytes,
+                                                ctypes.byref(gout), stream, times), "backward_profiled")
+        if it > 0:  # first iteration is warm-up
+            for i in range(len(STAGE_NAMES)):
+                acc[i] += float(times[i])
+    return {n: acc[i] / iters for i, n in enumerate(STAGE_NAMES)}, plan.num_rendered
