@@ -62,8 +62,19 @@ def _pick_capacity(key, P, V):
     return int(max(_MIN_CAPACITY, 3 * last + 65536))
 
 
+_dummy = {}
+
+
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if t.numel() == 0:
+        # empty tensors have a null data_ptr; the C-ABI distinguishes "absent" (null) from "empty" (P = 0)
+        d = _dummy.get(t.device)
+        if d is None:
+            d = _dummy[t.device] = torch.zeros(64, dtype=torch.float32, device=t.device)
+        return ctypes.c_void_p(d.data_ptr())
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _f32c(t, name, shape_last=None):
