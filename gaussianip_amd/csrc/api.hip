@@ -46,6 +46,7 @@ extern "C" int gip_raster_state_layout(const GipRasterConfig* c, GipRasterStateL
   L->records = off;      off = align256(off + V * P * GIP_RECORD_BYTES);
   L->inst_offset = off;  off = align256(off + V * P * 4);
   L->n_contrib = off;    off = align256(off + V * (size_t)c->H * c->W * 4);
+  L->tile_order = off;   off = align256(off + V * T * 4);
   L->keys = off;         off = align256(off + (size_t)c->capacity * 8);
   L->total = off;
   return GIP_OK;
@@ -91,6 +92,7 @@ static GipStatePtrs state_ptrs(void* state, const GipRasterStateLayout& L) {
   p.block_offset = (uint32_t*)(b + L.block_offset);
   p.keys = (unsigned long long*)(b + L.keys);
   p.n_contrib = (uint32_t*)(b + L.n_contrib);
+  p.tile_order = (uint32_t*)(b + L.tile_order);
   return p;
 }
 

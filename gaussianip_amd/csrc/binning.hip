@@ -62,14 +62,39 @@ __device__ void scan_array(const uint32_t* __restrict__ in, uint32_t* __restrict
   }
 }
 
+// Launch order for the per-tile kernels: tiles bucketed by floor(log2(count)) and emitted longest
+// bucket first, so the long lists start early and the short ones fill the tail.  Order inside a bucket
+// is arbitrary (it only decides which workgroup id renders which tile; results do not depend on it).
+__device__ void heavy_first_order(const uint32_t* __restrict__ counts, uint32_t* __restrict__ order, int n,
+                                  uint32_t* s_bucket /*[33]*/) {
+  for (int i = threadIdx.x; i < 33; i += SCAN_THREADS) s_bucket[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+    const uint32_t c = counts[i];
+    atomicAdd(&s_bucket[c ? 32 - __clz(c) : 0], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int b = 32; b >= 0; b--) { uint32_t c = s_bucket[b]; s_bucket[b] = run; run += c; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+    const uint32_t c = counts[i];
+    order[atomicAdd(&s_bucket[c ? 32 - __clz(c) : 0], 1u)] = (uint32_t)i;
+  }
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS)
 gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offset,
-                GipRasterHeader* __restrict__ header) {
+                uint32_t* __restrict__ tile_order, GipRasterHeader* __restrict__ header) {
   __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+  __shared__ uint32_t s_bucket[33];
   uint32_t total_tiles, max_tile, total_inst;
   scan_array(tile_count, tile_start, kp.V * kp.T, s_wave, &total_tiles, &max_tile);
   scan_array(block_sums, block_offset, kp.V * kp.nblk, s_wave, &total_inst, nullptr);
+  heavy_first_order(tile_count, tile_order, kp.V * kp.T, s_bucket);
   if (threadIdx.x == 0) {
     header->abi_version = GIP_ABI_VERSION;
     header->num_rendered = total_tiles;   // == total_inst
@@ -80,7 +105,7 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uin
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   hipLaunchKernelGGL(gip_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, kp, st.tile_count, st.tile_start,
-                     st.block_sums, st.block_offset, st.header);
+                     st.block_sums, st.block_offset, st.tile_order, st.header);
 }
 
 // ------------------------------------------------------------------------------------------------

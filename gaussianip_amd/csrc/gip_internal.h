@@ -47,6 +47,7 @@ struct GipStatePtrs {
   uint32_t* block_offset;   // [V*nblk+1]
   unsigned long long* keys; // [capacity]
   uint32_t* n_contrib;      // [V,H,W]
+  uint32_t* tile_order;     // [V*T] heavy-first launch order
 };
 
 // --- launchers implemented in the .hip translation units -----------------------------------------

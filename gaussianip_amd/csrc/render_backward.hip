@@ -27,25 +27,40 @@ __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
   return v + __builtin_bit_cast(float, moved);
 }
-// Sum of the 64 lanes, valid in lane 63.
-__device__ __forceinline__ float wave_reduce_to_lane63(float v) {
+// lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]   (v_permlane32_swap + add)
+__device__ __forceinline__ float fold32(float a, float b) {
+  // inline asm: the clang builtin's second result is mis-selected for float operands on ROCm 7.2 (both
+  // extracts return the first register); the swap updates both registers in place.
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+// rows (16 lanes) 0,2 <- a.row(r) + a.row(r+1), rows 1,3 <- b.row(r-1) + b.row(r)   (v_permlane16_swap + add)
+__device__ __forceinline__ float fold16(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+// sum of each 16-lane row, valid in the row's lane 15
+__device__ __forceinline__ float row_reduce(float v) {
   v = dpp_add<0x111, 0xf>(v);  // row_shr:1
   v = dpp_add<0x112, 0xf>(v);  // row_shr:2
   v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
-  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
   return v;
 }
 
 __global__ void __launch_bounds__(GIP_BLOCK)
-gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_start,
+gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_order,
+                           const uint32_t* __restrict__ tile_start,
                            const unsigned long long* __restrict__ keys, const GipRecord* __restrict__ records,
                            const uint32_t* __restrict__ inst_offset, const float* __restrict__ bg,
                            const uint32_t* __restrict__ n_contrib, const float* __restrict__ alpha_out,
                            const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                            const float* __restrict__ dL_dalpha_in, float* __restrict__ partial) {
-  const uint32_t vt = blockIdx.x;
+  const uint32_t vt = tile_order[blockIdx.x];
+  const uint32_t start = tile_start[vt];
+  uint32_t end = tile_start[vt + 1];
+  if (end > kp.capacity) end = kp.capacity;
+  if (end <= start) return;
   const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
   const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -53,11 +68,7 @@ gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile
   const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
   const bool inside = px < kp.W && py < kp.H;
   const float pxf = (float)px, pyf = (float)py;
-
-  const uint32_t start = tile_start[vt];
-  uint32_t end = tile_start[vt + 1];
-  if (end > kp.capacity) end = kp.capacity;
-  if (end <= start) return;
+  const float tile_x0 = (float)(tx * GIP_TILE), tile_y0 = (float)(ty * GIP_TILE);
   const int n = (int)(end - start);
   const GipRecord* recs = records + (size_t)v * kp.P;
   const uint32_t* ioff = inst_offset + (size_t)v * kp.P;
@@ -66,6 +77,7 @@ gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile
   __shared__ float4 s_con[BWD_BATCH];
   __shared__ float4 s_col[BWD_BATCH];
   __shared__ uint32_t s_row[BWD_BATCH];
+  __shared__ uint32_t s_mask[BWD_BATCH];
   __shared__ float s_part[4][BWD_BATCH][BWD_NV];
   __shared__ uint32_t s_max[4];
 
@@ -87,10 +99,8 @@ gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile
   const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
 
   // longest replay needed by any pixel of the tile
-  {
-    uint32_t m = gip_wave_max_u32(last_contributor);
-    if (lane == 0) s_max[wave] = m;
-  }
+  const int wave_maxc = (int)gip_wave_max_u32(last_contributor);
+  if (lane == 0) s_max[wave] = (uint32_t)wave_maxc;
   __syncthreads();
   const int maxc = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 
@@ -113,22 +123,41 @@ gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile
       s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
       const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
       s_row[threadIdx.x] = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
+      // quadrant mask from the extent of { alpha >= 1/255 } (same conservative test as the forward kernel)
+      uint32_t mask = 0xf;
+      const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
+      const float det = q1.x * q1.z - q1.y * q1.y;
+      if (t2 <= 0.f || i >= maxc) {
+        mask = 0;
+      } else if (det > 0.f) {
+        const float inv = t2 / det;
+        const float hx = sqrtf(inv * q1.z) * 1.01f + 0.05f, hy = sqrtf(inv * q1.x) * 1.01f + 0.05f;
+        const float rx = q0.x - tile_x0, ry = q0.y - tile_y0;
+        const bool xl = rx - hx <= 7.f, xr = rx + hx >= 8.f, yt = ry - hy <= 7.f, yb = ry + hy >= 8.f;
+        mask = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+      }
+      s_mask[threadIdx.x] = mask;
     }
     for (int e = threadIdx.x; e < 4 * BWD_BATCH * BWD_NV; e += GIP_BLOCK) (&s_part[0][0][0])[e] = 0.f;
     __syncthreads();
 
-    if (lo < maxc) {
-      for (int j = 0; j < cnt; j++) {
-        const int i = hi - 1 - j;
-        if (i >= maxc) continue;                       // uniform over the workgroup
-        const float2 xy = s_xy[j];
-        const float4 co = s_con[j];
-        const float dx = xy.x - pxf, dy = xy.y - pyf;
-        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
-        const bool c = (uint32_t)i < last_contributor && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
-        if (__any(c)) {                                 // uniform over the wave
+    if (lo < wave_maxc) {
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int e = c0 + lane;
+        const bool want = e < cnt && ((s_mask[e] >> wave) & 1u) && (hi - 1 - e) < wave_maxc;
+        unsigned long long m = __ballot(want);
+        while (m) {
+          const int j = c0 + __builtin_ctzll(m);
+          m &= m - 1;
+          const int i = hi - 1 - j;
+          const float2 xy = s_xy[j];
+          const float4 co = s_con[j];
+          const float dx = xy.x - pxf, dy = xy.y - pyf;
+          const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+          const float G = __expf(power);
+          const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
+          const bool c = (uint32_t)i < last_contributor && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
+          if (!__any(c)) continue;                      // uniform over the wave
           float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
           if (c) {
             const float4 cl = s_col[j];
@@ -158,16 +187,23 @@ gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile
             v4 = -0.5f * gdy * dy * dL_dG;
             v5 = G * dL_dalpha;
           }
-          v0 = wave_reduce_to_lane63(v0); v1 = wave_reduce_to_lane63(v1);
-          v2 = wave_reduce_to_lane63(v2); v3 = wave_reduce_to_lane63(v3);
-          v4 = wave_reduce_to_lane63(v4); v5 = wave_reduce_to_lane63(v5);
-          v6 = wave_reduce_to_lane63(v6); v7 = wave_reduce_to_lane63(v7);
-          v8 = wave_reduce_to_lane63(v8); v9 = wave_reduce_to_lane63(v9);
-          if (lane == 63) {
-            float4* dst = reinterpret_cast<float4*>(&s_part[wave][j][0]);
-            dst[0] = make_float4(v0, v1, v2, v3);
-            dst[1] = make_float4(v4, v5, v6, v7);
-            dst[2] = make_float4(v8, v9, 0.f, 0.f);
+          // 64-lane sums of the ten terms in 27 cross-lane ops: fold halves (permlane32_swap), fold row
+          // pairs (permlane16_swap), then one DPP row reduction per packed register.
+          const float p02 = fold32(v0, v2), p13 = fold32(v1, v3);   // [v0|v2], [v1|v3]
+          const float p46 = fold32(v4, v6), p57 = fold32(v5, v7);
+          const float p89 = fold32(v8, v9);
+          float qa = fold16(p02, p13);   // rows: v0, v1, v2, v3
+          float qb = fold16(p46, p57);   // rows: v4, v5, v6, v7
+          qa = row_reduce(qa);
+          qb = row_reduce(qb);
+          float qc = row_reduce(p89);    // rows 0,1: v8 ; rows 2,3: v9
+          qc = dpp_add<0x142, 0xa>(qc);  // row_bcast:15 -> lane 31 = v8, lane 63 = v9
+          if ((lane & 15) == 15) {
+            const int r = lane >> 4;
+            float* dst = &s_part[wave][j][0];
+            dst[r] = qa;
+            dst[4 + r] = qb;
+            if (r & 1) dst[8 + (r >> 1)] = qc;
           }
         }
       }
@@ -195,7 +231,8 @@ gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile
 
 void gip_launch_render_backward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, const GipRasterGradsIn& gin,
                                 float* partial, hipStream_t s) {
-  hipLaunchKernelGGL(gip_render_backward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_start, st.keys,
+  hipLaunchKernelGGL(gip_render_backward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_order,
+                     st.tile_start, st.keys,
                      st.records, st.inst_offset, bg, st.n_contrib, gin.alpha, gin.dL_dcolor, gin.dL_ddepth,
                      gin.dL_dalpha, partial);
 }

@@ -4,19 +4,26 @@
 // reference unpacks at gaussian_renderer/__init__.py:85: color [3,H,W], depth [1,H,W] = sum z a T,
 // alpha [1,H,W] = sum a T, plus n_contrib for the backward replay.
 //
-// One workgroup (4 x wave64) per 16x16 tile; wave w owns the 8x8 quadrant (w&1, w>>1) so that a wave
-// whose 64 pixels have all terminated drops out of the inner loop early.  The tile's depth-sorted list
-// is consumed in batches of 256: each lane fetches one key, gathers that Gaussian's 64-byte record with
-// dwordx4 loads and stages the 40 bytes the blend needs into LDS; the inner loop then reads each entry
-// as wave-uniform LDS broadcasts.
+// Structure (wave64-first, not a 16x16 thread block recompiled):
+//   * one workgroup = 4 waves per 16x16 tile; wave w owns the 8x8 pixel quadrant (w&1, w>>1);
+//   * workgroups are launched longest-list-first (tile_order from the scan kernel);
+//   * the tile's depth-sorted list is consumed in batches of 256: each lane fetches one key, gathers that
+//     Gaussian's 64-byte record with dwordx4 loads, stages the 40 bytes the blend needs into LDS, and
+//     computes a 4-bit QUADRANT MASK from the tight screen-space extent of the alpha >= 1/255 ellipse
+//     (|dx| <= sqrt(2 ln(255 o) cov_xx), same for y).  A pair outside that ellipse fails the reference's
+//     alpha < 1/255 test, so skipping it cannot change any output;
+//   * each wave ballots the mask bits of its quadrant and walks only the set bits with scalar
+//     find-first-one, evaluating the surviving entries with a branch-free body (LDS broadcast reads,
+//     v_exp_f32, predicated accumulation), and leaves as soon as all 64 of its pixels have terminated.
 #include "gip_internal.h"
 
 __global__ void __launch_bounds__(GIP_BLOCK)
-gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_start,
-                          const unsigned long long* __restrict__ keys, const GipRecord* __restrict__ records,
-                          const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
-                          float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
-  const uint32_t vt = blockIdx.x;            // view * T + tile
+gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_order,
+                          const uint32_t* __restrict__ tile_start, const unsigned long long* __restrict__ keys,
+                          const GipRecord* __restrict__ records, const float* __restrict__ bg,
+                          float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                          uint32_t* __restrict__ n_contrib) {
+  const uint32_t vt = tile_order[blockIdx.x];   // view * T + tile
   const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
   const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -24,6 +31,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
   const bool inside = px < kp.W && py < kp.H;
   const float pxf = (float)px, pyf = (float)py;
+  const float tile_x0 = (float)(tx * GIP_TILE), tile_y0 = (float)(ty * GIP_TILE);
 
   const uint32_t start = tile_start[vt];
   uint32_t end = tile_start[vt + 1];
@@ -34,6 +42,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   __shared__ float2 s_xy[GIP_BLOCK];
   __shared__ float4 s_con[GIP_BLOCK];   // conic a,b,c + opacity
   __shared__ float4 s_col[GIP_BLOCK];   // r,g,b + depth
+  __shared__ uint32_t s_mask[GIP_BLOCK];
 
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, Dp = 0.f;
@@ -49,34 +58,55 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
       s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
       s_con[threadIdx.x] = make_float4(q1.x, q1.y, q1.z, q0.w);
       s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
+      // extent of { power >= -ln(255 o) }  (conservative: +1% / +0.05 px)
+      uint32_t mask = 0xf;
+      const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
+      const float det = q1.x * q1.z - q1.y * q1.y;
+      if (t2 <= 0.f) {
+        mask = 0;
+      } else if (det > 0.f) {
+        const float inv = t2 / det;
+        const float hx = sqrtf(inv * q1.z) * 1.01f + 0.05f, hy = sqrtf(inv * q1.x) * 1.01f + 0.05f;
+        const float rx = q0.x - tile_x0, ry = q0.y - tile_y0;   // centre relative to the tile origin
+        const bool xl = rx - hx <= 7.f, xr = rx + hx >= 8.f;     // touches columns 0..7 / 8..15
+        const bool yt = ry - hy <= 7.f, yb = ry + hy >= 8.f;
+        mask = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+      }
+      s_mask[threadIdx.x] = mask;
     }
     __syncthreads();
     const int cnt = min((uint32_t)GIP_BLOCK, end - base);
-    for (int j = 0; j < cnt; j++) {
-      // wave-uniform early out (checked in converged control flow, every 8 entries)
-      if ((j & 7) == 0 && __all(done)) break;
-      if (!done) {
-        const float2 xy = s_xy[j];
-        const float4 co = s_con[j];
-        const float dx = xy.x - pxf, dy = xy.y - pyf;
-        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-        if (power <= 0.0f) {
+    if (!__all(done)) {
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int e = c0 + lane;
+        const uint32_t mk = e < cnt ? s_mask[e] : 0u;
+        unsigned long long m = __ballot((mk >> wave) & 1u);
+        bool wave_done = false;
+        while (m) {
+          const int j = c0 + __builtin_ctzll(m);
+          m &= m - 1;
+          const float2 xy = s_xy[j];
+          const float4 co = s_con[j];
+          const float4 cl = s_col[j];
+          const float dx = xy.x - pxf, dy = xy.y - pyf;
+          const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
           const float alpha = fminf(GIP_ALPHA_MAX, co.w * __expf(power));
-          if (alpha >= GIP_ALPHA_MIN) {
-            const float test_T = T * (1.f - alpha);
-            if (test_T < GIP_T_MIN) {
-              done = true;
-            } else {
-              const float4 cl = s_col[j];
-              const float w = alpha * T;
-              C0 += cl.x * w; C1 += cl.y * w; C2 += cl.z * w;
-              Wt += w;
-              Dp += cl.w * w;
-              T = test_T;
-              last_contributor = (base - start) + j + 1;
-            }
+          const bool valid = !done && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
+          const float test_T = T * (1.f - alpha);
+          const bool stop = valid && test_T < GIP_T_MIN;
+          const bool acc = valid && !stop;
+          done = done || stop;
+          const float w = acc ? alpha * T : 0.f;
+          C0 += cl.x * w; C1 += cl.y * w; C2 += cl.z * w;
+          Wt += w;
+          Dp += cl.w * w;
+          T = acc ? test_T : T;
+          last_contributor = acc ? (base - start) + j + 1 : last_contributor;
+          if (__any(stop)) {               // wave-uniform; re-test termination only when something changed
+            if (__all(done)) { wave_done = true; break; }
           }
         }
+        if (wave_done) break;
       }
     }
   }
@@ -96,6 +126,6 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
 
 void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth,
                                float* alpha, hipStream_t s) {
-  hipLaunchKernelGGL(gip_render_forward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_start, st.keys,
-                     st.records, bg, color, depth, alpha, st.n_contrib);
+  hipLaunchKernelGGL(gip_render_forward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_order,
+                     st.tile_start, st.keys, st.records, bg, color, depth, alpha, st.n_contrib);
 }

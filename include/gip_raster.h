@@ -137,6 +137,7 @@ typedef struct GipRasterStateLayout {
   size_t block_offset; /* [V*ceil(P/256)+1] u32 */
   size_t keys;         /* [capacity] u64 sorted per tile: (depth_bits << 32) | gaussian_index */
   size_t n_contrib;    /* [V,H,W] u32 */
+  size_t tile_order;   /* [V*T] u32: tile ids, longest lists first (launch order of the render kernels) */
   size_t total;        /* total bytes */
   uint32_t tiles_x, tiles_y, num_blocks, reserved;
 } GipRasterStateLayout;
