@@ -35,7 +35,7 @@ class GipRasterOutputs(ctypes.Structure):
 
 
 class GipRasterGradsIn(ctypes.Structure):
-    _fields_ = [(n, _vp) for n in ("dL_dcolor", "dL_ddepth", "dL_dalpha", "alpha")]
+    _fields_ = [(n, _vp) for n in ("dL_dcolor", "dL_ddepth", "dL_dalpha", "alpha", "color", "depth")]
 
 
 class GipRasterGradsOut(ctypes.Structure):
@@ -46,7 +46,7 @@ class GipRasterGradsOut(ctypes.Structure):
 class GipRasterStateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in ("header", "records", "inst_offset", "tile_count", "tile_start",
                                                 "tile_cursor", "block_sums", "block_offset", "keys", "n_contrib",
-                                                "tile_order", "total")] + \
+                                                "final_T", "tile_order", "seg_start", "ckpt_start", "seg_tile", "checkpoints", "total")] + \
                [(n, ctypes.c_uint32) for n in ("tiles_x", "tiles_y", "num_blocks", "reserved")]
 
 

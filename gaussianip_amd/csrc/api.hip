@@ -46,7 +46,13 @@ extern "C" int gip_raster_state_layout(const GipRasterConfig* c, GipRasterStateL
   L->records = off;      off = align256(off + V * P * GIP_RECORD_BYTES);
   L->inst_offset = off;  off = align256(off + V * P * 4);
   L->n_contrib = off;    off = align256(off + V * (size_t)c->H * c->W * 4);
+  L->final_T = off;      off = align256(off + V * (size_t)c->H * c->W * 4);
   L->tile_order = off;   off = align256(off + V * T * 4);
+  const size_t ckpt_cap = (size_t)c->capacity / GIP_SEGMENT + 1, seg_cap = ckpt_cap + V * T;
+  L->seg_start = off;    off = align256(off + (V * T + 1) * 4);
+  L->ckpt_start = off;   off = align256(off + (V * T + 1) * 4);
+  L->seg_tile = off;     off = align256(off + seg_cap * 4);
+  L->checkpoints = off;  off = align256(off + ckpt_cap * GIP_CKPT_FLOATS * 256 * sizeof(float));
   L->keys = off;         off = align256(off + (size_t)c->capacity * 8);
   L->total = off;
   return GIP_OK;
@@ -71,6 +77,8 @@ static void fill_params(const GipRasterConfig* c, const GipRasterStateLayout& L,
   kp->D = c->sh_degree; kp->M = c->sh_coeffs;
   kp->scale_modifier = c->scale_modifier;
   kp->capacity = (uint32_t)c->capacity;
+  kp->ckpt_capacity = (uint32_t)(c->capacity / GIP_SEGMENT + 1);
+  kp->seg_capacity = kp->ckpt_capacity + (uint32_t)(kp->V * kp->T);
   for (int v = 0; v < c->V; v++) {
     kp->view[v].tanfovx = c->tanfovx[v];
     kp->view[v].tanfovy = c->tanfovy[v];
@@ -92,7 +100,12 @@ static GipStatePtrs state_ptrs(void* state, const GipRasterStateLayout& L) {
   p.block_offset = (uint32_t*)(b + L.block_offset);
   p.keys = (unsigned long long*)(b + L.keys);
   p.n_contrib = (uint32_t*)(b + L.n_contrib);
+  p.final_T = (float*)(b + L.final_T);
   p.tile_order = (uint32_t*)(b + L.tile_order);
+  p.seg_start = (uint32_t*)(b + L.seg_start);
+  p.ckpt_start = (uint32_t*)(b + L.ckpt_start);
+  p.seg_tile = (uint32_t*)(b + L.seg_tile);
+  p.checkpoints = (float*)(b + L.checkpoints);
   return p;
 }
 
@@ -203,7 +216,7 @@ static int backward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, 
   if (!valid_config(cfg)) return GIP_ERR_BAD_ARGUMENT;
   int rc = check_inputs(cfg, in);
   if (rc != GIP_OK) return rc;
-  if (!gin || !gin->alpha || !gout || !state || !scratch) return GIP_ERR_BAD_ARGUMENT;
+  if (!gin || !gin->alpha || !gin->color || !gin->depth || !gout || !state || !scratch) return GIP_ERR_BAD_ARGUMENT;
   GipRasterStateLayout L;
   gip_raster_state_layout(cfg, &L);
   if (state_bytes < L.total || scratch_bytes < gip_raster_scratch_bytes(cfg)) return GIP_ERR_BUFFER_TOO_SMALL;

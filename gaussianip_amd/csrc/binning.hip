@@ -22,90 +22,149 @@
 // scan: one workgroup of 1024 threads, each thread owns a contiguous chunk
 // ------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
+#define SCAN_WAVES (SCAN_THREADS / 64)
 
-__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_wave /*[16]*/, uint32_t* total) {
+struct U3 { uint32_t a, b, c; };
+
+// exclusive scan of three quantities at once across the 1024 threads
+__device__ __forceinline__ U3 block_excl_scan3(U3 v, uint32_t (*s_wave)[SCAN_WAVES], U3* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = gip_wave_incl_scan_u32(v);
-  if (lane == 63) s_wave[wave] = incl;
+  U3 incl = {gip_wave_incl_scan_u32(v.a), gip_wave_incl_scan_u32(v.b), gip_wave_incl_scan_u32(v.c)};
+  if (lane == 63) { s_wave[0][wave] = incl.a; s_wave[1][wave] = incl.b; s_wave[2][wave] = incl.c; }
   __syncthreads();
-  uint32_t base = 0, tot = 0;
+  U3 base = {0, 0, 0}, tot = {0, 0, 0};
 #pragma unroll
-  for (int w = 0; w < SCAN_THREADS / 64; w++) {
-    uint32_t x = s_wave[w];
-    if (w < wave) base += x;
-    tot += x;
+  for (int w = 0; w < SCAN_WAVES; w++) {
+    const uint32_t xa = s_wave[0][w], xb = s_wave[1][w], xc = s_wave[2][w];
+    if (w < wave) { base.a += xa; base.b += xb; base.c += xc; }
+    tot.a += xa; tot.b += xb; tot.c += xc;
   }
   __syncthreads();
   *total = tot;
-  return base + incl - v;
+  return {base.a + incl.a - v.a, base.b + incl.b - v.b, base.c + incl.c - v.c};
 }
 
-__device__ void scan_array(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, uint32_t* s_wave,
-                           uint32_t* total_out, uint32_t* max_out) {
-  const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
-  const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
-  uint32_t sum = 0, mx = 0;
-  for (int i = lo; i < hi; i++) { uint32_t x = in[i]; sum += x; mx = x > mx ? x : mx; }
-  uint32_t total;
-  uint32_t run = block_excl_scan_1024(sum, s_wave, &total);
-  for (int i = lo; i < hi; i++) { uint32_t x = in[i]; out[i] = run; run += x; }
-  if (threadIdx.x == 0) out[n] = total;
-  *total_out = total;
-  if (max_out) {
-    mx = gip_wave_max_u32(mx);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    uint32_t m = 0;
-    for (int w = 0; w < SCAN_THREADS / 64; w++) m = s_wave[w] > m ? s_wave[w] : m;
-    __syncthreads();
-    *max_out = m;
-  }
-}
+__device__ __forceinline__ uint32_t nseg_of(uint32_t count) { return (count + GIP_SEGMENT - 1) / GIP_SEGMENT; }
+__device__ __forceinline__ int bucket_of(uint32_t c) { return c ? 32 - __clz(c) : 0; }
 
-// Launch order for the per-tile kernels: tiles bucketed by floor(log2(count)) and emitted longest
-// bucket first, so the long lists start early and the short ones fill the tail.  Order inside a bucket
-// is arbitrary (it only decides which workgroup id renders which tile; results do not depend on it).
+// Launch order for the per-tile kernels: tiles bucketed by floor(log2(count)) and emitted longest bucket
+// first, so the long lists start early and the short ones fill the tail.  Order inside a bucket is arbitrary
+// (it only decides which workgroup renders which tile; results do not depend on it).  Wave-aggregated:
+// one LDS atomic per (wave, bucket present) instead of one per tile.
 __device__ void heavy_first_order(const uint32_t* __restrict__ counts, uint32_t* __restrict__ order, int n,
-                                  uint32_t* s_bucket /*[33]*/) {
+                                  uint32_t* s_bucket /*[33]*/, uint32_t* class_end /*[4] out, thread 0*/) {
+  const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 33; i += SCAN_THREADS) s_bucket[i] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
-    const uint32_t c = counts[i];
-    atomicAdd(&s_bucket[c ? 32 - __clz(c) : 0], 1u);
+  const int rounds = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+  for (int r = 0; r < rounds; r++) {
+    const int i = r * SCAN_THREADS + threadIdx.x;
+    const int b = i < n ? bucket_of(counts[i]) : -1;
+    unsigned long long pending = __ballot(b >= 0);
+    while (pending) {
+      const int leader = __builtin_ctzll(pending);
+      const int lb = __shfl(b, leader, 64);
+      const unsigned long long m = __ballot(b == lb);
+      if (lane == leader) atomicAdd(&s_bucket[lb], (uint32_t)__popcll(m));
+      pending &= ~m;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t run = 0;
-    for (int b = 32; b >= 0; b--) { uint32_t c = s_bucket[b]; s_bucket[b] = run; run += c; }
+    for (int b = 32; b >= 0; b--) {
+      const uint32_t c = s_bucket[b];
+      s_bucket[b] = run;
+      run += c;
+      // sort classes: >= 8192 (bucket >= 14) | 2048..8191 (12,13) | 1024..2047 (11) | 1..1023 (1..10)
+      if (b == 14) class_end[0] = run;
+      if (b == 12) class_end[1] = run;
+      if (b == 11) class_end[2] = run;
+      if (b == 1) class_end[3] = run;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
-    const uint32_t c = counts[i];
-    order[atomicAdd(&s_bucket[c ? 32 - __clz(c) : 0], 1u)] = (uint32_t)i;
+  for (int r = 0; r < rounds; r++) {
+    const int i = r * SCAN_THREADS + threadIdx.x;
+    const int b = i < n ? bucket_of(counts[i]) : -1;
+    unsigned long long pending = __ballot(b >= 0);
+    while (pending) {
+      const int leader = __builtin_ctzll(pending);
+      const int lb = __shfl(b, leader, 64);
+      const unsigned long long m = __ballot(b == lb);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&s_bucket[lb], (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (b == lb) order[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+      pending &= ~m;
+    }
   }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                uint32_t* __restrict__ seg_start, uint32_t* __restrict__ ckpt_start, uint32_t* __restrict__ seg_tile,
                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offset,
                 uint32_t* __restrict__ tile_order, GipRasterHeader* __restrict__ header) {
-  __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+  __shared__ uint32_t s_wave[3][SCAN_WAVES];
   __shared__ uint32_t s_bucket[33];
-  uint32_t total_tiles, max_tile, total_inst;
-  scan_array(tile_count, tile_start, kp.V * kp.T, s_wave, &total_tiles, &max_tile);
-  scan_array(block_sums, block_offset, kp.V * kp.nblk, s_wave, &total_inst, nullptr);
-  heavy_first_order(tile_count, tile_order, kp.V * kp.T, s_bucket);
+  __shared__ uint32_t s_class[4];
+  // ---- tiles: instance ranges, segment ranges, checkpoint slots (one pass, three running sums) ----
+  const int n = kp.V * kp.T;
+  const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+  const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
+  U3 sum = {0, 0, 0};
+  uint32_t mx = 0;
+  for (int i = lo; i < hi; i++) {
+    const uint32_t c = tile_count[i], a = nseg_of(c);
+    sum.a += c; sum.b += a; sum.c += a ? a - 1 : 0;
+    mx = c > mx ? c : mx;
+  }
+  U3 total;
+  U3 run = block_excl_scan3(sum, s_wave, &total);
+  for (int i = lo; i < hi; i++) {
+    const uint32_t c = tile_count[i], a = nseg_of(c);
+    tile_start[i] = run.a; seg_start[i] = run.b; ckpt_start[i] = run.c;
+    for (uint32_t b = 0; b < a; b++)
+      if (run.b + b < kp.seg_capacity) seg_tile[run.b + b] = (uint32_t)i;
+    run.a += c; run.b += a; run.c += a ? a - 1 : 0;
+  }
+  if (threadIdx.x == 0) { tile_start[n] = total.a; seg_start[n] = total.b; ckpt_start[n] = total.c; }
+  mx = gip_wave_max_u32(mx);
+  if ((threadIdx.x & 63) == 0) s_wave[0][threadIdx.x >> 6] = mx;
+  __syncthreads();
+  uint32_t max_tile = 0;
+  for (int w = 0; w < SCAN_WAVES; w++) max_tile = s_wave[0][w] > max_tile ? s_wave[0][w] : max_tile;
+  __syncthreads();
+  // ---- Gaussians: per-workgroup sums of tiles_touched -> instance offsets ----
+  {
+    const int nb = kp.V * kp.nblk;
+    const int ch = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int l2 = threadIdx.x * ch, h2 = min(nb, l2 + ch);
+    U3 s2 = {0, 0, 0};
+    for (int i = l2; i < h2; i++) s2.a += block_sums[i];
+    U3 t2;
+    U3 r2 = block_excl_scan3(s2, s_wave, &t2);
+    for (int i = l2; i < h2; i++) { block_offset[i] = r2.a; r2.a += block_sums[i]; }
+    if (threadIdx.x == 0) block_offset[nb] = t2.a;
+  }
+  heavy_first_order(tile_count, tile_order, n, s_bucket, s_class);
+  __syncthreads();
   if (threadIdx.x == 0) {
     header->abi_version = GIP_ABI_VERSION;
-    header->num_rendered = total_tiles;   // == total_inst
-    header->overflow = (total_tiles > kp.capacity) ? 1u : 0u;
+    header->num_rendered = total.a;
+    header->overflow = (total.a > kp.capacity) ? 1u : 0u;
     header->max_tile_count = max_tile;
+    header->num_segments = total.b;
+    header->num_checkpoints = total.c;
+    header->class_end[0] = s_class[0]; header->class_end[1] = s_class[1];
+    header->class_end[2] = s_class[2]; header->class_end[3] = s_class[3];
   }
 }
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   hipLaunchKernelGGL(gip_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, kp, st.tile_count, st.tile_start,
-                     st.block_sums, st.block_offset, st.tile_order, st.header);
+                     st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,33 +243,41 @@ __device__ __forceinline__ void bitonic_any_n(PtrT a, uint32_t n) {
   }
 }
 
-// CAP > 0: sort in LDS, handles tiles with LO < n <= CAP.  CAP == 0: in place in global memory, n > LO.
-template <int CAP, int LO>
+// One class of tile sizes per launch; the classes are contiguous ranges of tile_order (written by the scan
+// kernel into header->class_end), walked grid-stride by a small persistent grid so that no workgroup is
+// launched for tiles outside the class.  CAP > 0: sort in LDS.  CAP == 0: in place in global memory.
+template <int CAP, int CLS>
 __global__ void __launch_bounds__(GIP_BLOCK)
-gip_tile_sort_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys) {
-  const uint32_t t = blockIdx.x;
-  const uint32_t start = tile_start[t];
-  uint32_t end = tile_start[t + 1];
-  if (end > kp.capacity) end = kp.capacity;
-  if (end <= start) return;
-  const uint32_t n = end - start;
-  if (n <= (uint32_t)LO) return;
-  if (CAP > 0) {
-    if (n > (uint32_t)CAP) return;
-    __shared__ unsigned long long s_keys[CAP > 0 ? CAP : 1];
-    for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) s_keys[i] = keys[start + i];
-    __syncthreads();
-    bitonic_any_n(s_keys, n);
-    for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) keys[start + i] = s_keys[i];
-  } else {
-    __threadfence_block();
-    bitonic_any_n(keys + start, n);
+gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
+                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys) {
+  const uint32_t pos_lo = CLS == 0 ? 0u : header->class_end[CLS - 1];
+  const uint32_t pos_hi = header->class_end[CLS];
+  __shared__ unsigned long long s_keys[CAP > 0 ? CAP : 1];
+  for (uint32_t pos = pos_lo + blockIdx.x; pos < pos_hi; pos += gridDim.x) {
+    const uint32_t t = tile_order[pos];
+    const uint32_t start = tile_start[t];
+    uint32_t end = tile_start[t + 1];
+    if (end > kp.capacity) end = kp.capacity;
+    if (end <= start + 1) continue;
+    const uint32_t n = end - start;
+    if (CAP > 0) {
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) s_keys[i] = keys[start + i];
+      __syncthreads();
+      bitonic_any_n(s_keys, n);
+      for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) keys[start + i] = s_keys[i];
+    } else {
+      __threadfence_block();
+      bitonic_any_n(keys + start, n);
+      __syncthreads();
+    }
   }
 }
 
 void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  const dim3 grid(kp.V * kp.T), block(GIP_BLOCK);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<1024, 1>), grid, block, 0, s, kp, st.tile_start, st.keys);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<8192, 1024>), grid, block, 0, s, kp, st.tile_start, st.keys);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<0, 8192>), grid, block, 0, s, kp, st.tile_start, st.keys);
+  const dim3 block(GIP_BLOCK);
+  hipLaunchKernelGGL((gip_tile_sort_kernel<0, 0>), dim3(256), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
+  hipLaunchKernelGGL((gip_tile_sort_kernel<8192, 1>), dim3(512), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
+  hipLaunchKernelGGL((gip_tile_sort_kernel<2048, 2>), dim3(1024), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
+  hipLaunchKernelGGL((gip_tile_sort_kernel<1024, 3>), dim3(2048), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
 }

@@ -33,6 +33,8 @@ struct GipKernelParams {
   int D, M;
   float scale_modifier;
   uint32_t capacity;
+  uint32_t seg_capacity;    // capacity / GIP_SEGMENT + V*T
+  uint32_t ckpt_capacity;   // capacity / GIP_SEGMENT
   GipViewConst view[GIP_MAX_VIEWS];
 };
 
@@ -47,7 +49,12 @@ struct GipStatePtrs {
   uint32_t* block_offset;   // [V*nblk+1]
   unsigned long long* keys; // [capacity]
   uint32_t* n_contrib;      // [V,H,W]
+  float* final_T;           // [V,H,W]
   uint32_t* tile_order;     // [V*T] heavy-first launch order
+  uint32_t* seg_start;      // [V*T+1]
+  uint32_t* ckpt_start;     // [V*T+1]
+  uint32_t* seg_tile;       // [seg_capacity]
+  float* checkpoints;       // [ckpt_capacity][5][256]
 };
 
 // --- launchers implemented in the .hip translation units -----------------------------------------

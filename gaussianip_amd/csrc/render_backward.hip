@@ -1,26 +1,33 @@
-// render_backward.hip — per-pixel reverse-order replay + wavefront segmented reduction (gfx950).
+// render_backward.hip — segment-parallel backward of the blend + wavefront segmented reduction (gfx950).
 //
-// Replaces the fork's backward renderCUDA<3> (SURVEY.md §2.1 "bwd 1").  The reference lets every
-// pixel thread atomicAdd nine floats per (pixel, Gaussian) pair into per-Gaussian accumulators — the
-// contention hot spot named in SURVEY.md §8a3.  Here no float atomic is issued at all:
+// Replaces the fork's backward renderCUDA<3> (SURVEY.md §2.1 "bwd 1").  The reference walks every
+// tile's list back to front, one thread per pixel, and atomicAdds nine floats per (pixel, Gaussian)
+// pair into per-Gaussian accumulators (the contention hot spot of SURVEY.md §8a3); the walk is serial
+// per tile, so the longest list sets the kernel time.
 //
-//   * a workgroup (4 x wave64, one 8x8 pixel quadrant per wave) walks its tile's depth-sorted list
-//     back to front in batches staged through LDS;
-//   * for each list entry every wave that has at least one contributing pixel reduces the ten
-//     per-pixel gradient terms across its 64 lanes with DPP row-shift / row-broadcast adds (no LDS
-//     traffic), and one lane deposits the wave's sums in LDS;
-//   * after the batch the four wave slots are added in fixed order and written as ONE 64-byte row per
-//     (tile, Gaussian) instance at row index inst_offset[g] + (tile's position inside g's rectangle).
-//
-// A Gaussian's rows are therefore contiguous and the follow-up kernel (gather_backward.hip) sums them
-// in a fixed order: gradients are bitwise reproducible run to run, unlike the atomic formulation.
+// MI355X-first formulation:
+//   * NO serial walk.  The forward kernel checkpoints the per-pixel blend state (T, C, D) every
+//     GIP_SEGMENT = 256 list entries.  With kappa_j = c_j.gC + d_j gD, S_tot = C_tot.gC + D_tot gD and the
+//     running prefix Sp_{j+1} = sum_{k<=j} a_k T_k kappa_k, the gradient of entry j is
+//         dL/dalpha_j = T_j kappa_j + [Sp_{j+1} - S_tot + T_final (gA - bg.gC)] / (1 - a_j)
+//     which is algebraically the reference's back-to-front recurrence (its accum_rec is
+//     (C_tot - Cp_{j+1}) / T_{j+1} and its 1 - accum_alpha is T_final / T_{j+1}).  Every (tile, segment)
+//     is therefore an independent, equally sized work item; a persistent grid walks the flat segment list.
+//   * NO float atomics.  Each wave (one 8x8 pixel quadrant) reduces the ten per-pixel terms of an entry
+//     across its 64 lanes in 27 cross-lane ops (v_permlane32_swap, v_permlane16_swap, DPP row shifts),
+//     the four waves' sums are added in fixed order, and ONE 64-byte row per (tile, Gaussian) instance
+//     is stored at row inst_offset[g] + (tile's position in g's rectangle).  gather_backward.hip sums a
+//     Gaussian's contiguous rows in fixed order: gradients are bitwise reproducible.
+//   * entries whose alpha >= 1/255 ellipse misses a wave's quadrant are skipped by that wave (same
+//     conservative quadrant mask as the forward kernel).
 //
 // Row layout (floats): 0,1 dL/dmean2D.xy (NDC units)  2,3,4 dL/dconic (x, y, w slots)  5 dL/dopacity
 //                      6,7,8 dL/dcolour  9 dL/ddepth  10..15 zero
 #include "gip_internal.h"
 
-#define BWD_BATCH 128
-#define BWD_NV 12   // floats kept per (wave, entry) slot; 10 used
+#define BWD_SUB 128   // entries staged per LDS sub-batch (two per segment)
+#define BWD_NV 12     // floats kept per (wave, entry) slot; 10 used
+#define BWD_GRID 2048 // persistent workgroups
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -49,181 +56,207 @@ __device__ __forceinline__ float row_reduce(float v) {
 }
 
 __global__ void __launch_bounds__(GIP_BLOCK)
-gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_order,
-                           const uint32_t* __restrict__ tile_start,
-                           const unsigned long long* __restrict__ keys, const GipRecord* __restrict__ records,
-                           const uint32_t* __restrict__ inst_offset, const float* __restrict__ bg,
-                           const uint32_t* __restrict__ n_contrib, const float* __restrict__ alpha_out,
-                           const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                           const float* __restrict__ dL_dalpha_in, float* __restrict__ partial) {
-  const uint32_t vt = tile_order[blockIdx.x];
-  const uint32_t start = tile_start[vt];
-  uint32_t end = tile_start[vt + 1];
-  if (end > kp.capacity) end = kp.capacity;
-  if (end <= start) return;
-  const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
-  const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
-  const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
-  const bool inside = px < kp.W && py < kp.H;
-  const float pxf = (float)px, pyf = (float)py;
-  const float tile_x0 = (float)(tx * GIP_TILE), tile_y0 = (float)(ty * GIP_TILE);
-  const int n = (int)(end - start);
-  const GipRecord* recs = records + (size_t)v * kp.P;
-  const uint32_t* ioff = inst_offset + (size_t)v * kp.P;
-
-  __shared__ float2 s_xy[BWD_BATCH];
-  __shared__ float4 s_con[BWD_BATCH];
-  __shared__ float4 s_col[BWD_BATCH];
-  __shared__ uint32_t s_row[BWD_BATCH];
-  __shared__ uint32_t s_mask[BWD_BATCH];
-  __shared__ float s_part[4][BWD_BATCH][BWD_NV];
+gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ header,
+                           const uint32_t* __restrict__ seg_tile, const uint32_t* __restrict__ seg_start,
+                           const uint32_t* __restrict__ ckpt_start, const float* __restrict__ checkpoints,
+                           const uint32_t* __restrict__ tile_start, const unsigned long long* __restrict__ keys,
+                           const GipRecord* __restrict__ records, const uint32_t* __restrict__ inst_offset,
+                           const float* __restrict__ bg, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
+                           const float* __restrict__ color_out, const float* __restrict__ depth_out,
+                           const float* __restrict__ alpha_out, const float* __restrict__ dL_dcolor,
+                           const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_in,
+                           float* __restrict__ partial) {
+  __shared__ float2 s_xy[BWD_SUB];
+  __shared__ float4 s_con[BWD_SUB];
+  __shared__ float4 s_col[BWD_SUB];
+  __shared__ uint32_t s_row[BWD_SUB];
+  __shared__ uint32_t s_mask[BWD_SUB];
+  __shared__ float s_part[4][BWD_SUB][BWD_NV];
   __shared__ uint32_t s_max[4];
 
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t HW = (size_t)kp.H * kp.W;
-  const size_t pix = (size_t)py * kp.W + px;
-  float T_final = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f;
-  uint32_t last_contributor = 0;
-  if (inside) {
-    T_final = 1.f - alpha_out[(size_t)v * HW + pix];
-    last_contributor = n_contrib[(size_t)v * HW + pix];
-    if (dL_dcolor) {
-      const float* p = dL_dcolor + (size_t)v * 3 * HW;
-      g0 = p[pix]; g1 = p[HW + pix]; g2 = p[2 * HW + pix];
-    }
-    if (dL_ddepth) gd = dL_ddepth[(size_t)v * HW + pix];
-    if (dL_dalpha_in) ga = dL_dalpha_in[(size_t)v * HW + pix];
-  }
-  const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
   const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  uint32_t nseg = header->num_segments;
+  if (nseg > kp.seg_capacity) nseg = kp.seg_capacity;
 
-  // longest replay needed by any pixel of the tile
-  const int wave_maxc = (int)gip_wave_max_u32(last_contributor);
-  if (lane == 0) s_max[wave] = (uint32_t)wave_maxc;
-  __syncthreads();
-  const int maxc = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+  for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const uint32_t vt = seg_tile[seg];
+    const uint32_t b = seg - seg_start[vt];              // segment index inside the tile
+    const uint32_t start = tile_start[vt];
+    uint32_t end = tile_start[vt + 1];
+    if (end > kp.capacity) end = kp.capacity;
+    if (end < start) end = start;
+    const int first = (int)(b * GIP_SEGMENT);            // list positions [first, last) of this segment
+    const int last = min((int)(end - start), first + GIP_SEGMENT);
+    const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
+    const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
+    const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
+    const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
+    const bool inside = px < kp.W && py < kp.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float tile_x0 = (float)(tx * GIP_TILE), tile_y0 = (float)(ty * GIP_TILE);
+    const GipRecord* recs = records + (size_t)v * kp.P;
+    const uint32_t* ioff = inst_offset + (size_t)v * kp.P;
+    const size_t pix1 = (size_t)py * kp.W + px;           // within one image plane
+    const size_t pix = (size_t)v * HW + pix1;
 
-  float T = T_final;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f, acca = 0.f;
-  float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
-
-  for (int hi = n; hi > 0; hi -= BWD_BATCH) {
-    const int lo = max(0, hi - BWD_BATCH);
-    const int cnt = hi - lo;
-    __syncthreads();   // previous batch fully flushed
-    if ((int)threadIdx.x < cnt) {
-      const int i = hi - 1 - (int)threadIdx.x;   // slot j holds list entry hi-1-j: back to front
-      const uint32_t g = (uint32_t)keys[start + i];
-      const float4* rp = reinterpret_cast<const float4*>(recs + g);
-      const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
-      const uint4 q3 = reinterpret_cast<const uint4*>(recs + g)[3];
-      s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
-      s_con[threadIdx.x] = make_float4(q1.x, q1.y, q1.z, q0.w);
-      s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
-      const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
-      s_row[threadIdx.x] = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
-      // quadrant mask from the extent of { alpha >= 1/255 } (same conservative test as the forward kernel)
-      uint32_t mask = 0xf;
-      const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
-      const float det = q1.x * q1.z - q1.y * q1.y;
-      if (t2 <= 0.f || i >= maxc) {
-        mask = 0;
-      } else if (det > 0.f) {
-        const float inv = t2 / det;
-        const float hx = sqrtf(inv * q1.z) * 1.01f + 0.05f, hy = sqrtf(inv * q1.x) * 1.01f + 0.05f;
-        const float rx = q0.x - tile_x0, ry = q0.y - tile_y0;
-        const bool xl = rx - hx <= 7.f, xr = rx + hx >= 8.f, yt = ry - hy <= 7.f, yb = ry + hy >= 8.f;
-        mask = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
-      }
-      s_mask[threadIdx.x] = mask;
-    }
-    for (int e = threadIdx.x; e < 4 * BWD_BATCH * BWD_NV; e += GIP_BLOCK) (&s_part[0][0][0])[e] = 0.f;
+    const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
+    const int wave_maxc = (int)gip_wave_max_u32(last_contributor);
+    __syncthreads();                                      // previous work item is done with LDS
+    if (lane == 0) s_max[wave] = (uint32_t)wave_maxc;
     __syncthreads();
+    const int maxc = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    if (first >= maxc) {
+      // no pixel blended anything of this segment: its rows are all zero
+      for (int e = threadIdx.x; e < (last - first) * 4; e += GIP_BLOCK) {
+        const int i = first + (e >> 2), q = e & 3;
+        const uint32_t g = (uint32_t)keys[start + i];
+        const uint4 q3 = reinterpret_cast<const uint4*>(recs + g)[3];
+        const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
+        const uint32_t row = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
+        if (row < kp.capacity)
+          reinterpret_cast<float4*>(partial + (size_t)row * GIP_PARTIAL_FLOATS)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      continue;
+    }
 
-    if (lo < wave_maxc) {
-      for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int e = c0 + lane;
-        const bool want = e < cnt && ((s_mask[e] >> wave) & 1u) && (hi - 1 - e) < wave_maxc;
-        unsigned long long m = __ballot(want);
-        while (m) {
-          const int j = c0 + __builtin_ctzll(m);
-          m &= m - 1;
-          const int i = hi - 1 - j;
-          const float2 xy = s_xy[j];
-          const float4 co = s_con[j];
-          const float dx = xy.x - pxf, dy = xy.y - pyf;
-          const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-          const float G = __expf(power);
-          const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
-          const bool c = (uint32_t)i < last_contributor && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
-          if (!__any(c)) continue;                      // uniform over the wave
-          float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
-          if (c) {
-            const float4 cl = s_col[j];
-            const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-            T = T * rcp1ma;
-            const float dchannel_dcolor = alpha * T;
-            float dL_dalpha;
-            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = cl.x;
-            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = cl.y;
-            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = cl.z;
-            dL_dalpha = (cl.x - acc0) * g0 + (cl.y - acc1) * g1 + (cl.z - acc2) * g2;
-            v6 = dchannel_dcolor * g0; v7 = dchannel_dcolor * g1; v8 = dchannel_dcolor * g2;
-            accd = last_alpha * last_depth + (1.f - last_alpha) * accd; last_depth = cl.w;
-            dL_dalpha += (cl.w - accd) * gd;
-            v9 = dchannel_dcolor * gd;
-            acca = last_alpha + (1.f - last_alpha) * acca;
-            dL_dalpha += (1.f - acca) * ga;
-            dL_dalpha *= T;
-            last_alpha = alpha;
-            dL_dalpha += (-T_final * rcp1ma) * bg_dot;
-            const float dL_dG = co.w * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            v0 = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
-            v1 = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
-            v2 = -0.5f * gdx * dx * dL_dG;
-            v3 = -0.5f * gdx * dy * dL_dG;
-            v4 = -0.5f * gdy * dy * dL_dG;
-            v5 = G * dL_dalpha;
-          }
-          // 64-lane sums of the ten terms in 27 cross-lane ops: fold halves (permlane32_swap), fold row
-          // pairs (permlane16_swap), then one DPP row reduction per packed register.
-          const float p02 = fold32(v0, v2), p13 = fold32(v1, v3);   // [v0|v2], [v1|v3]
-          const float p46 = fold32(v4, v6), p57 = fold32(v5, v7);
-          const float p89 = fold32(v8, v9);
-          float qa = fold16(p02, p13);   // rows: v0, v1, v2, v3
-          float qb = fold16(p46, p57);   // rows: v4, v5, v6, v7
-          qa = row_reduce(qa);
-          qb = row_reduce(qb);
-          float qc = row_reduce(p89);    // rows 0,1: v8 ; rows 2,3: v9
-          qc = dpp_add<0x142, 0xa>(qc);  // row_bcast:15 -> lane 31 = v8, lane 63 = v9
-          if ((lane & 15) == 15) {
-            const int r = lane >> 4;
-            float* dst = &s_part[wave][j][0];
-            dst[r] = qa;
-            dst[4 + r] = qb;
-            if (r & 1) dst[8 + (r >> 1)] = qc;
-          }
+    // per-pixel constants and the blend state at the segment start
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f;
+    float T = 1.f, Sp = 0.f, Kc = 0.f;   // Kc = T_final (gA - bg.gC) - S_tot
+    if (inside) {
+      // The fork's backward re-derives every T_j from T_final := 1 - alpha_out (not from the forward's own
+      // final T), i.e. all its T_j carry the factor rho = (1 - alpha_out) / final_T.  Reproduce that.
+      const float T_final = 1.f - alpha_out[pix];
+      const float Tf_fwd = final_T[pix];
+      const float rho = T_final / Tf_fwd;
+      if (dL_dcolor) {
+        const float* p = dL_dcolor + (size_t)v * 3 * HW + pix1;
+        g0 = p[0]; g1 = p[HW]; g2 = p[2 * HW];
+      }
+      if (dL_ddepth) gd = dL_ddepth[pix];
+      if (dL_dalpha_in) ga = dL_dalpha_in[pix];
+      const float* co = color_out + (size_t)v * 3 * HW + pix1;
+      // C_tot = colour output minus the background term the forward added
+      const float ct0 = co[0] - Tf_fwd * bg0, ct1 = co[HW] - Tf_fwd * bg1, ct2 = co[2 * HW] - Tf_fwd * bg2;
+      const float Stot = ct0 * g0 + ct1 * g1 + ct2 * g2 + depth_out[pix] * gd;
+      Kc = T_final * (ga - (bg0 * g0 + bg1 * g1 + bg2 * g2)) - rho * Stot;
+      T = rho;
+      if (b > 0) {
+        const uint32_t slot = ckpt_start[vt] + b - 1;
+        if (slot < kp.ckpt_capacity) {
+          const float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * GIP_BLOCK) + threadIdx.x;
+          T = rho * cp[0];
+          Sp = rho * (cp[GIP_BLOCK] * g0 + cp[2 * GIP_BLOCK] * g1 + cp[3 * GIP_BLOCK] * g2 + cp[4 * GIP_BLOCK] * gd);
         }
       }
     }
-    __syncthreads();
-    // flush: 4 lanes per entry, one 16-byte quad each -> one 64-byte row per (tile, Gaussian)
-    for (int e = threadIdx.x; e < cnt * 4; e += GIP_BLOCK) {
-      const int j = e >> 2, q = e & 3;
-      const uint32_t row = s_row[j];
-      if (row < kp.capacity) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < 3) {
-          const float4 a = reinterpret_cast<const float4*>(&s_part[0][j][0])[q];
-          const float4 b = reinterpret_cast<const float4*>(&s_part[1][j][0])[q];
-          const float4 c4 = reinterpret_cast<const float4*>(&s_part[2][j][0])[q];
-          const float4 d = reinterpret_cast<const float4*>(&s_part[3][j][0])[q];
-          s.x = (a.x + b.x) + (c4.x + d.x); s.y = (a.y + b.y) + (c4.y + d.y);
-          s.z = (a.z + b.z) + (c4.z + d.z); s.w = (a.w + b.w) + (c4.w + d.w);
+
+    for (int sub = first; sub < last; sub += BWD_SUB) {
+      const int cnt = min(BWD_SUB, last - sub);
+      if (sub != first) __syncthreads();                  // previous sub-batch flushed
+      if ((int)threadIdx.x < cnt) {
+        const int i = sub + (int)threadIdx.x;
+        const uint32_t g = (uint32_t)keys[start + i];
+        const float4* rp = reinterpret_cast<const float4*>(recs + g);
+        const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+        const uint4 q3 = reinterpret_cast<const uint4*>(recs + g)[3];
+        s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
+        s_con[threadIdx.x] = make_float4(q1.x, q1.y, q1.z, q0.w);
+        s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
+        const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
+        s_row[threadIdx.x] = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
+        uint32_t mask = 0xf;
+        const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
+        const float det = q1.x * q1.z - q1.y * q1.y;
+        if (t2 <= 0.f || i >= maxc) {
+          mask = 0;
+        } else if (det > 0.f) {
+          const float inv = t2 / det;
+          const float hx = sqrtf(inv * q1.z) * 1.01f + 0.05f, hy = sqrtf(inv * q1.x) * 1.01f + 0.05f;
+          const float rx = q0.x - tile_x0, ry = q0.y - tile_y0;
+          const bool xl = rx - hx <= 7.f, xr = rx + hx >= 8.f, yt = ry - hy <= 7.f, yb = ry + hy >= 8.f;
+          mask = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
         }
-        reinterpret_cast<float4*>(partial + (size_t)row * GIP_PARTIAL_FLOATS)[q] = s;
+        s_mask[threadIdx.x] = mask;
+      }
+      for (int e = threadIdx.x; e < 4 * BWD_SUB * BWD_NV; e += GIP_BLOCK) (&s_part[0][0][0])[e] = 0.f;
+      __syncthreads();
+
+      if (sub < wave_maxc) {
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+          const int e = c0 + lane;
+          const bool want = e < cnt && ((s_mask[e] >> wave) & 1u) && (sub + e) < wave_maxc;
+          unsigned long long m = __ballot(want);
+          while (m) {
+            const int j = c0 + __builtin_ctzll(m);
+            m &= m - 1;
+            const int i = sub + j;
+            const float2 xy = s_xy[j];
+            const float4 co = s_con[j];
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
+            const bool c = (uint32_t)i < last_contributor && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
+            if (!__any(c)) continue;                      // uniform over the wave
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
+            if (c) {
+              const float4 cl = s_col[j];
+              const float w = alpha * T;                  // blend weight of this entry at this pixel
+              const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+              const float kappa = cl.x * g0 + cl.y * g1 + cl.z * g2 + cl.w * gd;
+              Sp += w * kappa;                            // prefix including this entry
+              const float dL_dalpha = T * kappa + (Sp + Kc) * rcp1ma;
+              T = T * (1.f - alpha);
+              v6 = w * g0; v7 = w * g1; v8 = w * g2; v9 = w * gd;
+              const float dL_dG = co.w * dL_dalpha;
+              const float gdx = G * dx, gdy = G * dy;
+              v0 = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
+              v1 = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
+              v2 = -0.5f * gdx * dx * dL_dG;
+              v3 = -0.5f * gdx * dy * dL_dG;
+              v4 = -0.5f * gdy * dy * dL_dG;
+              v5 = G * dL_dalpha;
+            }
+            // 64-lane sums of the ten terms in 27 cross-lane ops
+            const float p02 = fold32(v0, v2), p13 = fold32(v1, v3);   // [v0|v2], [v1|v3]
+            const float p46 = fold32(v4, v6), p57 = fold32(v5, v7);
+            const float p89 = fold32(v8, v9);
+            float qa = fold16(p02, p13);   // rows: v0, v1, v2, v3
+            float qb = fold16(p46, p57);   // rows: v4, v5, v6, v7
+            qa = row_reduce(qa);
+            qb = row_reduce(qb);
+            float qc = row_reduce(p89);    // rows 0,1: v8 ; rows 2,3: v9
+            qc = dpp_add<0x142, 0xa>(qc);  // row_bcast:15 -> lane 31 = v8, lane 63 = v9
+            if ((lane & 15) == 15) {
+              const int r = lane >> 4;
+              float* dst = &s_part[wave][j][0];
+              dst[r] = qa;
+              dst[4 + r] = qb;
+              if (r & 1) dst[8 + (r >> 1)] = qc;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // flush: 4 lanes per entry, one 16-byte quad each -> one 64-byte row per (tile, Gaussian)
+      for (int e = threadIdx.x; e < cnt * 4; e += GIP_BLOCK) {
+        const int j = e >> 2, q = e & 3;
+        const uint32_t row = s_row[j];
+        if (row < kp.capacity) {
+          float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (q < 3) {
+            const float4 a = reinterpret_cast<const float4*>(&s_part[0][j][0])[q];
+            const float4 bq = reinterpret_cast<const float4*>(&s_part[1][j][0])[q];
+            const float4 c4 = reinterpret_cast<const float4*>(&s_part[2][j][0])[q];
+            const float4 d = reinterpret_cast<const float4*>(&s_part[3][j][0])[q];
+            s.x = (a.x + bq.x) + (c4.x + d.x); s.y = (a.y + bq.y) + (c4.y + d.y);
+            s.z = (a.z + bq.z) + (c4.z + d.z); s.w = (a.w + bq.w) + (c4.w + d.w);
+          }
+          reinterpret_cast<float4*>(partial + (size_t)row * GIP_PARTIAL_FLOATS)[q] = s;
+        }
       }
     }
   }
@@ -231,8 +264,7 @@ gip_render_backward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile
 
 void gip_launch_render_backward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, const GipRasterGradsIn& gin,
                                 float* partial, hipStream_t s) {
-  hipLaunchKernelGGL(gip_render_backward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_order,
-                     st.tile_start, st.keys,
-                     st.records, st.inst_offset, bg, st.n_contrib, gin.alpha, gin.dL_dcolor, gin.dL_ddepth,
-                     gin.dL_dalpha, partial);
+  hipLaunchKernelGGL(gip_render_backward_kernel, dim3(BWD_GRID), dim3(GIP_BLOCK), 0, s, kp, st.header, st.seg_tile,
+                     st.seg_start, st.ckpt_start, st.checkpoints, st.tile_start, st.keys, st.records, st.inst_offset, bg,
+                     st.n_contrib, st.final_T, gin.color, gin.depth, gin.alpha, gin.dL_dcolor, gin.dL_ddepth, gin.dL_dalpha, partial);
 }

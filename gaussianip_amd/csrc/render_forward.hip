@@ -14,7 +14,9 @@
 //     alpha < 1/255 test, so skipping it cannot change any output;
 //   * each wave ballots the mask bits of its quadrant and walks only the set bits with scalar
 //     find-first-one, evaluating the surviving entries with a branch-free body (LDS broadcast reads,
-//     v_exp_f32, predicated accumulation), and leaves as soon as all 64 of its pixels have terminated.
+//     v_exp_f32, predicated accumulation), and leaves as soon as all 64 of its pixels have terminated;
+//   * at every 256-entry boundary the per-pixel blend state (T, C, D) is checkpointed (20 B / pixel) so
+//     that the backward pass needs no sequential walk over the tile.
 #include "gip_internal.h"
 
 __global__ void __launch_bounds__(GIP_BLOCK)
@@ -22,7 +24,8 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
                           const uint32_t* __restrict__ tile_start, const unsigned long long* __restrict__ keys,
                           const GipRecord* __restrict__ records, const float* __restrict__ bg,
                           float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                          uint32_t* __restrict__ n_contrib) {
+                          uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, const uint32_t* __restrict__ ckpt_start,
+                          float* __restrict__ checkpoints) {
   const uint32_t vt = tile_order[blockIdx.x];   // view * T + tile
   const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
   const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
@@ -50,6 +53,15 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
 
   for (uint32_t base = start; base < end; base += GIP_BLOCK) {
     if (__syncthreads_count(done) == GIP_BLOCK) break;
+    if (base != start) {
+      // blend state at the start of segment b >= 1: lets the backward replay every 256-entry segment of
+      // this tile as an independent work item (render_backward.hip)
+      const uint32_t slot = ckpt_start[vt] + (base - start) / GIP_SEGMENT - 1;
+      if (slot < kp.ckpt_capacity) {
+        float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * GIP_BLOCK) + threadIdx.x;
+        cp[0] = T; cp[GIP_BLOCK] = C0; cp[2 * GIP_BLOCK] = C1; cp[3 * GIP_BLOCK] = C2; cp[4 * GIP_BLOCK] = Dp;
+      }
+    }
     const uint32_t k = base + threadIdx.x;
     if (k < end) {
       const uint32_t g = (uint32_t)keys[k];
@@ -121,11 +133,13 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     out_depth[(size_t)v * HW + pix] = Dp;
     out_alpha[(size_t)v * HW + pix] = Wt;
     n_contrib[(size_t)v * HW + pix] = last_contributor;
+    final_T[(size_t)v * HW + pix] = T;
   }
 }
 
 void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth,
                                float* alpha, hipStream_t s) {
   hipLaunchKernelGGL(gip_render_forward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_order,
-                     st.tile_start, st.keys, st.records, bg, color, depth, alpha, st.n_contrib);
+                     st.tile_start, st.keys, st.records, bg, color, depth, alpha, st.n_contrib, st.final_T, st.ckpt_start,
+                     st.checkpoints);
 }

@@ -186,7 +186,7 @@ def _verify_pending(plan):
             "buffers synchronously like the reference does." % (num_rendered, cap))
 
 
-def _run_backward(plan, alpha, g_color, g_depth, g_alpha, want):
+def _run_backward(plan, outs, g_color, g_depth, g_alpha):
     lib = _lib.raster_lib()
     dev = plan.means3D.device
     V, P, M = plan.V, plan.P, plan.M
@@ -205,7 +205,8 @@ def _run_backward(plan, alpha, g_color, g_depth, g_alpha, want):
     ins = _lib.GipRasterInputs(_ptr(plan.means3D), _ptr(plan.shs), _ptr(plan.colors_precomp), _ptr(plan.opacities),
                                _ptr(plan.scales), _ptr(plan.rotations), _ptr(plan.cov3D_precomp),
                                _ptr(plan.viewmatrix), _ptr(plan.projmatrix), _ptr(plan.campos), _ptr(plan.bg))
-    gin = _lib.GipRasterGradsIn(_ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(alpha))
+    color, depth, alpha = outs
+    gin = _lib.GipRasterGradsIn(_ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(alpha), _ptr(color), _ptr(depth))
     gout = _lib.GipRasterGradsOut(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]),
                                   _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]),
                                   _ptr(g["cov3D_precomp"]))
@@ -265,14 +266,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         color, radii, depth, alpha = _forward_with_policy(plan, need_bwd and torch.is_grad_enabled())
         ctx.plan = plan
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
-        ctx.save_for_backward(alpha)
+        ctx.save_for_backward(color, depth, alpha)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, g_color, g_radii, g_depth, g_alpha):
         plan = ctx.plan
-        (alpha,) = ctx.saved_tensors
+        color, depth, alpha = ctx.saved_tensors
         _verify_pending(plan)
 
         def prep(g):
@@ -280,7 +281,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 return None
             return g.float().contiguous()
 
-        g = _run_backward(plan, alpha, prep(g_color), prep(g_depth), prep(g_alpha), None)
+        g = _run_backward(plan, (color, depth, alpha), prep(g_color), prep(g_depth), prep(g_alpha))
         g2d = None if ctx.means2D_shape is None else g["means2D"].reshape(ctx.means2D_shape)
         return (g["means3D"], g2d, g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"],
                 g["cov3D_precomp"], None)
@@ -401,7 +402,7 @@ def profile_stages(means3D, opacities, settings_list, g_color, g_depth=None, g_a
                                _ptr(plan.scales), _ptr(plan.rotations), _ptr(plan.cov3D_precomp),
                                _ptr(plan.viewmatrix), _ptr(plan.projmatrix), _ptr(plan.campos), _ptr(plan.bg))
     outs = _lib.GipRasterOutputs(_ptr(color), _ptr(radii), _ptr(depth), _ptr(alpha))
-    gin = _lib.GipRasterGradsIn(_ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(alpha))
+    gin = _lib.GipRasterGradsIn(_ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(alpha), _ptr(color), _ptr(depth))
     gout = _lib.GipRasterGradsOut(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), _ptr(g["colors"]),
                                   _ptr(g["opac"]), _ptr(g["scales"]), _ptr(g["rots"]), _ptr(g["cov"]))
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -43,6 +43,8 @@ extern "C" {
 #define GIP_MAX_VIEWS 16       /* views per call */
 #define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
 #define GIP_PARTIAL_FLOATS 16  /* per-(tile, Gaussian) gradient partial row, 64 bytes */
+#define GIP_SEGMENT 256        /* list entries per backward work item; forward checkpoints every GIP_SEGMENT entries */
+#define GIP_CKPT_FLOATS 5      /* per pixel per checkpoint: T, C.r, C.g, C.b, D */
 
 /* status codes */
 enum {
@@ -93,12 +95,15 @@ typedef struct GipRasterOutputs {
   float*   alpha;  /* [V,1,H,W] */
 } GipRasterOutputs;
 
-/* Upstream gradients (any may be null = zero) and saved forward output needed by backward. */
+/* Upstream gradients (any may be null = zero) and the forward outputs (all three required: the
+ * segment-parallel backward derives the blend suffix of every entry from the totals). */
 typedef struct GipRasterGradsIn {
   const float* dL_dcolor; /* [V,3,H,W] */
   const float* dL_ddepth; /* [V,1,H,W] */
   const float* dL_dalpha; /* [V,1,H,W] */
   const float* alpha;     /* [V,1,H,W] forward output `alpha` (final T = 1 - alpha) */
+  const float* color;     /* [V,3,H,W] forward output `color` */
+  const float* depth;     /* [V,1,H,W] forward output `depth` */
 } GipRasterGradsIn;
 
 /* Gradients w.r.t. the inputs, summed over the V views (means2D is per view).  Null = not wanted.
@@ -121,7 +126,10 @@ typedef struct GipRasterHeader {
   uint32_t overflow;       /* 1 if num_rendered > capacity: outputs are invalid, re-run with more */
   uint32_t max_tile_count; /* longest per-tile list */
   uint32_t num_visible;    /* Gaussians with radii > 0, over all views */
-  uint32_t reserved[11];
+  uint32_t num_segments;   /* sum over tiles of ceil(count / GIP_SEGMENT): work items of the backward replay */
+  uint32_t num_checkpoints;/* sum over tiles of max(segments - 1, 0) */
+  uint32_t class_end[4];   /* positions in tile_order where the per-tile-sort size classes end */
+  uint32_t reserved[5];
 } GipRasterHeader;
 
 /* Byte offsets of the sub-buffers inside `state` (for tests, debugging and parity checks of the
@@ -137,7 +145,12 @@ typedef struct GipRasterStateLayout {
   size_t block_offset; /* [V*ceil(P/256)+1] u32 */
   size_t keys;         /* [capacity] u64 sorted per tile: (depth_bits << 32) | gaussian_index */
   size_t n_contrib;    /* [V,H,W] u32 */
+  size_t final_T;      /* [V,H,W] f32: transmittance after the last blended entry (the fork's final_T) */
   size_t tile_order;   /* [V*T] u32: tile ids, longest lists first (launch order of the render kernels) */
+  size_t seg_start;    /* [V*T+1] u32: exclusive scan of per-tile segment counts */
+  size_t ckpt_start;   /* [V*T+1] u32: exclusive scan of per-tile checkpoint counts (segments - 1) */
+  size_t seg_tile;     /* [capacity/GIP_SEGMENT + V*T] u32: tile of each segment */
+  size_t checkpoints;  /* [capacity/GIP_SEGMENT][GIP_CKPT_FLOATS][256] f32: per-pixel blend state at segment starts */
   size_t total;        /* total bytes */
   uint32_t tiles_x, tiles_y, num_blocks, reserved;
 } GipRasterStateLayout;

@@ -433,7 +433,7 @@ static void render_backward(const oracle_ctx* c, const float* bg, const float* a
         if (px >= W || py >= H) continue;
         const int pix_id = W * py + px;
         const float pixf[2] = {(float)px, (float)py};
-        const float T_final = 1.f - alphas[pix_id];
+        const float T_final = getenv("ORACLE_EXACT_FINAL_T") ? c->final_T[pix_id] : 1.f - alphas[pix_id];
         float T = T_final;
         const uint32_t last_contributor = c->n_contrib[pix_id];
         float accum_rec[3] = {0, 0, 0}, accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
