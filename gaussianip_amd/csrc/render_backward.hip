@@ -27,7 +27,9 @@
 
 #define BWD_SUB 128   // entries staged per LDS sub-batch (two per segment)
 #define BWD_NV 12     // floats kept per (wave, entry) slot; 10 used
+#ifndef BWD_GRID
 #define BWD_GRID 2048 // persistent workgroups
+#endif
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
