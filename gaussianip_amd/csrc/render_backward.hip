@@ -13,22 +13,22 @@
 //     which is algebraically the reference's back-to-front recurrence (its accum_rec is
 //     (C_tot - Cp_{j+1}) / T_{j+1} and its 1 - accum_alpha is T_final / T_{j+1}).  Every (tile, segment)
 //     is therefore an independent, equally sized work item; a persistent grid walks the flat segment list.
-//   * NO float atomics.  Each wave (one 8x8 pixel quadrant) reduces the ten per-pixel terms of an entry
-//     across its 64 lanes in 27 cross-lane ops (v_permlane32_swap, v_permlane16_swap, DPP row shifts),
-//     the four waves' sums are added in fixed order, and ONE 64-byte row per (tile, Gaussian) instance
-//     is stored at row inst_offset[g] + (tile's position in g's rectangle).  gather_backward.hip sums a
-//     Gaussian's contiguous rows in fixed order: gradients are bitwise reproducible.
-//   * entries whose alpha >= 1/255 ellipse misses a wave's quadrant are skipped by that wave (same
-//     conservative quadrant mask as the forward kernel).
+//   * ONE WAVE per work item, four pixels per lane (one per 8x8 quadrant, as in the forward kernel): no
+//     workgroup barrier, no cross-wave LDS traffic, four-way ILP in the per-pixel math.
+//   * NO float atomics.  The ten per-pixel terms of an entry are first added over a lane's four pixels
+//     in registers, then reduced across the 64 lanes in 27 cross-lane ops (v_permlane32_swap,
+//     v_permlane16_swap, DPP row shifts), and ONE row per (tile, Gaussian) instance is stored at row
+//     inst_offset[g] + (tile's position in g's rectangle).  gather_backward.hip sums a Gaussian's
+//     contiguous rows in fixed order: gradients are bitwise reproducible.
+//   * quadrants that the entry's alpha >= 1/255 ellipse misses are skipped with wave-uniform branches
+//     (same conservative quadrant mask as the forward kernel).
 //
 // Row layout (floats): 0,1 dL/dmean2D.xy (NDC units)  2,3,4 dL/dconic (x, y, w slots)  5 dL/dopacity
 //                      6,7,8 dL/dcolour  9 dL/ddepth  10..15 zero
 #include "gip_internal.h"
 
-#define BWD_SUB 128   // entries staged per LDS sub-batch (two per segment)
-#define BWD_NV 12     // floats kept per (wave, entry) slot; 10 used
 #ifndef BWD_GRID
-#define BWD_GRID 2048 // persistent workgroups
+#define BWD_GRID 16384 // persistent single-wave workgroups (grid-stride over the segment list)
 #endif
 
 template <int CTRL, int ROW_MASK>
@@ -57,7 +57,43 @@ __device__ __forceinline__ float row_reduce(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(GIP_BLOCK)
+struct BwdPix {
+  float T, Sp, Kc, g0, g1, g2, gd;
+  uint32_t lastc;
+};
+
+struct BwdAcc { float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9; };
+
+__device__ __forceinline__ bool bwd_pair(BwdPix& p, BwdAcc& a, float pxf, float pyf, const float2 xy, const float4 co,
+                                         const float4 cl, uint32_t i, float ddelx_dx, float ddely_dy) {
+  const float dx = xy.x - pxf, dy = xy.y - pyf;
+  const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+  const float G = __expf(power);
+  const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
+  const bool c = i < p.lastc && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
+  // predicated (branch-free): a non-contributing pixel adds exact zeros and keeps its state
+  const float w = c ? alpha * p.T : 0.f;                  // blend weight of this entry at this pixel
+  const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+  const float kappa = cl.x * p.g0 + cl.y * p.g1 + cl.z * p.g2 + cl.w * p.gd;
+  p.Sp += w * kappa;                                      // prefix including this entry
+  const float dL_dalpha = c ? p.T * kappa + (p.Sp + p.Kc) * rcp1ma : 0.f;
+  p.T = c ? p.T * (1.f - alpha) : p.T;
+  a.v6 += w * p.g0; a.v7 += w * p.g1; a.v8 += w * p.g2; a.v9 += w * p.gd;
+  const float dL_dG = co.w * dL_dalpha;
+  const float gdx = G * dx, gdy = G * dy;
+  a.v0 += dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
+  a.v1 += dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
+  a.v2 += -0.5f * gdx * dx * dL_dG;
+  a.v3 += -0.5f * gdx * dy * dL_dG;
+  a.v4 += -0.5f * gdy * dy * dL_dG;
+  a.v5 += G * dL_dalpha;
+  return c;
+}
+
+#ifndef BWD_MINW
+#define BWD_MINW 1
+#endif
+__global__ void __launch_bounds__(64, BWD_MINW)
 gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ header,
                            const uint32_t* __restrict__ seg_tile, const uint32_t* __restrict__ seg_start,
                            const uint32_t* __restrict__ ckpt_start, const float* __restrict__ checkpoints,
@@ -68,15 +104,14 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
                            const float* __restrict__ alpha_out, const float* __restrict__ dL_dcolor,
                            const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_in,
                            float* __restrict__ partial) {
-  __shared__ float2 s_xy[BWD_SUB];
-  __shared__ float4 s_con[BWD_SUB];
-  __shared__ float4 s_col[BWD_SUB];
-  __shared__ uint32_t s_row[BWD_SUB];
-  __shared__ uint32_t s_mask[BWD_SUB];
-  __shared__ float s_part[4][BWD_SUB][BWD_NV];
-  __shared__ uint32_t s_max[4];
+  __shared__ float2 s_xy[64];
+  __shared__ float4 s_con[64];
+  __shared__ float4 s_col[64];
+  __shared__ uint32_t s_row[64];
+  __shared__ uint32_t s_mask[64];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x;
+  const int lx = lane & 7, ly = lane >> 3;
   const size_t HW = (size_t)kp.H * kp.W;
   const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -94,82 +129,72 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
     const int last = min((int)(end - start), first + GIP_SEGMENT);
     const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
     const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
-    const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
-    const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
-    const bool inside = px < kp.W && py < kp.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const int px0 = tx * GIP_TILE + lx, py0 = ty * GIP_TILE + ly;
+    const float pxf0 = (float)px0, pyf0 = (float)py0, pxf1 = pxf0 + 8.f, pyf1 = pyf0 + 8.f;
     const float tile_x0 = (float)(tx * GIP_TILE), tile_y0 = (float)(ty * GIP_TILE);
     const GipRecord* recs = records + (size_t)v * kp.P;
     const uint32_t* ioff = inst_offset + (size_t)v * kp.P;
-    const size_t pix1 = (size_t)py * kp.W + px;           // within one image plane
-    const size_t pix = (size_t)v * HW + pix1;
-
-    const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
-    const int wave_maxc = (int)gip_wave_max_u32(last_contributor);
-    __syncthreads();                                      // previous work item is done with LDS
-    if (lane == 0) s_max[wave] = (uint32_t)wave_maxc;
-    __syncthreads();
-    const int maxc = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    if (first >= maxc) {
-      // no pixel blended anything of this segment: its rows are all zero
-      for (int e = threadIdx.x; e < (last - first) * 4; e += GIP_BLOCK) {
-        const int i = first + (e >> 2), q = e & 3;
-        const uint32_t g = (uint32_t)keys[start + i];
-        const uint4 q3 = reinterpret_cast<const uint4*>(recs + g)[3];
-        const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
-        const uint32_t row = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
-        if (row < kp.capacity)
-          reinterpret_cast<float4*>(partial + (size_t)row * GIP_PARTIAL_FLOATS)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      continue;
-    }
 
     // per-pixel constants and the blend state at the segment start
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f;
-    float T = 1.f, Sp = 0.f, Kc = 0.f;   // Kc = T_final (gA - bg.gC) - S_tot
-    if (inside) {
-      // The fork's backward re-derives every T_j from T_final := 1 - alpha_out (not from the forward's own
-      // final T), i.e. all its T_j carry the factor rho = (1 - alpha_out) / final_T.  Reproduce that.
-      const float T_final = 1.f - alpha_out[pix];
-      const float Tf_fwd = final_T[pix];
-      const float rho = T_final / Tf_fwd;
-      if (dL_dcolor) {
-        const float* p = dL_dcolor + (size_t)v * 3 * HW + pix1;
-        g0 = p[0]; g1 = p[HW]; g2 = p[2 * HW];
-      }
-      if (dL_ddepth) gd = dL_ddepth[pix];
-      if (dL_dalpha_in) ga = dL_dalpha_in[pix];
-      const float* co = color_out + (size_t)v * 3 * HW + pix1;
-      // C_tot = colour output minus the background term the forward added
-      const float ct0 = co[0] - Tf_fwd * bg0, ct1 = co[HW] - Tf_fwd * bg1, ct2 = co[2 * HW] - Tf_fwd * bg2;
-      const float Stot = ct0 * g0 + ct1 * g1 + ct2 * g2 + depth_out[pix] * gd;
-      Kc = T_final * (ga - (bg0 * g0 + bg1 * g1 + bg2 * g2)) - rho * Stot;
-      T = rho;
-      if (b > 0) {
-        const uint32_t slot = ckpt_start[vt] + b - 1;
-        if (slot < kp.ckpt_capacity) {
-          const float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * GIP_BLOCK) + threadIdx.x;
-          T = rho * cp[0];
-          Sp = rho * (cp[GIP_BLOCK] * g0 + cp[2 * GIP_BLOCK] * g1 + cp[3 * GIP_BLOCK] * g2 + cp[4 * GIP_BLOCK] * gd);
+    BwdPix p[4];
+    uint32_t lmax = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int px = px0 + ((q & 1) << 3), py = py0 + ((q >> 1) << 3);
+      p[q].T = 1.f; p[q].Sp = 0.f; p[q].Kc = 0.f; p[q].g0 = p[q].g1 = p[q].g2 = p[q].gd = 0.f; p[q].lastc = 0;
+      if (px < kp.W && py < kp.H) {
+        const size_t pix1 = (size_t)py * kp.W + px, pix = (size_t)v * HW + pix1;
+        p[q].lastc = n_contrib[pix];
+        if (p[q].lastc > (uint32_t)first) {
+          // The fork's backward re-derives every T_j from T_final := 1 - alpha_out (not from the forward's own
+          // final T), i.e. all its T_j carry the factor rho = (1 - alpha_out) / final_T.  Reproduce that.
+          const float T_final = 1.f - alpha_out[pix];
+          const float Tf_fwd = final_T[pix];
+          const float rho = T_final / Tf_fwd;
+          float ga = 0.f;
+          if (dL_dcolor) {
+            const float* gp = dL_dcolor + (size_t)v * 3 * HW + pix1;
+            p[q].g0 = gp[0]; p[q].g1 = gp[HW]; p[q].g2 = gp[2 * HW];
+          }
+          if (dL_ddepth) p[q].gd = dL_ddepth[pix];
+          if (dL_dalpha_in) ga = dL_dalpha_in[pix];
+          const float* co = color_out + (size_t)v * 3 * HW + pix1;
+          // C_tot = colour output minus the background term the forward added
+          const float ct0 = co[0] - Tf_fwd * bg0, ct1 = co[HW] - Tf_fwd * bg1, ct2 = co[2 * HW] - Tf_fwd * bg2;
+          const float Stot = ct0 * p[q].g0 + ct1 * p[q].g1 + ct2 * p[q].g2 + depth_out[pix] * p[q].gd;
+          p[q].Kc = T_final * (ga - (bg0 * p[q].g0 + bg1 * p[q].g1 + bg2 * p[q].g2)) - rho * Stot;
+          p[q].T = rho;
+          if (b > 0) {
+            const uint32_t slot = ckpt_start[vt] + b - 1;
+            if (slot < kp.ckpt_capacity) {
+              const float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * 256) + q * 64 + lane;
+              p[q].T = rho * cp[0];
+              p[q].Sp = rho * (cp[256] * p[q].g0 + cp[512] * p[q].g1 + cp[768] * p[q].g2 + cp[1024] * p[q].gd);
+            }
+          }
         }
+        lmax = max(lmax, p[q].lastc);
       }
     }
+    const int maxc = (int)gip_wave_max_u32(lmax);           // longest replay needed by any pixel of the tile
 
-    for (int sub = first; sub < last; sub += BWD_SUB) {
-      const int cnt = min(BWD_SUB, last - sub);
-      if (sub != first) __syncthreads();                  // previous sub-batch flushed
-      if ((int)threadIdx.x < cnt) {
-        const int i = sub + (int)threadIdx.x;
+    for (int sub = first; sub < last; sub += 64) {
+      const int cnt = min(64, last - sub);
+      uint32_t mask = 0, row = 0xffffffffu;
+      __syncthreads();   // single-wave workgroup: previous chunk's LDS reads are done
+      if (lane < cnt) {
+        const int i = sub + lane;
         const uint32_t g = (uint32_t)keys[start + i];
         const float4* rp = reinterpret_cast<const float4*>(recs + g);
         const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
         const uint4 q3 = reinterpret_cast<const uint4*>(recs + g)[3];
-        s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
-        s_con[threadIdx.x] = make_float4(q1.x, q1.y, q1.z, q0.w);
-        s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
+        s_xy[lane] = make_float2(q0.x, q0.y);
+        s_con[lane] = make_float4(q1.x, q1.y, q1.z, q0.w);
+        s_col[lane] = make_float4(q2.x, q2.y, q2.z, q0.z);
         const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
-        s_row[threadIdx.x] = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
-        uint32_t mask = 0xf;
+        row = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
+        if (row >= kp.capacity) row = 0xffffffffu;
+        mask = 0xf;
         const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
         const float det = q1.x * q1.z - q1.y * q1.y;
         if (t2 <= 0.f || i >= maxc) {
@@ -181,83 +206,53 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
           const bool xl = rx - hx <= 7.f, xr = rx + hx >= 8.f, yt = ry - hy <= 7.f, yb = ry + hy >= 8.f;
           mask = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
         }
-        s_mask[threadIdx.x] = mask;
-      }
-      for (int e = threadIdx.x; e < 4 * BWD_SUB * BWD_NV; e += GIP_BLOCK) (&s_part[0][0][0])[e] = 0.f;
-      __syncthreads();
-
-      if (sub < wave_maxc) {
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
-          const int e = c0 + lane;
-          const bool want = e < cnt && ((s_mask[e] >> wave) & 1u) && (sub + e) < wave_maxc;
-          unsigned long long m = __ballot(want);
-          while (m) {
-            const int j = c0 + __builtin_ctzll(m);
-            m &= m - 1;
-            const int i = sub + j;
-            const float2 xy = s_xy[j];
-            const float4 co = s_con[j];
-            const float dx = xy.x - pxf, dy = xy.y - pyf;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
-            const bool c = (uint32_t)i < last_contributor && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
-            if (!__any(c)) continue;                      // uniform over the wave
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
-            if (c) {
-              const float4 cl = s_col[j];
-              const float w = alpha * T;                  // blend weight of this entry at this pixel
-              const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-              const float kappa = cl.x * g0 + cl.y * g1 + cl.z * g2 + cl.w * gd;
-              Sp += w * kappa;                            // prefix including this entry
-              const float dL_dalpha = T * kappa + (Sp + Kc) * rcp1ma;
-              T = T * (1.f - alpha);
-              v6 = w * g0; v7 = w * g1; v8 = w * g2; v9 = w * gd;
-              const float dL_dG = co.w * dL_dalpha;
-              const float gdx = G * dx, gdy = G * dy;
-              v0 = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
-              v1 = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
-              v2 = -0.5f * gdx * dx * dL_dG;
-              v3 = -0.5f * gdx * dy * dL_dG;
-              v4 = -0.5f * gdy * dy * dL_dG;
-              v5 = G * dL_dalpha;
-            }
-            // 64-lane sums of the ten terms in 27 cross-lane ops
-            const float p02 = fold32(v0, v2), p13 = fold32(v1, v3);   // [v0|v2], [v1|v3]
-            const float p46 = fold32(v4, v6), p57 = fold32(v5, v7);
-            const float p89 = fold32(v8, v9);
-            float qa = fold16(p02, p13);   // rows: v0, v1, v2, v3
-            float qb = fold16(p46, p57);   // rows: v4, v5, v6, v7
-            qa = row_reduce(qa);
-            qb = row_reduce(qb);
-            float qc = row_reduce(p89);    // rows 0,1: v8 ; rows 2,3: v9
-            qc = dpp_add<0x142, 0xa>(qc);  // row_bcast:15 -> lane 31 = v8, lane 63 = v9
-            if ((lane & 15) == 15) {
-              const int r = lane >> 4;
-              float* dst = &s_part[wave][j][0];
-              dst[r] = qa;
-              dst[4 + r] = qb;
-              if (r & 1) dst[8 + (r >> 1)] = qc;
-            }
-          }
+        s_mask[lane] = mask;
+        s_row[lane] = row;
+        // entries no pixel can contribute to: the lane that staged the entry zeroes its row right away
+        if (mask == 0 && row != 0xffffffffu) {
+          float4* dst = reinterpret_cast<float4*>(partial + (size_t)row * GIP_PARTIAL_FLOATS);
+          const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[0] = z; dst[1] = z; dst[2] = z;
         }
       }
       __syncthreads();
-      // flush: 4 lanes per entry, one 16-byte quad each -> one 64-byte row per (tile, Gaussian)
-      for (int e = threadIdx.x; e < cnt * 4; e += GIP_BLOCK) {
-        const int j = e >> 2, q = e & 3;
-        const uint32_t row = s_row[j];
-        if (row < kp.capacity) {
-          float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (q < 3) {
-            const float4 a = reinterpret_cast<const float4*>(&s_part[0][j][0])[q];
-            const float4 bq = reinterpret_cast<const float4*>(&s_part[1][j][0])[q];
-            const float4 c4 = reinterpret_cast<const float4*>(&s_part[2][j][0])[q];
-            const float4 d = reinterpret_cast<const float4*>(&s_part[3][j][0])[q];
-            s.x = (a.x + bq.x) + (c4.x + d.x); s.y = (a.y + bq.y) + (c4.y + d.y);
-            s.z = (a.z + bq.z) + (c4.z + d.z); s.w = (a.w + bq.w) + (c4.w + d.w);
-          }
-          reinterpret_cast<float4*>(partial + (size_t)row * GIP_PARTIAL_FLOATS)[q] = s;
+      unsigned long long m = __ballot(mask != 0);
+      while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t mk = __builtin_amdgcn_readfirstlane(s_mask[j]);
+        const uint32_t rowj = __builtin_amdgcn_readfirstlane(s_row[j]);
+        const uint32_t i = (uint32_t)(sub + j);
+        const float2 xy = s_xy[j];
+        const float4 co = s_con[j];
+        const float4 cl = s_col[j];
+        BwdAcc a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bool c = false;
+        if (mk & 1u) c |= bwd_pair(p[0], a, pxf0, pyf0, xy, co, cl, i, ddelx_dx, ddely_dy);
+        if (mk & 2u) c |= bwd_pair(p[1], a, pxf1, pyf0, xy, co, cl, i, ddelx_dx, ddely_dy);
+        if (mk & 4u) c |= bwd_pair(p[2], a, pxf0, pyf1, xy, co, cl, i, ddelx_dx, ddely_dy);
+        if (mk & 8u) c |= bwd_pair(p[3], a, pxf1, pyf1, xy, co, cl, i, ddelx_dx, ddely_dy);
+        if (rowj == 0xffffffffu) continue;
+        float* dst = partial + (size_t)rowj * GIP_PARTIAL_FLOATS;
+        if (!__any(c)) {
+          if (lane < 3) reinterpret_cast<float4*>(dst)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+          continue;
+        }
+        // 64-lane sums of the ten terms in 27 cross-lane ops
+        const float p02 = fold32(a.v0, a.v2), p13 = fold32(a.v1, a.v3);   // [v0|v2], [v1|v3]
+        const float p46 = fold32(a.v4, a.v6), p57 = fold32(a.v5, a.v7);
+        const float p89 = fold32(a.v8, a.v9);
+        float qa = fold16(p02, p13);   // rows: v0, v1, v2, v3
+        float qb = fold16(p46, p57);   // rows: v4, v5, v6, v7
+        qa = row_reduce(qa);
+        qb = row_reduce(qb);
+        float qc = row_reduce(p89);    // rows 0,1: v8 ; rows 2,3: v9
+        qc = dpp_add<0x142, 0xa>(qc);  // row_bcast:15 -> lane 31 = v8, lane 63 = v9
+        if ((lane & 15) == 15) {
+          const int r = lane >> 4;
+          dst[r] = qa;
+          dst[4 + r] = qb;
+          if (r & 1) dst[8 + (r >> 1)] = qc;
         }
       }
     }
@@ -266,7 +261,8 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
 
 void gip_launch_render_backward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, const GipRasterGradsIn& gin,
                                 float* partial, hipStream_t s) {
-  hipLaunchKernelGGL(gip_render_backward_kernel, dim3(BWD_GRID), dim3(GIP_BLOCK), 0, s, kp, st.header, st.seg_tile,
+  hipLaunchKernelGGL(gip_render_backward_kernel, dim3(BWD_GRID), dim3(64), 0, s, kp, st.header, st.seg_tile,
                      st.seg_start, st.ckpt_start, st.checkpoints, st.tile_start, st.keys, st.records, st.inst_offset, bg,
-                     st.n_contrib, st.final_T, gin.color, gin.depth, gin.alpha, gin.dL_dcolor, gin.dL_ddepth, gin.dL_dalpha, partial);
+                     st.n_contrib, st.final_T, gin.color, gin.depth, gin.alpha, gin.dL_dcolor, gin.dL_ddepth,
+                     gin.dL_dalpha, partial);
 }

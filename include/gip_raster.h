@@ -43,7 +43,10 @@ extern "C" {
 #define GIP_MAX_VIEWS 16       /* views per call */
 #define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
 #define GIP_PARTIAL_FLOATS 16  /* per-(tile, Gaussian) gradient partial row, 64 bytes */
-#define GIP_SEGMENT 256        /* list entries per backward work item; forward checkpoints every GIP_SEGMENT entries */
+#ifndef GIP_SEGMENT
+#define GIP_SEGMENT 256
+#endif
+//#define GIP_SEGMENT_DOC        /* list entries per backward work item; forward checkpoints every GIP_SEGMENT entries */
 #define GIP_CKPT_FLOATS 5      /* per pixel per checkpoint: T, C.r, C.g, C.b, D */
 
 /* status codes */
