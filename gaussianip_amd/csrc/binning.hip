@@ -23,6 +23,7 @@
 // ------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
+#define SCAN_LDS_TILES 32768   // tile counts staged in LDS when V*T fits (128 KB of the 160 KB)
 
 struct U3 { uint32_t a, b, c; };
 
@@ -110,20 +111,29 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uin
   __shared__ uint32_t s_bucket[33];
   __shared__ uint32_t s_class[4];
   // ---- tiles: instance ranges, segment ranges, checkpoint slots (one pass, three running sums) ----
+  // counts are first staged in LDS with coalesced loads (each thread then walks its contiguous chunk
+  // out of LDS instead of issuing serial dependent global loads)
+  extern __shared__ uint32_t s_cnt[];
   const int n = kp.V * kp.T;
+  const bool in_lds = n <= SCAN_LDS_TILES;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) s_cnt[i] = tile_count[i];
+    __syncthreads();
+  }
+  const uint32_t* cnt = in_lds ? s_cnt : tile_count;
   const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
   const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
   U3 sum = {0, 0, 0};
   uint32_t mx = 0;
   for (int i = lo; i < hi; i++) {
-    const uint32_t c = tile_count[i], a = nseg_of(c);
+    const uint32_t c = cnt[i], a = nseg_of(c);
     sum.a += c; sum.b += a; sum.c += a ? a - 1 : 0;
     mx = c > mx ? c : mx;
   }
   U3 total;
   U3 run = block_excl_scan3(sum, s_wave, &total);
   for (int i = lo; i < hi; i++) {
-    const uint32_t c = tile_count[i], a = nseg_of(c);
+    const uint32_t c = cnt[i], a = nseg_of(c);
     tile_start[i] = run.a; seg_start[i] = run.b; ckpt_start[i] = run.c;
     for (uint32_t b = 0; b < a; b++)
       if (run.b + b < kp.seg_capacity) seg_tile[run.b + b] = (uint32_t)i;
@@ -148,7 +158,7 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uin
     for (int i = l2; i < h2; i++) { block_offset[i] = r2.a; r2.a += block_sums[i]; }
     if (threadIdx.x == 0) block_offset[nb] = t2.a;
   }
-  heavy_first_order(tile_count, tile_order, n, s_bucket, s_class);
+  heavy_first_order(cnt, tile_order, n, s_bucket, s_class);
   __syncthreads();
   if (threadIdx.x == 0) {
     header->abi_version = GIP_ABI_VERSION;
@@ -163,7 +173,13 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uin
 }
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  hipLaunchKernelGGL(gip_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, kp, st.tile_count, st.tile_start,
+  const int n = kp.V * kp.T;
+  const size_t lds = n <= SCAN_LDS_TILES ? (size_t)n * 4 : 0;
+  // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process)
+  static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(gip_scan_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_TILES * 4);
+  (void)attr_once;
+  hipLaunchKernelGGL(gip_scan_kernel, dim3(1), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_start,
                      st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header);
 }
 
@@ -252,6 +268,7 @@ gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ hea
                      const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys) {
   const uint32_t pos_lo = CLS == 0 ? 0u : header->class_end[CLS - 1];
   const uint32_t pos_hi = header->class_end[CLS];
+  if (pos_lo + blockIdx.x >= pos_hi) return;
   __shared__ unsigned long long s_keys[CAP > 0 ? CAP : 1];
   for (uint32_t pos = pos_lo + blockIdx.x; pos < pos_hi; pos += gridDim.x) {
     const uint32_t t = tile_order[pos];
@@ -276,8 +293,8 @@ gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ hea
 
 void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   const dim3 block(GIP_BLOCK);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<0, 0>), dim3(256), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<8192, 1>), dim3(512), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<2048, 2>), dim3(1024), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
+  hipLaunchKernelGGL((gip_tile_sort_kernel<0, 0>), dim3(64), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
+  hipLaunchKernelGGL((gip_tile_sort_kernel<8192, 1>), dim3(128), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
+  hipLaunchKernelGGL((gip_tile_sort_kernel<2048, 2>), dim3(512), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
   hipLaunchKernelGGL((gip_tile_sort_kernel<1024, 3>), dim3(2048), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
 }

@@ -178,21 +178,39 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
     }
     const int maxc = (int)gip_wave_max_u32(lmax);           // longest replay needed by any pixel of the tile
 
-    for (int sub = first; sub < last; sub += 64) {
+    // the segment's keys are fetched up front (one load per lane per 64-entry chunk) and the records of
+    // chunk c+1 are in flight while chunk c is processed: the dependent key -> record gather is hidden
+    uint32_t gk[GIP_SEGMENT / 64];
+#pragma unroll
+    for (int c = 0; c < GIP_SEGMENT / 64; c++) {
+      const int i = first + c * 64 + lane;
+      gk[c] = i < last ? (uint32_t)keys[start + i] : 0xffffffffu;
+    }
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    uint4 r3 = make_uint4(0, 0, 0, 0);
+    uint32_t rio = 0;
+    if (gk[0] != 0xffffffffu) {
+      const float4* rp = reinterpret_cast<const float4*>(recs + gk[0]);
+      r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = reinterpret_cast<const uint4*>(rp)[3];
+      rio = ioff[gk[0]];
+    }
+
+#pragma unroll
+    for (int c = 0; c < GIP_SEGMENT / 64; c++) {
+      const int sub = first + c * 64;
+      if (sub >= last) break;
       const int cnt = min(64, last - sub);
       uint32_t mask = 0, row = 0xffffffffu;
       __syncthreads();   // single-wave workgroup: previous chunk's LDS reads are done
       if (lane < cnt) {
         const int i = sub + lane;
-        const uint32_t g = (uint32_t)keys[start + i];
-        const float4* rp = reinterpret_cast<const float4*>(recs + g);
-        const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
-        const uint4 q3 = reinterpret_cast<const uint4*>(recs + g)[3];
+        const float4 q0 = r0, q1 = r1, q2 = r2;
+        const uint4 q3 = r3;
         s_xy[lane] = make_float2(q0.x, q0.y);
         s_con[lane] = make_float4(q1.x, q1.y, q1.z, q0.w);
         s_col[lane] = make_float4(q2.x, q2.y, q2.z, q0.z);
         const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
-        row = ioff[g] + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
+        row = rio + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
         if (row >= kp.capacity) row = 0xffffffffu;
         mask = 0xf;
         const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
@@ -213,6 +231,14 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
           float4* dst = reinterpret_cast<float4*>(partial + (size_t)row * GIP_PARTIAL_FLOATS);
           const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
           dst[0] = z; dst[1] = z; dst[2] = z;
+        }
+      }
+      if (c + 1 < GIP_SEGMENT / 64) {
+        const uint32_t gn = gk[c + 1 < GIP_SEGMENT / 64 ? c + 1 : 0];
+        if (gn != 0xffffffffu) {
+          const float4* rp = reinterpret_cast<const float4*>(recs + gn);
+          r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = reinterpret_cast<const uint4*>(rp)[3];
+          rio = ioff[gn];
         }
       }
       __syncthreads();

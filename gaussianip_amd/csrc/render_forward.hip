@@ -19,6 +19,10 @@
 //     that the backward pass needs no sequential walk over the tile.
 #include "gip_internal.h"
 
+#ifndef FWD_UNROLL
+#define FWD_UNROLL 4
+#endif
+
 __global__ void __launch_bounds__(GIP_BLOCK)
 gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_order,
                           const uint32_t* __restrict__ tile_start, const unsigned long long* __restrict__ keys,
@@ -51,6 +55,17 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, Dp = 0.f;
   uint32_t last_contributor = 0;
 
+  // software pipeline over the batches: the key of batch b+2 and the record of batch b+1 are in flight
+  // while batch b is blended, so the dependent key -> record gather never stalls the blend loop
+  uint32_t g_next = 0xffffffffu, g_next2 = 0xffffffffu;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+  if (start + threadIdx.x < end) g_next = (uint32_t)keys[start + threadIdx.x];
+  if (start + GIP_BLOCK + threadIdx.x < end) g_next2 = (uint32_t)keys[start + GIP_BLOCK + threadIdx.x];
+  if (g_next != 0xffffffffu) {
+    const float4* rp = reinterpret_cast<const float4*>(recs + g_next);
+    r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+  }
+
   for (uint32_t base = start; base < end; base += GIP_BLOCK) {
     if (__syncthreads_count(done) == GIP_BLOCK) break;
     if (base != start) {
@@ -64,9 +79,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     }
     const uint32_t k = base + threadIdx.x;
     if (k < end) {
-      const uint32_t g = (uint32_t)keys[k];
-      const float4* rp = reinterpret_cast<const float4*>(recs + g);
-      const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+      const float4 q0 = r0, q1 = r1, q2 = r2;
       s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
       s_con[threadIdx.x] = make_float4(q1.x, q1.y, q1.z, q0.w);
       s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
@@ -86,6 +99,13 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
       }
       s_mask[threadIdx.x] = mask;
     }
+    // issue the loads of the following batches (consumed one / two iterations from now)
+    g_next = g_next2;
+    g_next2 = (k + 2 * GIP_BLOCK < end) ? (uint32_t)keys[k + 2 * GIP_BLOCK] : 0xffffffffu;
+    if (g_next != 0xffffffffu) {
+      const float4* rp = reinterpret_cast<const float4*>(recs + g_next);
+      r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+    }
     __syncthreads();
     const int cnt = min((uint32_t)GIP_BLOCK, end - base);
     if (!__all(done)) {
@@ -95,26 +115,40 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
         unsigned long long m = __ballot((mk >> wave) & 1u);
         bool wave_done = false;
         while (m) {
-          const int j = c0 + __builtin_ctzll(m);
-          m &= m - 1;
-          const float2 xy = s_xy[j];
-          const float4 co = s_con[j];
-          const float4 cl = s_col[j];
-          const float dx = xy.x - pxf, dy = xy.y - pyf;
-          const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-          const float alpha = fminf(GIP_ALPHA_MAX, co.w * __expf(power));
-          const bool valid = !done && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
-          const float test_T = T * (1.f - alpha);
-          const bool stop = valid && test_T < GIP_T_MIN;
-          const bool acc = valid && !stop;
-          done = done || stop;
-          const float w = acc ? alpha * T : 0.f;
-          C0 += cl.x * w; C1 += cl.y * w; C2 += cl.z * w;
-          Wt += w;
-          Dp += cl.w * w;
-          T = acc ? test_T : T;
-          last_contributor = acc ? (base - start) + j + 1 : last_contributor;
-          if (__any(stop)) {               // wave-uniform; re-test termination only when something changed
+          // FWD_UNROLL list entries per trip: their exp / alpha chains are independent, only the short
+          // transmittance update is serial (cuts the latency-bound time per entry)
+          int jj[FWD_UNROLL];
+          bool okk[FWD_UNROLL];
+          float al[FWD_UNROLL];
+          float4 cc[FWD_UNROLL];
+#pragma unroll
+          for (int u = 0; u < FWD_UNROLL; u++) {
+            const bool have = m != 0;
+            jj[u] = have ? c0 + __builtin_ctzll(m) : jj[0];
+            m &= m - 1;                                   // (0 & anything) stays 0
+            const float2 xy = s_xy[jj[u]];
+            const float4 co = s_con[jj[u]];
+            cc[u] = s_col[jj[u]];
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            al[u] = fminf(GIP_ALPHA_MAX, co.w * __expf(power));
+            okk[u] = have && power <= 0.0f && al[u] >= GIP_ALPHA_MIN;
+          }
+          bool any_stop = false;
+#pragma unroll
+          for (int u = 0; u < FWD_UNROLL; u++) {
+            const bool valid = !done && okk[u];
+            const float test_T = T * (1.f - al[u]);
+            const bool stop = valid && test_T < GIP_T_MIN;
+            const bool acc = valid && !stop;
+            done = done || stop;
+            const float w = acc ? al[u] * T : 0.f;
+            C0 += cc[u].x * w; C1 += cc[u].y * w; C2 += cc[u].z * w; Wt += w; Dp += cc[u].w * w;
+            T = acc ? test_T : T;
+            last_contributor = acc ? (base - start) + jj[u] + 1 : last_contributor;
+            any_stop = any_stop || stop;
+          }
+          if (__any(any_stop)) {           // wave-uniform; re-test termination only when something changed
             if (__all(done)) { wave_done = true; break; }
           }
         }
