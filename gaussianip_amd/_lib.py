@@ -45,7 +45,7 @@ class GipRasterGradsOut(ctypes.Structure):
 
 class GipRasterStateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in ("header", "records", "inst_offset", "tile_count", "tile_start",
-                                                "tile_cursor", "block_sums", "block_offset", "keys", "n_contrib",
+                                                "tile_cursor", "tile_count_b", "inst_slot", "block_sums", "block_offset", "keys", "n_contrib",
                                                 "final_T", "tile_order", "seg_start", "ckpt_start", "seg_tile", "checkpoints", "total")] + \
                [(n, ctypes.c_uint32) for n in ("tiles_x", "tiles_y", "num_blocks", "reserved")]
 

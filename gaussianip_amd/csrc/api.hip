@@ -40,11 +40,13 @@ extern "C" int gip_raster_state_layout(const GipRasterConfig* c, GipRasterStateL
   // the three zero-initialised arrays are adjacent so that one memset clears header..block region
   L->tile_count = off;   off = align256(off + V * T * 4);
   L->tile_cursor = off;  off = align256(off + V * T * 4);
+  L->tile_count_b = off; off = align256(off + V * T * 4);
   L->tile_start = off;   off = align256(off + (V * T + 1) * 4);
   L->block_sums = off;   off = align256(off + (V * nblk + 1) * 4);
   L->block_offset = off; off = align256(off + (V * nblk + 1) * 4);
   L->records = off;      off = align256(off + V * P * GIP_RECORD_BYTES);
   L->inst_offset = off;  off = align256(off + V * P * 4);
+  L->inst_slot = off;    off = align256(off + V * P * GIP_SLOTS * 4);
   L->n_contrib = off;    off = align256(off + V * (size_t)c->H * c->W * 4);
   L->final_T = off;      off = align256(off + V * (size_t)c->H * c->W * 4);
   L->tile_order = off;   off = align256(off + V * T * 4);
@@ -96,6 +98,8 @@ static GipStatePtrs state_ptrs(void* state, const GipRasterStateLayout& L) {
   p.tile_count = (uint32_t*)(b + L.tile_count);
   p.tile_start = (uint32_t*)(b + L.tile_start);
   p.tile_cursor = (uint32_t*)(b + L.tile_cursor);
+  p.tile_count_b = (uint32_t*)(b + L.tile_count_b);
+  p.inst_slot = (uint32_t*)(b + L.inst_slot);
   p.block_sums = (uint32_t*)(b + L.block_sums);
   p.block_offset = (uint32_t*)(b + L.block_offset);
   p.keys = (unsigned long long*)(b + L.keys);
@@ -169,7 +173,7 @@ static int forward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, c
   hipStream_t s = (hipStream_t)stream;
   StageTimer tm(s, times);
 
-  // header + tile_count + tile_cursor are contiguous: one clear
+  // header + tile_count + tile_cursor + tile_count_b are contiguous: one clear
   tm.begin(GIP_STAGE_CLEAR);
   HIP_TRY(hipMemsetAsync((char*)state + L.header, 0, L.tile_start - L.header, s));
   tm.end(GIP_STAGE_CLEAR);

@@ -21,6 +21,9 @@
 // ------------------------------------------------------------------------------------------------
 // scan: one workgroup of 1024 threads, each thread owns a contiguous chunk
 // ------------------------------------------------------------------------------------------------
+#ifndef SCAN_SKIP
+#define SCAN_SKIP 0
+#endif
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
 #define SCAN_LDS_TILES 32768   // tile counts staged in LDS when V*T fits (128 KB of the 160 KB)
@@ -48,62 +51,65 @@ __device__ __forceinline__ U3 block_excl_scan3(U3 v, uint32_t (*s_wave)[SCAN_WAV
 __device__ __forceinline__ uint32_t nseg_of(uint32_t count) { return (count + GIP_SEGMENT - 1) / GIP_SEGMENT; }
 __device__ __forceinline__ int bucket_of(uint32_t c) { return c ? 32 - __clz(c) : 0; }
 
-// Launch order for the per-tile kernels: tiles bucketed by floor(log2(count)) and emitted longest bucket
-// first, so the long lists start early and the short ones fill the tail.  Order inside a bucket is arbitrary
-// (it only decides which workgroup renders which tile; results do not depend on it).  Wave-aggregated:
-// one LDS atomic per (wave, bucket present) instead of one per tile.
-__device__ void heavy_first_order(const uint32_t* __restrict__ counts, uint32_t* __restrict__ order, int n,
-                                  uint32_t* s_bucket /*[33]*/, uint32_t* class_end /*[4] out, thread 0*/) {
+// Launch order for the per-tile kernels: tiles grouped into 6 size classes and emitted longest class first,
+// so the long lists start early and the short ones fill the tail.  Order inside a class is arbitrary (it only
+// decides which workgroup handles which tile; results do not depend on it).  Wave-aggregated: one LDS atomic
+// per (wave, class, round) — the empty-tile class would otherwise serialise 64 lanes on one LDS word.
+//   class 0: >= 2048 | 1: 1024..2047 | 2: 512..1023 | 3: 128..511 | 4: 1..127 | 5: empty
+#define ORDER_CLASSES 6
+__device__ __forceinline__ int class_of(uint32_t c) {
+  return c >= 2048 ? 0 : c >= 1024 ? 1 : c >= 512 ? 2 : c >= 128 ? 3 : c >= 1 ? 4 : 5;
+}
+__device__ void heavy_first_order(const uint32_t* lds_counts, const uint32_t* ca, const uint32_t* cb,
+                                  uint32_t* __restrict__ order, int n, uint32_t* s_bucket /*[33]*/,
+                                  uint32_t* class_end /*[4] out, thread 0*/) {
+  auto count_of = [&](int i) -> uint32_t { return lds_counts ? lds_counts[i] : ca[i] + cb[i]; };
   const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   for (int i = threadIdx.x; i < 33; i += SCAN_THREADS) s_bucket[i] = 0;
   __syncthreads();
   const int rounds = (n + SCAN_THREADS - 1) / SCAN_THREADS;
   for (int r = 0; r < rounds; r++) {
     const int i = r * SCAN_THREADS + threadIdx.x;
-    const int b = i < n ? bucket_of(counts[i]) : -1;
-    unsigned long long pending = __ballot(b >= 0);
-    while (pending) {
-      const int leader = __builtin_ctzll(pending);
-      const int lb = __shfl(b, leader, 64);
-      const unsigned long long m = __ballot(b == lb);
-      if (lane == leader) atomicAdd(&s_bucket[lb], (uint32_t)__popcll(m));
-      pending &= ~m;
+    const int cls = i < n ? class_of(count_of(i)) : -1;
+#pragma unroll
+    for (int c = 0; c < ORDER_CLASSES; c++) {
+      const unsigned long long m = __ballot(cls == c);
+      if (m && lane == 0) atomicAdd(&s_bucket[c], (uint32_t)__popcll(m));
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t run = 0;
-    for (int b = 32; b >= 0; b--) {
-      const uint32_t c = s_bucket[b];
-      s_bucket[b] = run;
-      run += c;
-      // sort classes: >= 8192 (bucket >= 14) | 2048..8191 (12,13) | 1024..2047 (11) | 1..1023 (1..10)
-      if (b == 14) class_end[0] = run;
-      if (b == 12) class_end[1] = run;
-      if (b == 11) class_end[2] = run;
-      if (b == 1) class_end[3] = run;
+    for (int c = 0; c < ORDER_CLASSES; c++) {
+      const uint32_t k = s_bucket[c];
+      s_bucket[c] = run;
+      run += k;
+      if (c == 0) class_end[0] = class_end[1] = run;   // sort role A: >= 2048
+      if (c == 1) class_end[2] = run;                  // sort role B: 1024..2047
+      if (c == 4) class_end[3] = run;                  // sort role C: 1..1023 ; beyond: empty tiles
     }
   }
   __syncthreads();
   for (int r = 0; r < rounds; r++) {
     const int i = r * SCAN_THREADS + threadIdx.x;
-    const int b = i < n ? bucket_of(counts[i]) : -1;
-    unsigned long long pending = __ballot(b >= 0);
-    while (pending) {
-      const int leader = __builtin_ctzll(pending);
-      const int lb = __shfl(b, leader, 64);
-      const unsigned long long m = __ballot(b == lb);
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&s_bucket[lb], (uint32_t)__popcll(m));
-      base = __shfl(base, leader, 64);
-      if (b == lb) order[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
-      pending &= ~m;
+    const int cls = i < n ? class_of(count_of(i)) : -1;
+#pragma unroll
+    for (int c = 0; c < ORDER_CLASSES; c++) {
+      const unsigned long long m = __ballot(cls == c);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_bucket[c], (uint32_t)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (cls == c) order[base + __popcll(m & lt)] = (uint32_t)i;
+      }
     }
   }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_count_b,
+                uint32_t* __restrict__ tile_start,
                 uint32_t* __restrict__ seg_start, uint32_t* __restrict__ ckpt_start, uint32_t* __restrict__ seg_tile,
                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offset,
                 uint32_t* __restrict__ tile_order, GipRasterHeader* __restrict__ header) {
@@ -117,26 +123,43 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uin
   const int n = kp.V * kp.T;
   const bool in_lds = n <= SCAN_LDS_TILES;
   if (in_lds) {
-    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) s_cnt[i] = tile_count[i];
+    // 8 independent load pairs in flight per thread (a plain loop would wait for each pair in turn)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * SCAN_THREADS) {
+      uint32_t va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * SCAN_THREADS;
+        va[u] = i < n ? tile_count[i] : 0u;
+        vb[u] = i < n ? tile_count_b[i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * SCAN_THREADS;
+        if (i < n) s_cnt[i] = va[u] + vb[u];
+      }
+    }
     __syncthreads();
   }
-  const uint32_t* cnt = in_lds ? s_cnt : tile_count;
+  // (beyond SCAN_LDS_TILES tiles the two partial counts are summed on the fly from global memory)
+  auto cnt_at = [&](int i) -> uint32_t { return in_lds ? s_cnt[i] : tile_count[i] + tile_count_b[i]; };
   const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
   const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
   U3 sum = {0, 0, 0};
   uint32_t mx = 0;
   for (int i = lo; i < hi; i++) {
-    const uint32_t c = cnt[i], a = nseg_of(c);
+    const uint32_t c = cnt_at(i), a = nseg_of(c);
     sum.a += c; sum.b += a; sum.c += a ? a - 1 : 0;
     mx = c > mx ? c : mx;
   }
   U3 total;
   U3 run = block_excl_scan3(sum, s_wave, &total);
   for (int i = lo; i < hi; i++) {
-    const uint32_t c = cnt[i], a = nseg_of(c);
+    const uint32_t c = cnt_at(i), a = nseg_of(c);
     tile_start[i] = run.a; seg_start[i] = run.b; ckpt_start[i] = run.c;
+#if !(SCAN_SKIP & 2)
     for (uint32_t b = 0; b < a; b++)
       if (run.b + b < kp.seg_capacity) seg_tile[run.b + b] = (uint32_t)i;
+#endif
     run.a += c; run.b += a; run.c += a ? a - 1 : 0;
   }
   if (threadIdx.x == 0) { tile_start[n] = total.a; seg_start[n] = total.b; ckpt_start[n] = total.c; }
@@ -158,7 +181,9 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, uin
     for (int i = l2; i < h2; i++) { block_offset[i] = r2.a; r2.a += block_sums[i]; }
     if (threadIdx.x == 0) block_offset[nb] = t2.a;
   }
-  heavy_first_order(cnt, tile_order, n, s_bucket, s_class);
+#if !(SCAN_SKIP & 1)
+  heavy_first_order(in_lds ? s_cnt : nullptr, tile_count, tile_count_b, tile_order, n, s_bucket, s_class);
+#endif
   __syncthreads();
   if (threadIdx.x == 0) {
     header->abi_version = GIP_ABI_VERSION;
@@ -179,7 +204,7 @@ void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) 
   static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(gip_scan_kernel),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_TILES * 4);
   (void)attr_once;
-  hipLaunchKernelGGL(gip_scan_kernel, dim3(1), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_start,
+  hipLaunchKernelGGL(gip_scan_kernel, dim3(1), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
                      st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header);
 }
 
@@ -188,7 +213,8 @@ void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GIP_BLOCK)
 gip_scatter_kernel(GipKernelParams kp, const GipRecord* __restrict__ records, const uint32_t* __restrict__ tile_start,
-                   uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ block_offset,
+                   const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_cursor,
+                   const uint32_t* __restrict__ inst_slot, const uint32_t* __restrict__ block_offset,
                    uint32_t* __restrict__ inst_offset, unsigned long long* __restrict__ keys) {
   const int v = blockIdx.y;
   const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
@@ -211,10 +237,24 @@ gip_scatter_kernel(GipKernelParams kp, const GipRecord* __restrict__ records, co
   const int rminx = rmin & 0xffff, rminy = rmin >> 16, rmaxx = rmax & 0xffff, rmaxy = rmax >> 16;
   const unsigned long long key = ((unsigned long long)dbits << 32) | (uint32_t)idx;
   const size_t tbase = (size_t)v * kp.T;
+  // slots drawn by preprocess (first GIP_SLOTS instances): no atomic here
+  const uint4* sp = reinterpret_cast<const uint4*>(inst_slot + ((size_t)v * kp.P + idx) * GIP_SLOTS);
+  const uint4 s0 = sp[0];
+  uint4 s1 = make_uint4(0, 0, 0, 0);
+  if (tiles > 4) s1 = sp[1];
+  const uint32_t slots[GIP_SLOTS] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  int k = 0;
   for (int ty = rminy; ty < rmaxy; ty++)
-    for (int tx = rminx; tx < rmaxx; tx++) {
+    for (int tx = rminx; tx < rmaxx; tx++, k++) {
       const size_t t = tbase + ty * kp.tiles_x + tx;
-      const uint32_t slot = atomicAdd(&tile_cursor[t], 1u);
+      uint32_t slot;
+      if (k < GIP_SLOTS) {
+        slot = 0;
+#pragma unroll
+        for (int kk = 0; kk < GIP_SLOTS; kk++) if (kk == k) slot = slots[kk];
+      } else {
+        slot = tile_count[t] + atomicAdd(&tile_cursor[t], 1u);   // after the remembered-slot part of the bucket
+      }
       const uint32_t pos = tile_start[t] + slot;
       if (pos < kp.capacity) keys[pos] = key;
     }
@@ -222,7 +262,7 @@ gip_scatter_kernel(GipKernelParams kp, const GipRecord* __restrict__ records, co
 
 void gip_launch_scatter(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   hipLaunchKernelGGL(gip_scatter_kernel, dim3(kp.nblk, kp.V), dim3(GIP_BLOCK), 0, s, kp, st.records, st.tile_start,
-                     st.tile_cursor, st.block_offset, st.inst_offset, st.keys);
+                     st.tile_count, st.tile_cursor, st.inst_slot, st.block_offset, st.inst_offset, st.keys);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -259,42 +299,111 @@ __device__ __forceinline__ void bitonic_any_n(PtrT a, uint32_t n) {
   }
 }
 
-// One class of tile sizes per launch; the classes are contiguous ranges of tile_order (written by the scan
-// kernel into header->class_end), walked grid-stride by a small persistent grid so that no workgroup is
-// launched for tiles outside the class.  CAP > 0: sort in LDS.  CAP == 0: in place in global memory.
-template <int CAP, int CLS>
+// Per-tile sort, ONE launch.  The size classes are contiguous ranges of tile_order (written by the scan kernel
+// into header->class_end); workgroups take a role by blockIdx so that the few long lists (many bitonic stages,
+// latency-bound) sort concurrently with the many short ones instead of in separate back-to-back launches:
+//   role A  [0, SORT_WG_BIG)              tiles with >= 2048 entries: all-ascending network, strides < 2048 in LDS
+//                                          one 2048-key chunk at a time, longer strides in place in global memory
+//   role B  [SORT_WG_BIG, +SORT_WG_MID)   1024..2047 entries, fully in LDS
+//   role C  the rest                       1..1023 entries, fully in LDS
+#define BIG_CHUNK 2048
+#define SORT_WG_BIG 256
+#define SORT_WG_MID 512
+#define SORT_WG_SMALL 2048
+__device__ __forceinline__ void ce_global(unsigned long long* a, uint32_t lo, uint32_t hi, uint32_t n) {
+  if (hi < n) {
+    const unsigned long long x = a[lo], y = a[hi];
+    if (x > y) { a[lo] = y; a[hi] = x; }
+  }
+}
+
+__device__ void sort_big_tile(unsigned long long* a, uint32_t n, unsigned long long* s_keys) {
+  uint32_t m = 1;
+  while (m < n) m <<= 1;
+  // phase 1: sort every BIG_CHUNK-aligned chunk completely in LDS
+  for (uint32_t c0 = 0; c0 < n; c0 += BIG_CHUNK) {
+    const uint32_t cn = min((uint32_t)BIG_CHUNK, n - c0);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) s_keys[i] = a[c0 + i];
+    __syncthreads();
+    bitonic_any_n(s_keys, cn);
+    for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) a[c0 + i] = s_keys[i];
+  }
+  __threadfence_block();
+  __syncthreads();
+  // phase 2: merges of size k > BIG_CHUNK
+  for (uint32_t k = 2 * BIG_CHUNK; k <= m; k <<= 1) {
+    const uint32_t hk = k >> 1;
+    for (uint32_t tt = threadIdx.x; tt < (m >> 1); tt += GIP_BLOCK) {       // flip stage, global
+      const uint32_t blk = tt / hk, off = tt - blk * hk;
+      ce_global(a, blk * k + off, blk * k + k - 1 - off, n);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t j = k >> 2; j >= BIG_CHUNK; j >>= 1) {                    // long strides, global
+      for (uint32_t tt = threadIdx.x; tt < (m >> 1); tt += GIP_BLOCK) {
+        const uint32_t lo = 2 * j * (tt / j) + (tt % j);
+        ce_global(a, lo, lo + j, n);
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    for (uint32_t c0 = 0; c0 < n; c0 += BIG_CHUNK) {                        // strides < BIG_CHUNK, in LDS
+      const uint32_t cn = min((uint32_t)BIG_CHUNK, n - c0);
+      for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) s_keys[i] = a[c0 + i];
+      __syncthreads();
+      for (uint32_t j = BIG_CHUNK >> 1; j >= 1; j >>= 1) {
+        for (uint32_t tt = threadIdx.x; tt < (BIG_CHUNK >> 1); tt += GIP_BLOCK) {
+          const uint32_t lo = 2 * j * (tt / j) + (tt % j), hi = lo + j;
+          if (hi < cn) {
+            const unsigned long long x = s_keys[lo], y = s_keys[hi];
+            if (x > y) { s_keys[lo] = y; s_keys[hi] = x; }
+          }
+        }
+        __syncthreads();
+      }
+      for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) a[c0 + i] = s_keys[i];
+      __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 __global__ void __launch_bounds__(GIP_BLOCK)
 gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
                      const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys) {
-  const uint32_t pos_lo = CLS == 0 ? 0u : header->class_end[CLS - 1];
-  const uint32_t pos_hi = header->class_end[CLS];
-  if (pos_lo + blockIdx.x >= pos_hi) return;
-  __shared__ unsigned long long s_keys[CAP > 0 ? CAP : 1];
-  for (uint32_t pos = pos_lo + blockIdx.x; pos < pos_hi; pos += gridDim.x) {
+  __shared__ unsigned long long s_keys[BIG_CHUNK];
+  uint32_t pos_lo, pos_hi, first, stride;
+  bool big = false;
+  if (blockIdx.x < SORT_WG_BIG) {
+    pos_lo = 0; pos_hi = header->class_end[1]; first = blockIdx.x; stride = SORT_WG_BIG; big = true;
+  } else if (blockIdx.x < SORT_WG_BIG + SORT_WG_MID) {
+    pos_lo = header->class_end[1]; pos_hi = header->class_end[2]; first = blockIdx.x - SORT_WG_BIG; stride = SORT_WG_MID;
+  } else {
+    pos_lo = header->class_end[2]; pos_hi = header->class_end[3];
+    first = blockIdx.x - SORT_WG_BIG - SORT_WG_MID; stride = SORT_WG_SMALL;
+  }
+  for (uint32_t pos = pos_lo + first; pos < pos_hi; pos += stride) {
     const uint32_t t = tile_order[pos];
     const uint32_t start = tile_start[t];
     uint32_t end = tile_start[t + 1];
     if (end > kp.capacity) end = kp.capacity;
     if (end <= start + 1) continue;
     const uint32_t n = end - start;
-    if (CAP > 0) {
+    if (big) {
+      sort_big_tile(keys + start, n, s_keys);
+    } else {
       __syncthreads();
       for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) s_keys[i] = keys[start + i];
       __syncthreads();
       bitonic_any_n(s_keys, n);
       for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) keys[start + i] = s_keys[i];
-    } else {
-      __threadfence_block();
-      bitonic_any_n(keys + start, n);
-      __syncthreads();
     }
   }
 }
 
 void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  const dim3 block(GIP_BLOCK);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<0, 0>), dim3(64), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<8192, 1>), dim3(128), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<2048, 2>), dim3(512), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
-  hipLaunchKernelGGL((gip_tile_sort_kernel<1024, 3>), dim3(2048), block, 0, s, kp, st.header, st.tile_order, st.tile_start, st.keys);
+  hipLaunchKernelGGL(gip_tile_sort_kernel, dim3(SORT_WG_BIG + SORT_WG_MID + SORT_WG_SMALL), dim3(GIP_BLOCK), 0, s, kp,
+                     st.header, st.tile_order, st.tile_start, st.keys);
 }

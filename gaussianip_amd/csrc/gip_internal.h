@@ -45,6 +45,8 @@ struct GipStatePtrs {
   uint32_t* tile_count;     // [V*T]
   uint32_t* tile_start;     // [V*T+1]
   uint32_t* tile_cursor;    // [V*T]
+  uint32_t* tile_count_b;   // [V*T]
+  uint32_t* inst_slot;      // [V,P,GIP_SLOTS]
   uint32_t* block_sums;     // [V*nblk]
   uint32_t* block_offset;   // [V*nblk+1]
   unsigned long long* keys; // [capacity]

@@ -52,7 +52,8 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ camposs,
                       int32_t* __restrict__ radii, GipRecord* __restrict__ records,
-                      uint32_t* __restrict__ tile_count, uint32_t* __restrict__ block_sums,
+                      uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_count_b,
+                      uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ block_sums,
                       GipRasterHeader* __restrict__ header) {
   const int v = blockIdx.y;
   const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
@@ -159,10 +160,27 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
           rec.rmin = (uint32_t)rminx | ((uint32_t)rminy << 16);
           rec.rmax = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
           rec.clamped = clamped;
-          // per-tile histogram
+          // per-tile histogram.  The first GIP_SLOTS instances remember the bucket slot the atomic returned,
+          // so the scatter pass places them without a second atomic; the (rare) rest only count here.
           uint32_t* tc = tile_count + (size_t)v * kp.T;
+          uint32_t* tcb = tile_count_b + (size_t)v * kp.T;
+          uint32_t slots[GIP_SLOTS];
+#pragma unroll
+          for (int k = 0; k < GIP_SLOTS; k++) slots[k] = 0;
+          int k = 0;
           for (int ty = rminy; ty < rmaxy; ty++)
-            for (int tx = rminx; tx < rmaxx; tx++) atomicAdd(&tc[ty * gx + tx], 1u);
+            for (int tx = rminx; tx < rmaxx; tx++, k++) {
+              if (k < GIP_SLOTS) {
+                const uint32_t sl = atomicAdd(&tc[ty * gx + tx], 1u);
+#pragma unroll
+                for (int kk = 0; kk < GIP_SLOTS; kk++) if (kk == k) slots[kk] = sl;
+              } else {
+                atomicAdd(&tcb[ty * gx + tx], 1u);
+              }
+            }
+          uint4* sp = reinterpret_cast<uint4*>(inst_slot + ((size_t)v * kp.P + idx) * GIP_SLOTS);
+          sp[0] = make_uint4(slots[0], slots[1], slots[2], slots[3]);
+          if (ntiles > 4) sp[1] = make_uint4(slots[4], slots[5], slots[6], slots[7]);
         }
       }
     }
@@ -191,7 +209,7 @@ void gip_launch_preprocess(const GipKernelParams& kp, const GipRasterInputs& in,
   dim3 grid(kp.nblk, kp.V), block(GIP_BLOCK);
   hipLaunchKernelGGL(gip_preprocess_kernel, grid, block, 0, s, kp, in.means3D, in.shs, in.colors_precomp, in.opacities,
                      in.scales, in.rotations, in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, radii,
-                     st.records, st.tile_count, st.block_sums, st.header);
+                     st.records, st.tile_count, st.tile_count_b, st.inst_slot, st.block_sums, st.header);
 }
 
 // mark_visible: the fork's checkFrustum (view-space z > 0.2).

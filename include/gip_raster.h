@@ -47,6 +47,7 @@ extern "C" {
 #define GIP_SEGMENT 256
 #endif
 //#define GIP_SEGMENT_DOC        /* list entries per backward work item; forward checkpoints every GIP_SEGMENT entries */
+#define GIP_SLOTS 8            /* bucket slots remembered per (view, Gaussian): scatter needs no second atomic for these */
 #define GIP_CKPT_FLOATS 5      /* per pixel per checkpoint: T, C.r, C.g, C.b, D */
 
 /* status codes */
@@ -141,9 +142,11 @@ typedef struct GipRasterStateLayout {
   size_t header;       /* GipRasterHeader */
   size_t records;      /* [V,P] x GIP_RECORD_BYTES */
   size_t inst_offset;  /* [V,P] u32: exclusive prefix sum of tiles_touched (view-major, global) */
-  size_t tile_count;   /* [V,T] u32: entries per tile */
+  size_t tile_count;   /* [V,T] u32: entries per tile drawn through the remembered slots (total = this + tile_count_b) */
   size_t tile_start;   /* [V*T+1] u32: exclusive scan of tile_count == ranges[tile].x, ranges[tile].y = next */
-  size_t tile_cursor;  /* [V,T] u32 scratch for bucket fill */
+  size_t tile_cursor;  /* [V,T] u32 scratch for bucket fill (instances beyond GIP_SLOTS per Gaussian) */
+  size_t tile_count_b; /* [V,T] u32: part of the per-tile count contributed by instances beyond GIP_SLOTS */
+  size_t inst_slot;    /* [V,P,GIP_SLOTS] u32: bucket slot each of a Gaussian's first GIP_SLOTS instances drew */
   size_t block_sums;   /* [V,ceil(P/256)] u32 */
   size_t block_offset; /* [V*ceil(P/256)+1] u32 */
   size_t keys;         /* [capacity] u64 sorted per tile: (depth_bits << 32) | gaussian_index */
