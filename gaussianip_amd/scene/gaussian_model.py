@@ -1,0 +1,328 @@
+"""Gaussian parameter store + Adam-state surgery + densify / prune, API-compatible with the reference.
+
+Reference: gaussiansplatting/scene/gaussian_model.py — activations :15-30, fields :33-48, getters :84-107,
+create_from_pcd :113-136, training_setup :138-159, lr schedule :161-181, PLY I/O :183-264, optimizer surgery
+:266-355, densify_and_split :357-380, densify_and_clone :382-393, densify_and_prune :395-410, prune_only :413-418,
+add_densification_stats :420-422.  Pinned by tests/golden/gaussian_model.npz (traces captured from the imported
+reference class).
+
+Differences that do not change results: tensors follow `device` (default "cuda") instead of a hard-coded "cuda";
+the six parameter groups are handled through one table instead of six hand-written copies; PLY files are read and
+written by a small built-in binary reader/writer (same header and column order as plyfile produces).
+"""
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..utils.general import (build_rotation, build_scaling_rotation, get_expon_lr_func, inverse_sigmoid,
+                             strip_symmetric)
+from ..utils.graphics import BasicPointCloud
+from ..utils.sh import RGB2SH
+
+# optimizer group name -> attribute holding the parameter (order = the reference's param_groups order)
+_GROUPS = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+           ("scaling", "_scaling"), ("rotation", "_rotation"))
+
+
+def _covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    L = build_scaling_rotation(scaling_modifier * scaling, rotation)
+    return strip_symmetric(L @ L.transpose(1, 2))
+
+
+class GaussianModel:
+    def setup_functions(self):
+        self.scaling_activation = torch.exp
+        self.scaling_inverse_activation = torch.log
+        self.covariance_activation = _covariance_from_scaling_rotation
+        self.opacity_activation = torch.sigmoid
+        self.inverse_opacity_activation = inverse_sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    def __init__(self, sh_degree: int, device="cuda"):
+        self.device = torch.device(device)
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        for _, attr in _GROUPS:
+            setattr(self, attr, torch.empty(0))
+        self.max_radii2D = torch.empty(0)
+        self.xyz_gradient_accum = torch.empty(0)
+        self.denom = torch.empty(0)
+        self.optimizer = None
+        self.percent_dense = 0
+        self.spatial_lr_scale = 0
+        self.setup_functions()
+
+    # ------------------------------------------------------------------ state hand-off
+    def capture(self):
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
+                self.spatial_lr_scale)
+
+    def restore(self, model_args, training_args):
+        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+         self._opacity, self.max_radii2D, grad_accum, denom, opt_dict, self.spatial_lr_scale) = model_args
+        self.training_setup(training_args)
+        self.xyz_gradient_accum, self.denom = grad_accum, denom
+        self.optimizer.load_state_dict(opt_dict)
+
+    # ------------------------------------------------------------------ activated views
+    @property
+    def get_scaling(self):
+        return self.scaling_activation(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    def get_covariance(self, scaling_modifier=1):
+        # raw (un-normalised) rotation: build_rotation normalises it (reference quirk kept, :106-107)
+        return self.covariance_activation(self.get_scaling, scaling_modifier, self._rotation)
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ------------------------------------------------------------------ initialisation
+    def create_from_pcd(self, pcd: BasicPointCloud, spatial_lr_scale: float, dist2=None):
+        """`dist2` (mean squared 3-NN distance per point) defaults to the HIP distCUDA2 replacement."""
+        dev = self.device
+        self.spatial_lr_scale = spatial_lr_scale
+        pts = torch.tensor(np.asarray(pcd.points)).float().to(dev)
+        n = pts.shape[0]
+        n_coef = (self.max_sh_degree + 1) ** 2
+        feats = torch.zeros((n, 3, n_coef), dtype=torch.float32, device=dev)
+        feats[:, :3, 0] = RGB2SH(torch.tensor(np.asarray(pcd.colors)).float().to(dev))
+        print("Number of points at initialisation : ", n)
+        if dist2 is None:
+            from ..knn import distCUDA2
+            dist2 = distCUDA2(pts)
+        dist2 = torch.clamp_min(torch.as_tensor(dist2, dtype=torch.float32, device=dev), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros((n, 4), device=dev)
+        rots[:, 0] = 1
+        opac = inverse_sigmoid(0.1 * torch.ones((n, 1), dtype=torch.float32, device=dev))
+        self._xyz = nn.Parameter(pts.requires_grad_(True))
+        self._features_dc = nn.Parameter(feats[:, :, 0:1].transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(feats[:, :, 1:].transpose(1, 2).contiguous().requires_grad_(True))
+        self._scaling = nn.Parameter(scales.requires_grad_(True))
+        self._rotation = nn.Parameter(rots.requires_grad_(True))
+        self._opacity = nn.Parameter(opac.requires_grad_(True))
+        self.max_radii2D = torch.zeros((n,), device=dev)
+
+    def training_setup(self, training_args):
+        n, dev = self.get_xyz.shape[0], self.get_xyz.device
+        self.percent_dense = training_args.percent_dense
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        lrs = {"xyz": training_args.position_lr_init * self.spatial_lr_scale, "f_dc": training_args.feature_lr,
+               "f_rest": training_args.feature_lr / 20.0, "opacity": training_args.opacity_lr,
+               "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
+        self.params_list = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in _GROUPS]
+        self.optimizer = torch.optim.Adam(self.params_list, lr=0.0, eps=1e-15)
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=training_args.position_lr_init * self.spatial_lr_scale,
+            lr_final=training_args.position_lr_final * self.spatial_lr_scale,
+            lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            if group["name"] == "xyz":
+                group["lr"] = self.xyz_scheduler_args(iteration)
+
+    def set_refine_learning_rate(self, iteration):
+        self.update_learning_rate(iteration)
+
+    # ------------------------------------------------------------------ PLY (float32 columns, plyfile-compatible)
+    def construct_list_of_attributes(self):
+        names = ["x", "y", "z", "nx", "ny", "nz"]
+        names += ["f_dc_%d" % i for i in range(self._features_dc.shape[1] * self._features_dc.shape[2])]
+        names += ["f_rest_%d" % i for i in range(self._features_rest.shape[1] * self._features_rest.shape[2])]
+        names.append("opacity")
+        names += ["scale_%d" % i for i in range(self._scaling.shape[1])]
+        names += ["rot_%d" % i for i in range(self._rotation.shape[1])]
+        return names
+
+    def save_ply(self, path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        xyz = self._xyz.detach().cpu().numpy()
+        cols = [xyz, np.zeros_like(xyz),
+                self._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
+                self._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
+                self._opacity.detach().cpu().numpy(), self._scaling.detach().cpu().numpy(),
+                self._rotation.detach().cpu().numpy()]
+        table = np.concatenate(cols, axis=1).astype("<f4")
+        names = self.construct_list_of_attributes()
+        assert table.shape[1] == len(names)
+        header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % table.shape[0]
+        header += "".join("property float %s\n" % n for n in names) + "end_header\n"
+        with open(path, "wb") as f:
+            f.write(header.encode("ascii"))
+            f.write(np.ascontiguousarray(table).tobytes())
+
+    @staticmethod
+    def _read_ply(path):
+        with open(path, "rb") as f:
+            names, n, fmt = [], 0, None
+            while True:
+                line = f.readline().decode("ascii").strip()
+                if line.startswith("format"):
+                    fmt = line.split()[1]
+                elif line.startswith("element vertex"):
+                    n = int(line.split()[-1])
+                elif line.startswith("property"):
+                    parts = line.split()
+                    if parts[1] not in ("float", "float32"):
+                        raise ValueError("only float32 vertex properties are supported: %s" % line)
+                    names.append(parts[2])
+                elif line == "end_header":
+                    break
+            if fmt != "binary_little_endian":
+                raise ValueError("unsupported PLY format %r" % fmt)
+            data = np.frombuffer(f.read(n * len(names) * 4), dtype="<f4").reshape(n, len(names))
+        return {name: data[:, i] for i, name in enumerate(names)}
+
+    def load_ply(self, path):
+        col = self._read_ply(path)
+        dev = self.device
+        xyz = np.stack((col["x"], col["y"], col["z"]), axis=1)
+        n = xyz.shape[0]
+
+        def numbered(prefix):
+            keys = sorted((k for k in col if k.startswith(prefix)), key=lambda k: int(k.split("_")[-1]))
+            return np.stack([col[k] for k in keys], axis=1) if keys else np.zeros((n, 0), np.float32)
+
+        f_dc = np.stack((col["f_dc_0"], col["f_dc_1"], col["f_dc_2"]), axis=1).reshape(n, 3, 1)
+        f_rest = numbered("f_rest_")
+        assert f_rest.shape[1] == 3 * (self.max_sh_degree + 1) ** 2 - 3
+        f_rest = f_rest.reshape(n, 3, (self.max_sh_degree + 1) ** 2 - 1)
+
+        def param(a):
+            return nn.Parameter(torch.tensor(np.ascontiguousarray(a), dtype=torch.float, device=dev).requires_grad_(True))
+
+        self._xyz = param(xyz)
+        self._features_dc = nn.Parameter(torch.tensor(f_dc, dtype=torch.float, device=dev).transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(torch.tensor(f_rest, dtype=torch.float, device=dev).transpose(1, 2).contiguous().requires_grad_(True))
+        self._opacity = param(col["opacity"][..., None])
+        self._scaling = param(numbered("scale_"))
+        self._rotation = param(numbered("rot"))
+        self.active_sh_degree = self.max_sh_degree
+
+    # ------------------------------------------------------------------ optimizer surgery
+    def _rebuild(self, transform, state_transform):
+        """Replace every group's parameter by transform(name, old) and its Adam moments by state_transform(name, m);
+        returns {name: new parameter}."""
+        out = {}
+        for group in self.optimizer.param_groups:
+            assert len(group["params"]) == 1
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            new = nn.Parameter(transform(group["name"], old).requires_grad_(True))
+            if state is not None:
+                state["exp_avg"] = state_transform(group["name"], state["exp_avg"])
+                state["exp_avg_sq"] = state_transform(group["name"], state["exp_avg_sq"])
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            out[group["name"]] = new
+        return out
+
+    def _adopt(self, tensors):
+        for name, attr in _GROUPS:
+            if name in tensors:
+                setattr(self, attr, tensors[name])
+
+    def replace_tensor_to_optimizer(self, tensor, name):
+        out = {}
+        for group in self.optimizer.param_groups:
+            if group["name"] != name:
+                continue
+            state = self.optimizer.state.pop(group["params"][0], None)
+            state["exp_avg"] = torch.zeros_like(tensor)
+            state["exp_avg_sq"] = torch.zeros_like(tensor)
+            group["params"][0] = nn.Parameter(tensor.requires_grad_(True))
+            self.optimizer.state[group["params"][0]] = state
+            out[name] = group["params"][0]
+        return out
+
+    def reset_opacity(self):
+        new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
+        self._opacity = self.replace_tensor_to_optimizer(new, "opacity")["opacity"]
+
+    def _prune_optimizer(self, mask):
+        return self._rebuild(lambda _n, p: p[mask], lambda _n, m: m[mask])
+
+    def prune_points(self, mask):
+        keep = ~mask
+        self._adopt(self._prune_optimizer(keep))
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
+        self.denom = self.denom[keep]
+        self.max_radii2D = self.max_radii2D[keep]
+
+    def cat_tensors_to_optimizer(self, tensors_dict):
+        return self._rebuild(lambda n, p: torch.cat((p, tensors_dict[n]), dim=0),
+                             lambda n, m: torch.cat((m, torch.zeros_like(tensors_dict[n])), dim=0))
+
+    def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation):
+        self._adopt(self.cat_tensors_to_optimizer({"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest,
+                                                   "opacity": new_opacities, "scaling": new_scaling,
+                                                   "rotation": new_rotation}))
+        n, dev = self.get_xyz.shape[0], self.get_xyz.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        self.max_radii2D = torch.zeros((n,), device=dev)
+
+    # ------------------------------------------------------------------ densification
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        n, dev = self.get_xyz.shape[0], self.get_xyz.device
+        padded = torch.zeros((n,), device=dev)
+        padded[:grads.shape[0]] = grads.squeeze()
+        sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
+        stds = self.get_scaling[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
+        rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[sel].repeat(N, 1)
+        new_scaling = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
+        self.densification_postfix(new_xyz, self._features_dc[sel].repeat(N, 1, 1), self._features_rest[sel].repeat(N, 1, 1),
+                                   self._opacity[sel].repeat(N, 1), new_scaling, self._rotation[sel].repeat(N, 1))
+        self.prune_points(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=dev, dtype=torch.bool))))
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
+              (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
+        self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel], self._opacity[sel],
+                                   self._scaling[sel], self._rotation[sel])
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, max_world_size):
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent)
+        prune = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            prune = prune | (self.max_radii2D > max_screen_size) | (self.get_scaling.max(dim=1).values > max_world_size)
+        self.prune_points(prune)
+        if self.get_xyz.is_cuda:
+            torch.cuda.empty_cache()
+
+    def prune_only(self, min_opacity=0.05, max_world_size=0.01):
+        prune = (self.get_opacity < min_opacity).squeeze() | (self.get_scaling.max(dim=1).values > max_world_size)
+        self.prune_points(prune)
+        if self.get_xyz.is_cuda:
+            torch.cuda.empty_cache()
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1

@@ -173,7 +173,12 @@ def main():
                rotation=gm._rotation.detach().numpy().copy(), opacity=gm._opacity.detach().numpy().copy(),
                f_dc=gm._features_dc.detach().numpy().copy(), grad_accum=gm.xyz_gradient_accum.numpy().copy(),
                denom=gm.denom.numpy().copy(), viewspace=vs.numpy(), vis=vis.numpy(),
-               exp_avg_xyz=gm.optimizer.state[gm.optimizer.param_groups[0]["params"][0]]["exp_avg"].numpy().copy())
+               exp_avg_xyz=gm.optimizer.state[gm.optimizer.param_groups[0]["params"][0]]["exp_avg"].numpy().copy(),
+               f_rest=gm._features_rest.detach().numpy().copy())
+    for grp in gm.optimizer.param_groups:
+        st = gm.optimizer.state[grp["params"][0]]
+        pre["m_" + grp["name"]] = st["exp_avg"].numpy().copy()
+        pre["v_" + grp["name"]] = st["exp_avg_sq"].numpy().copy()
     torch.manual_seed(1234)   # the split samples come from torch.normal on the global generator (gaussian_model.py:368)
     gm.densify_and_prune(0.0002, 0.05, 4.0, None, 0.015)
     post = dict(xyz=gm._xyz.detach().numpy().copy(), scaling=gm._scaling.detach().numpy().copy(),
@@ -182,6 +187,10 @@ def main():
                 exp_avg_xyz=gm.optimizer.state[gm.optimizer.param_groups[0]["params"][0]]["exp_avg"].numpy().copy(),
                 exp_avg_sq_scaling=gm.optimizer.state[gm.optimizer.param_groups[4]["params"][0]]["exp_avg_sq"].numpy().copy(),
                 max_radii2D=gm.max_radii2D.numpy().copy(), denom=gm.denom.numpy().copy())
+    for grp in gm.optimizer.param_groups:
+        st = gm.optimizer.state[grp["params"][0]]
+        post["m_" + grp["name"]] = st["exp_avg"].numpy().copy()
+        post["v_" + grp["name"]] = st["exp_avg_sq"].numpy().copy()
     gm.prune_only(min_opacity=0.05, max_world_size=0.01)
     post2 = dict(xyz=gm._xyz.detach().numpy().copy(), opacity=gm._opacity.detach().numpy().copy())
     np.savez(os.path.join(OUT, "gaussian_model.npz"), points=pts, colors=cols, spatial_lr_scale=4.0, seed_before_densify=1234,
