@@ -92,21 +92,20 @@ def main():
     gC = torch.randn((V, 3, H, W), device=dev, generator=gen) * 1e-3
     gD = torch.randn((V, 1, H, W), device=dev, generator=gen) * 1e-3
     names = ["means3D", "shs", "opacities", "scales", "rotations"]
-    flat_n = sum(t[n].numel() for n in names)
-    bucket = torch.empty(flat_n, device=dev)
+
+    from gaussianip_amd import parallel
+    plist = [t[n] for n in names]
 
     def step():
         m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
         color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], sts, shs=t["shs"],
                                                      scales=t["scales"], rotations=t["rotations"])
-        grads = torch.autograd.grad([color, depth], [t[n] for n in names] + [m2d], [gC, gD])
+        grads = torch.autograd.grad([color, depth], plist + [m2d], [gC, gD])
         if world > 1:
-            torch.cat([g.reshape(-1) for g in grads[:-1]], out=bucket)
-            dist.all_reduce(bucket)
-            vs = grads[-1][..., :2].norm(dim=-1).sum(0)
-            dist.all_reduce(vs)
-            rmax = radii.max(dim=0).values
-            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+            for p_, g_ in zip(plist, grads[:-1]):
+                p_.grad = g_
+            parallel.exchange_step(plist, grads[-1][..., :2].norm(dim=-1).sum(0), radii.max(dim=0).values,
+                                   depth.max())
         return color
 
     for _ in range(args.warmup):
