@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's "ipa-guidance" plugin.
+
+Reference: threestudio/models/guidance/ipa_guidance.py — registry name :71, Config :74-123, forward_unet :311-358,
+compute_grad_anpg :361-440, compute_grad_sds :443-519, encode_images :522-531, __call__ :602-660.  Same call signature
+and returned dict ({"loss_sds", "grad_norm"}), same token layout into the U-Net ([neg x B | pos x B | null x B], each
+[77 text | 4 image tokens]; :382-386), same ANPG combine, weighting, clip and loss.
+
+Differences: networks come from gaussianip_amd.guidance.networks (no diffusers dependency; random weights unless state
+dicts are supplied); text / face-ID embeddings are inputs (`PromptEmbeddings`, `set_image_embeds`) because CLIP,
+insightface and the checkpoints are outside this path; the frozen LoRA is folded into the base weights once.
+"""
+from dataclasses import dataclass
+from typing import Any, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import sds
+from .ahds import AHDSSchedule
+from .networks import IP_TOKENS, TEXT_TOKENS, ControlNet, UNet, VAEEncoder, init_for_benchmark
+
+
+@dataclass
+class GuidanceConfig:
+    # the subset of ipa_guidance.py:74-123 that the per-step path reads (values of configs/exp.yaml:78-120 as defaults)
+    use_ipa_faceid: bool = True
+    use_pose_controlnet: bool = True
+    batch_size: int = 4
+    guidance_scale: float = 7.5
+    ipa_scale: float = 0.6
+    ipa_faceid_scale: float = 0.5
+    half_precision_weights: bool = True
+    use_anpg: bool = True
+    weighting_strategy: str = "sds"
+    view_dependent_prompting: bool = True
+    guidance_rescale: float = 0.0
+    grad_clip_pixel: bool = True
+    grad_clip_threshold: float = 1.0
+    fold_lora: bool = True
+    channels_last: bool = False   # measured on MI355X: U-Net/ControlNet equal either way, VAE 1.5x faster in NCHW
+    seed: int = 0
+
+
+class PromptEmbeddings:
+    """Stand-in for PromptProcessorOutput (prompt_processors/base.py:52-81): view-dependent text embeddings are looked
+    up from [D,77,768] tables by a direction index; returns cat[pos, neg, null] = [3B,77,768]."""
+
+    def __init__(self, pos, neg, null, direction_fn=None):
+        self.pos, self.neg, self.null, self.direction_fn = pos, neg, null, direction_fn
+
+    def get_text_embeddings(self, elevation, azimuth, center, all_vis_all, camera_distances, view_dependent_prompting=True):
+        B = elevation.shape[0]
+        if view_dependent_prompting and self.direction_fn is not None:
+            idx = self.direction_fn(elevation, azimuth, center, all_vis_all, camera_distances)
+        else:
+            idx = torch.zeros(B, dtype=torch.long, device=self.pos.device)
+        pick = lambda tab: tab[idx % tab.shape[0]]  # noqa: E731
+        return torch.cat([pick(self.pos), pick(self.neg), pick(self.null)], dim=0)
+
+
+class StableDiffusionGuidance:
+    registry_name = "ipa-guidance"
+
+    def __init__(self, cfg: Optional[GuidanceConfig] = None, device="cuda", unet=None, controlnet=None, vae=None,
+                 schedule: Optional[AHDSSchedule] = None):
+        self.cfg = cfg or GuidanceConfig()
+        self.device = torch.device(device)
+        self.weights_dtype = torch.float16 if self.cfg.half_precision_weights else torch.float32
+        scale = self.cfg.ipa_faceid_scale if self.cfg.use_ipa_faceid else self.cfg.ipa_scale
+        self.unet = unet if unet is not None else init_for_benchmark(UNet(128, True, scale), self.cfg.seed)
+        self.controlnet = controlnet if controlnet is not None else init_for_benchmark(ControlNet(), self.cfg.seed + 1)
+        self.vae = vae if vae is not None else init_for_benchmark(VAEEncoder(), self.cfg.seed + 2)
+        if self.cfg.fold_lora:
+            self.unet.fold_lora(1.0)
+        for m in (self.unet, self.controlnet, self.vae):
+            m.to(self.device, self.weights_dtype).eval().requires_grad_(False)
+            if self.cfg.channels_last and m is not self.vae:
+                m.to(memory_format=torch.channels_last)
+        self.num_train_timesteps = 1000
+        self.alphas = sds.alphas_cumprod(device=self.device)
+        self.schedule = schedule or AHDSSchedule()
+        self.ahds_chosen_t_all = self.schedule.table
+        self.ahds_chosen_t_min = self.schedule.t_min
+        z = torch.zeros(1, IP_TOKENS, 768, device=self.device, dtype=self.weights_dtype)
+        self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = z, z, z
+
+    def set_image_embeds(self, pos, neg, null):
+        """[1 or B, 4, 768] face-ID image tokens: pos = identity, null = irrelevant face, neg = zeros
+        (ip_adapter_faceid.py:362-382, ipa_guidance.py:250-257)."""
+        cast = lambda t: t.to(self.device, self.weights_dtype)  # noqa: E731
+        self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = cast(pos), cast(neg), cast(null)
+
+    # ------------------------------------------------------------------ networks
+    def forward_unet(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet=True, **_unused):
+        dt = self.weights_dtype
+        x = noisy_latents.to(dt)
+        ctx = encoder_hidden_states.to(dt)
+        if self.cfg.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        with torch.autocast("cuda", enabled=False):
+            if not use_pose_controlnet:
+                return self.unet(x, t, ctx).to(noisy_latents.dtype)
+            cond = control_img.to(dt)
+            if self.cfg.channels_last:
+                cond = cond.contiguous(memory_format=torch.channels_last)
+            down, mid = self.controlnet(x, t, ctx, cond, 1.0)
+            return self.unet(x, t, ctx, down, mid).to(noisy_latents.dtype)
+
+    def encode_images(self, imgs, generator=None):
+        x = (imgs * 2.0 - 1.0).to(self.weights_dtype)
+        with torch.autocast("cuda", enabled=False):
+            return self.vae.encode(x, generator).to(imgs.dtype)
+
+    # ------------------------------------------------------------------ gradients
+    def _prompt_embeds(self, prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, n_sets):
+        B = elevation.shape[0]
+        text = prompt_utils.get_text_embeddings(elevation, azimuth, center, all_vis_all, camera_distances,
+                                                self.cfg.view_dependent_prompting).to(self.weights_dtype)
+        pos_t, neg_t, null_t = text[:B], text[B:2 * B], text[2 * B:3 * B]
+        ex = lambda e: e.expand(B, -1, -1) if e.shape[0] == 1 else e  # noqa: E731
+        pos = torch.cat([pos_t, ex(self.pos_image_embeds)], dim=1)
+        neg = torch.cat([neg_t, ex(self.neg_image_embeds)], dim=1)
+        if n_sets == 2:
+            return torch.cat([pos, neg], dim=0)
+        null = torch.cat([null_t, ex(self.null_image_embeds)], dim=1)
+        return torch.cat([neg, pos, null], dim=0)
+
+    def compute_grad_anpg(self, latents, control_img, t, prompt_utils, use_pose_controlnet, all_vis_all, elevation,
+                          azimuth, center, camera_distances, generator=None):
+        B = elevation.shape[0]
+        embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 3)
+        assert embeds.shape[1] == TEXT_TOKENS + IP_TOKENS
+        with torch.no_grad():
+            noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
+            latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
+            noise_pred = self.forward_unet(torch.cat([latents_noisy] * 3, dim=0), torch.cat([control_img] * 3, dim=0),
+                                           torch.cat([t] * 3), embeds, use_pose_controlnet)
+            direction = sds.anpg_direction(noise_pred, t, self.cfg.guidance_scale)
+        grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
+        if self.cfg.grad_clip_pixel:
+            grad = sds.clip_grad_pixel(grad, self.cfg.grad_clip_threshold)
+        return grad, {"t_orig": t, "latents_noisy": latents_noisy, "noise_pred": noise_pred, "neg_guidance_weights": None}
+
+    def compute_grad_sds(self, latents, control_img, t, prompt_utils, use_pose_controlnet, all_vis_all, elevation,
+                         azimuth, center, camera_distances, generator=None):
+        embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 2)
+        with torch.no_grad():
+            noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
+            latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
+            noise_pred = self.forward_unet(torch.cat([latents_noisy] * 2, dim=0), torch.cat([control_img] * 2, dim=0),
+                                           torch.cat([t] * 2), embeds, use_pose_controlnet)
+            direction = sds.cfg_direction(noise_pred, noise, self.cfg.guidance_scale, self.cfg.guidance_rescale)
+        grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
+        if self.cfg.grad_clip_pixel:
+            grad = sds.clip_grad_pixel(grad, self.cfg.grad_clip_threshold)
+        return grad, {"t_orig": t, "latents_noisy": latents_noisy, "noise_pred": noise_pred}
+
+    # ------------------------------------------------------------------ the plugin call
+    def __call__(self, step, rgb, control_img, prompt_utils, use_pose_controlnet, all_vis_all, elevation, azimuth,
+                 center, camera_distances, generator=None, **kwargs: Any):
+        """rgb [B,H,W,3], control_img [B,h,w,3] -> {"loss_sds", "grad_norm"}."""
+        B = rgb.shape[0]
+        rgb_512 = F.interpolate(rgb.permute(0, 3, 1, 2), (512, 512), mode="bilinear", align_corners=False)
+        control = control_img.permute(0, 3, 1, 2)
+        latents = self.encode_images(rgb_512.to(self.weights_dtype), generator)
+        t = self.schedule.sample(step, B, self.device, generator)
+        fn = self.compute_grad_anpg if self.cfg.use_anpg else self.compute_grad_sds
+        grad, _ = fn(latents, control, t, prompt_utils, use_pose_controlnet, all_vis_all, elevation, azimuth, center,
+                     camera_distances, generator)
+        loss_sds, grad = sds.sds_loss(latents, grad)
+        return {"loss_sds": loss_sds, "grad_norm": grad.norm()}
