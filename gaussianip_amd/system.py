@@ -1,0 +1,115 @@
+"""Stage-1 step glue of the GaussianIP system, restated around the batched renderer.
+
+Reference: threestudio/systems/GaussianIP.py — forward :144-230 (loop over the batch's cameras, stack, running radii
+max, opacity := depth / (depth.max() + 1e-5)), training_step :362-395 (loss assembly), on_before_optimizer_step
+:446-475 (densification statistics + densify / prune schedule), Adam set-up :569-575.  Config values are those of
+configs/exp.yaml:66-75,131-138,163-168.  The Lightning plumbing, prompt processor and OpenPose drawing are the
+caller's (out of scope): pose maps and prompt embeddings are inputs here.
+
+One behavioural difference, by design: the cameras of a step are rendered in ONE launch set (`render_views`) instead
+of sequentially; per-view results are identical (tests/test_gpu_pipeline.py).
+"""
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from .renderer import render_views
+from .scene.cameras import Camera
+
+
+@dataclass
+class StageOneConfig:
+    # configs/exp.yaml values
+    densify_prune_start_step: int = 200
+    densify_prune_end_step: int = 1700
+    densify_prune_interval: int = 500
+    densify_prune_min_opacity: float = 0.04
+    densify_prune_screen_size_threshold: int = 20
+    densify_prune_screen_size_threshold_fix_step: int = 1500
+    densify_prune_world_size_threshold: float = 0.015
+    max_grad: float = 0.0002
+    prune_only_start_step: int = 1700
+    prune_only_end_step: int = 1900
+    prune_only_interval: int = 300
+    prune_opacity_threshold: float = 0.04
+    prune_world_size_threshold: float = 0.015
+    refine_start_step: int = 2400
+    cameras_extent: float = 4.0
+    lambda_sds: float = 1.0
+    lambda_sparsity: float = 1.0
+    lambda_opaque: float = 0.0
+    disable_hand_densification: bool = False
+    hand_radius: float = 0.05
+
+
+def binary_cross_entropy(inp, target):
+    """threestudio/utils/ops.py:295-300 (no clamping of the log like F.binary_cross_entropy)."""
+    return -(target * torch.log(inp) + (1 - target) * torch.log(1 - inp)).mean()
+
+
+class StageOneStep:
+    def __init__(self, gaussian, pipe, background: torch.Tensor, cfg: Optional[StageOneConfig] = None,
+                 hand_centers: Optional[torch.Tensor] = None):
+        self.gaussian, self.pipe, self.background = gaussian, pipe, background
+        self.cfg = cfg or StageOneConfig()
+        self.hand_centers = hand_centers
+        self.viewspace_points = None
+        self.radii = None
+        self.visibility_filter = None
+
+    # GaussianIP.forward
+    def forward(self, batch: Dict, renderbackground=None) -> Dict:
+        bg = self.background if renderbackground is None else renderbackground
+        B = batch["c2w"].shape[0]
+        cams: List[Camera] = [Camera(c2w=batch["c2w"][i], FoVy=batch["fovy"][i], height=batch["height"], width=batch["width"])
+                              for i in range(B)]
+        pkg = render_views(cams, self.gaussian, self.pipe, bg)
+        self.viewspace_points = pkg["viewspace_points"]              # [B,P,3]; .grad after backward
+        self.radii = pkg["radii"].max(dim=0).values                  # running max over the views (:165-168)
+        self.visibility_filter = self.radii > 0.0
+        if self.cfg.disable_hand_densification and self.hand_centers is not None:
+            dist = torch.norm(self.gaussian.get_xyz[:, None, :] - self.hand_centers[None, :, :], dim=-1)
+            self.visibility_filter = self.visibility_filter & ~(dist.min(dim=-1).values < self.cfg.hand_radius)
+        images = pkg["render"].permute(0, 2, 3, 1)                   # [B,H,W,3]
+        depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)               # [B,H,W,1]
+        return {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (depths.max() + 1e-5),
+                "scale": self.gaussian.get_scaling}
+
+    # GaussianIP.training_step (loss assembly)
+    def loss(self, out: Dict, guidance_out: Dict) -> torch.Tensor:
+        c = self.cfg
+        loss = guidance_out["loss_sds"] * c.lambda_sds
+        loss = loss + (out["opacity"] ** 2 + 0.01).sqrt().mean() * c.lambda_sparsity
+        if c.lambda_opaque != 0:
+            oc = out["opacity"].clamp(1.0e-3, 1.0 - 1.0e-3)
+            loss = loss + binary_cross_entropy(oc, oc) * c.lambda_opaque
+        return loss
+
+    # GaussianIP.on_before_optimizer_step (stage 1 branch)
+    @torch.no_grad()
+    def on_before_optimizer_step(self, step: int) -> Optional[str]:
+        c, g = self.cfg, self.gaussian
+        if step >= c.refine_start_step:
+            return None
+        action = None
+
+        def accumulate():
+            grad = self.viewspace_points.grad.sum(dim=0)             # sum of the per-view grads (:451-454)
+            vis = self.visibility_filter
+            g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], self.radii[vis].to(g.max_radii2D.dtype))
+            g.add_densification_stats(grad, vis)
+
+        if step < c.densify_prune_end_step:
+            accumulate()
+            min_opacity = c.densify_prune_min_opacity if step > 1900 else 0.05
+            if step > c.densify_prune_start_step and step % c.densify_prune_interval == 0:
+                screen = c.densify_prune_screen_size_threshold if step > c.densify_prune_screen_size_threshold_fix_step else None
+                g.densify_and_prune(c.max_grad, min_opacity, c.cameras_extent, screen, c.densify_prune_world_size_threshold)
+                action = "densify_and_prune"
+        if c.prune_only_start_step < step < c.prune_only_end_step:
+            accumulate()
+            if step % c.prune_only_interval == 0:
+                g.prune_only(min_opacity=c.prune_opacity_threshold, max_world_size=c.prune_world_size_threshold)
+                action = "prune_only"
+        return action

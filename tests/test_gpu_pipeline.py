@@ -143,3 +143,32 @@ def test_dropin_package_names_resolve():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: F401
     from simple_knn._C import distCUDA2
     assert float(distCUDA2(torch.rand(100, 3).cuda()).min()) > 0
+
+
+def test_stage_one_step_schedule_and_loss():
+    """GaussianIP.forward / training_step / on_before_optimizer_step mirror (gaussianip_amd/system.py)."""
+    import sys
+    from gaussianip_amd.arguments import PipelineParams
+    from gaussianip_amd.system import StageOneStep
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from make_golden import orbit_c2w
+    gm = _model(P=6000, seed=3)
+    st = StageOneStep(gm, PipelineParams(ArgumentParser()), torch.zeros(3, device="cuda"))
+    batch = dict(c2w=torch.stack([orbit_c2w(5.0, 90.0 * i, 1.5) for i in range(4)]).cuda(),
+                 fovy=torch.full((4,), math.radians(55.0)), height=128, width=128)
+    fired = {}
+    for step in (499, 500, 1000, 1500, 1700, 1800):
+        out = st.forward(batch)
+        assert out["comp_rgb"].shape == (4, 128, 128, 3) and out["opacity"].shape == (4, 128, 128, 1)
+        assert float(out["opacity"].max()) <= 1.0
+        loss = st.loss(out, {"loss_sds": (out["comp_rgb"] ** 2).mean()})
+        gm.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        n0 = gm.get_xyz.shape[0]
+        fired[step] = st.on_before_optimizer_step(step)
+        if fired[step] is None:
+            gm.optimizer.step()
+        else:
+            assert gm.get_xyz.shape[0] != n0 or fired[step] == "prune_only"
+    assert fired == {499: None, 500: "densify_and_prune", 1000: "densify_and_prune", 1500: "densify_and_prune",
+                     1700: None, 1800: "prune_only"}
