@@ -43,7 +43,8 @@ class GaussianRasterizationSettings(NamedTuple):
 # capacity policy (replaces the reference's per-call D2H of num_rendered)
 # ---------------------------------------------------------------------------------------------
 _MIN_CAPACITY = 1 << 20
-_capacity_hint = {}     # (device index, P bucket, V, H, W) -> last observed num_rendered
+_CAPACITY_MARGIN = 65536
+_capacity_hint = {}     # (device index, P, V, H, W) -> last observed num_rendered
 _pending_checks = []    # (event, pinned header, key, capacity) of no-grad-free calls not yet verified
 
 
@@ -52,14 +53,15 @@ def _strict():
 
 
 def _hint_key(dev, P, V, H, W):
-    return (dev.index if dev.index is not None else torch.cuda.current_device(), V, H, W)
+    # keyed by P too: a densify / prune step changes P, and the first call with the new P sizes itself synchronously
+    return (dev.index if dev.index is not None else torch.cuda.current_device(), P, V, H, W)
 
 
 def _pick_capacity(key, P, V):
     last = _capacity_hint.get(key)
     if last is None:
         return None  # unknown: first call learns it synchronously
-    return int(max(_MIN_CAPACITY, 3 * last + 65536))
+    return int(max(_MIN_CAPACITY, 3 * last + _CAPACITY_MARGIN))
 
 
 _dummy = {}
@@ -259,11 +261,12 @@ class _RasterizeGaussians(torch.autograd.Function):
     """Differentiable V-view rasterization.  Inputs that are None are passed as None (the fork passes empty tensors)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list,
+                need_bwd=True):
+        # `need_bwd` is decided by the caller (grad mode is always off inside Function.forward and
+        # ctx.needs_input_grad ignores torch.no_grad()): a backward will follow, so the overflow check may be deferred
         plan = _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list)
-        need_bwd = any(t is not None and t.requires_grad for t in
-                       (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
-        color, radii, depth, alpha = _forward_with_policy(plan, need_bwd and torch.is_grad_enabled())
+        color, radii, depth, alpha = _forward_with_policy(plan, need_bwd)
         ctx.plan = plan
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(color, depth, alpha)
@@ -284,7 +287,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         g = _run_backward(plan, (color, depth, alpha), prep(g_color), prep(g_depth), prep(g_alpha))
         g2d = None if ctx.means2D_shape is None else g["means2D"].reshape(ctx.means2D_shape)
         return (g["means3D"], g2d, g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"],
-                g["cov3D_precomp"], None)
+                g["cov3D_precomp"], None, None)
+
+
+def _will_backward(tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def _validate(shs, colors_precomp, scales, rotations, cov3D_precomp):
@@ -298,8 +305,8 @@ def _validate(shs, colors_precomp, scales, rotations, cov3D_precomp):
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     """Single view; returns the reference 4-tuple with the reference shapes."""
-    color, radii, depth, alpha = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
-                                                           rotations, cov3Ds_precomp, [raster_settings])
+    ins = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+    color, radii, depth, alpha = _RasterizeGaussians.apply(*ins, [raster_settings], _will_backward(ins))
     return color[0], radii[0], depth[0], alpha[0]
 
 
@@ -308,8 +315,8 @@ def rasterize_views(means3D, means2D, opacities, settings_list: Sequence[Gaussia
     """V views in one launch set.  means2D: [V,P,3] zero grad carrier (or None).
     Returns color [V,3,H,W], radii [V,P], depth [V,1,H,W], alpha [V,1,H,W]."""
     _validate(shs, colors_precomp, scales, rotations, cov3D_precomp)
-    return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                     cov3D_precomp, list(settings_list))
+    ins = (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+    return _RasterizeGaussians.apply(*ins, list(settings_list), _will_backward(ins))
 
 
 class GaussianRasterizer(torch.nn.Module):
