@@ -83,9 +83,15 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
       a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
       a[8] += r2.x; a[9] += r2.y;
     }
-    const float g2x = a[0], g2y = a[1], gcx = a[2], gcy = a[3], gcw = a[4];
+    // rows hold moments of Q = dL/dG * G (render_backward.hip); apply this (view, Gaussian)'s constants once
+    const float4 q0r = reinterpret_cast<const float4*>(rec)[0];
+    const float4 q1r = reinterpret_cast<const float4*>(rec)[1];
+    const float con_a = q1r.x, con_b = q1r.y, con_c = q1r.z, opac = q0r.w;
+    const float g2x = -(con_a * a[0] + con_b * a[1]) * (0.5f * kp.W);
+    const float g2y = -(con_c * a[1] + con_b * a[0]) * (0.5f * kp.H);
+    const float gcx = -0.5f * a[2], gcy = -0.5f * a[3], gcw = -0.5f * a[4];
     if (d2) { d2[0] = g2x; d2[1] = g2y; d2[2] = 0.f; }
-    dopac += a[5];
+    dopac += opac != 0.f ? a[5] / opac : 0.f;
 
     const float* view = viewmatrix + 16 * v;
     const float* proj = projmatrix + 16 * v;

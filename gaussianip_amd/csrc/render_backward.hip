@@ -23,8 +23,8 @@
 //   * quadrants that the entry's alpha >= 1/255 ellipse misses are skipped with wave-uniform branches
 //     (same conservative quadrant mask as the forward kernel).
 //
-// Row layout (floats): 0,1 dL/dmean2D.xy (NDC units)  2,3,4 dL/dconic (x, y, w slots)  5 dL/dopacity
-//                      6,7,8 dL/dcolour  9 dL/ddepth  10..15 zero
+// Row layout (floats): 0,1 M1,M2  2,3,4 M3,M4,M5  5 M0   (moments of Q = dL/dG * G over the pixel offsets dx, dy)
+//                      6,7,8 dL/dcolour  9 dL/ddepth  10..15 unused
 #include "gip_internal.h"
 
 #ifndef BWD_GRID
@@ -36,17 +36,20 @@ __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
   return v + __builtin_bit_cast(float, moved);
 }
-// lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]   (v_permlane32_swap + add)
-__device__ __forceinline__ float fold32(float a, float b) {
-  // inline asm: the clang builtin's second result is mis-selected for float operands on ROCm 7.2 (both
-  // extracts return the first register); the swap updates both registers in place.
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return a + b;
+// Cross-lane folds.  v_permlane32_swap(a, b): lanes 0-31 keep a, take b's low half into a's high half ...
+// after the swap a = [a_lo | b_lo], b = [a_hi | b_hi], so a + b = [sum of a's halves | sum of b's halves].
+// v_permlane16_swap does the same on 16-lane rows (odd rows of a <-> even rows of b).
+// Inline asm because the clang builtin mis-selects its second result for float operands on ROCm 7.2 (both extracts
+// return the first register); one s_nop pair per GROUP of independent swaps covers the VALU->permlane hazards.
+__device__ __forceinline__ void fold32x5(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2, float& a3,
+                                         float& b3, float& a4, float& b4) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
+               "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\ts_nop 1"
+               : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3), "+v"(a4), "+v"(b4));
 }
-// rows (16 lanes) 0,2 <- a.row(r) + a.row(r+1), rows 1,3 <- b.row(r-1) + b.row(r)   (v_permlane16_swap + add)
-__device__ __forceinline__ float fold16(float a, float b) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return a + b;
+__device__ __forceinline__ void fold16x2(float& a0, float& b0, float& a1, float& b1) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+               : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
 }
 // sum of each 16-lane row, valid in the row's lane 15
 __device__ __forceinline__ float row_reduce(float v) {
@@ -65,7 +68,7 @@ struct BwdPix {
 struct BwdAcc { float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9; };
 
 __device__ __forceinline__ bool bwd_pair(BwdPix& p, BwdAcc& a, float pxf, float pyf, const float2 xy, const float4 co,
-                                         const float4 cl, uint32_t i, float ddelx_dx, float ddely_dy) {
+                                         const float4 cl, uint32_t i) {
   const float dx = xy.x - pxf, dy = xy.y - pyf;
   const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
   const float G = __expf(power);
@@ -79,14 +82,14 @@ __device__ __forceinline__ bool bwd_pair(BwdPix& p, BwdAcc& a, float pxf, float 
   const float dL_dalpha = c ? p.T * kappa + (p.Sp + p.Kc) * rcp1ma : 0.f;
   p.T = c ? p.T * (1.f - alpha) : p.T;
   a.v6 += w * p.g0; a.v7 += w * p.g1; a.v8 += w * p.g2; a.v9 += w * p.gd;
-  const float dL_dG = co.w * dL_dalpha;
-  const float gdx = G * dx, gdy = G * dy;
-  a.v0 += dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
-  a.v1 += dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
-  a.v2 += -0.5f * gdx * dx * dL_dG;
-  a.v3 += -0.5f * gdx * dy * dL_dG;
-  a.v4 += -0.5f * gdy * dy * dL_dG;
-  a.v5 += G * dL_dalpha;
+  // geometric terms as MOMENTS of Q = dL/dG * G over the pixel offsets; the per-Gaussian constants (conic,
+  // opacity, 0.5 W/H) are applied once per Gaussian in gather_backward.hip:
+  //   dL/dmean2D = -(a M1 + b M2, c M2 + b M1) * 0.5 (W, H),  dL/dconic = -0.5 (M3, M4, M5),  dL/dopacity = M0 / o
+  const float Q = co.w * dL_dalpha * G;
+  const float Qdx = Q * dx, Qdy = Q * dy;
+  a.v5 += Q;
+  a.v0 += Qdx; a.v1 += Qdy;
+  a.v2 += Qdx * dx; a.v3 += Qdx * dy; a.v4 += Qdy * dy;
   return c;
 }
 
@@ -113,7 +116,6 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
   const size_t HW = (size_t)kp.H * kp.W;
-  const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   uint32_t nseg = header->num_segments;
   if (nseg > kp.seg_capacity) nseg = kp.seg_capacity;
@@ -254,10 +256,10 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
         const float4 cl = s_col[j];
         BwdAcc a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         bool c = false;
-        if (mk & 1u) c |= bwd_pair(p[0], a, pxf0, pyf0, xy, co, cl, i, ddelx_dx, ddely_dy);
-        if (mk & 2u) c |= bwd_pair(p[1], a, pxf1, pyf0, xy, co, cl, i, ddelx_dx, ddely_dy);
-        if (mk & 4u) c |= bwd_pair(p[2], a, pxf0, pyf1, xy, co, cl, i, ddelx_dx, ddely_dy);
-        if (mk & 8u) c |= bwd_pair(p[3], a, pxf1, pyf1, xy, co, cl, i, ddelx_dx, ddely_dy);
+        if (mk & 1u) c |= bwd_pair(p[0], a, pxf0, pyf0, xy, co, cl, i);
+        if (mk & 2u) c |= bwd_pair(p[1], a, pxf1, pyf0, xy, co, cl, i);
+        if (mk & 4u) c |= bwd_pair(p[2], a, pxf0, pyf1, xy, co, cl, i);
+        if (mk & 8u) c |= bwd_pair(p[3], a, pxf1, pyf1, xy, co, cl, i);
         if (rowj == 0xffffffffu) continue;
         float* dst = partial + (size_t)rowj * GIP_PARTIAL_FLOATS;
         if (!__any(c)) {
@@ -265,15 +267,15 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
           continue;
         }
         // 64-lane sums of the ten terms in 27 cross-lane ops
-        const float p02 = fold32(a.v0, a.v2), p13 = fold32(a.v1, a.v3);   // [v0|v2], [v1|v3]
-        const float p46 = fold32(a.v4, a.v6), p57 = fold32(a.v5, a.v7);
-        const float p89 = fold32(a.v8, a.v9);
-        float qa = fold16(p02, p13);   // rows: v0, v1, v2, v3
-        float qb = fold16(p46, p57);   // rows: v4, v5, v6, v7
-        qa = row_reduce(qa);
-        qb = row_reduce(qb);
-        float qc = row_reduce(p89);    // rows 0,1: v8 ; rows 2,3: v9
-        qc = dpp_add<0x142, 0xa>(qc);  // row_bcast:15 -> lane 31 = v8, lane 63 = v9
+        fold32x5(a.v0, a.v2, a.v1, a.v3, a.v4, a.v6, a.v5, a.v7, a.v8, a.v9);
+        float p02 = a.v0 + a.v2, p13 = a.v1 + a.v3;   // [v0|v2], [v1|v3]
+        float p46 = a.v4 + a.v6, p57 = a.v5 + a.v7;
+        const float p89 = a.v8 + a.v9;
+        fold16x2(p02, p13, p46, p57);
+        float qa = row_reduce(p02 + p13);   // rows: v0, v1, v2, v3
+        float qb = row_reduce(p46 + p57);   // rows: v4, v5, v6, v7
+        float qc = row_reduce(p89);         // rows 0,1: v8 ; rows 2,3: v9
+        qc = dpp_add<0x142, 0xa>(qc);       // row_bcast:15 -> lane 31 = v8, lane 63 = v9
         if ((lane & 15) == 15) {
           const int r = lane >> 4;
           dst[r] = qa;
