@@ -44,7 +44,7 @@ extern "C" {
 #define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
 #define GIP_PARTIAL_FLOATS 16  /* per-(tile, Gaussian) gradient partial row, 64 bytes */
 #ifndef GIP_SEGMENT
-#define GIP_SEGMENT 256
+#define GIP_SEGMENT 64
 #endif
 //#define GIP_SEGMENT_DOC        /* list entries per backward work item; forward checkpoints every GIP_SEGMENT entries */
 #define GIP_SLOTS 8            /* bucket slots remembered per (view, Gaussian): scatter needs no second atomic for these */
