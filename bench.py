@@ -51,8 +51,8 @@ def stage_bytes(stage, P, K, R, T, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=100000)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--views", type=int, default=4)

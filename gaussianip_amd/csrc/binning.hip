@@ -152,15 +152,30 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
     mx = c > mx ? c : mx;
   }
   U3 total;
-  U3 run = block_excl_scan3(sum, s_wave, &total);
-  for (int i = lo; i < hi; i++) {
-    const uint32_t c = cnt_at(i), a = nseg_of(c);
-    tile_start[i] = run.a; seg_start[i] = run.b; ckpt_start[i] = run.c;
-#if !(SCAN_SKIP & 2)
-    for (uint32_t b = 0; b < a; b++)
-      if (run.b + b < kp.seg_capacity) seg_tile[run.b + b] = (uint32_t)i;
-#endif
-    run.a += c; run.b += a; run.c += a ? a - 1 : 0;
+  const U3 run0 = block_excl_scan3(sum, s_wave, &total);
+  if (in_lds && 2 * n <= SCAN_LDS_TILES) {
+    // prefixes go through a second LDS array so that the global stores are coalesced (a thread's own chunk is
+    // 16 consecutive words: written directly it costs 64 separate cache lines per wave store)
+    uint32_t* s_out = s_cnt + n;
+    for (int which = 0; which < 3; which++) {
+      uint32_t r = which == 0 ? run0.a : which == 1 ? run0.b : run0.c;
+      for (int i = lo; i < hi; i++) {
+        const uint32_t c = s_cnt[i], a = nseg_of(c);
+        s_out[i] = r;
+        r += which == 0 ? c : which == 1 ? a : (a ? a - 1 : 0);
+      }
+      __syncthreads();
+      uint32_t* dst = which == 0 ? tile_start : which == 1 ? seg_start : ckpt_start;
+      for (int i = threadIdx.x; i < n; i += SCAN_THREADS) dst[i] = s_out[i];
+      __syncthreads();
+    }
+  } else {
+    U3 run = run0;
+    for (int i = lo; i < hi; i++) {
+      const uint32_t c = cnt_at(i), a = nseg_of(c);
+      tile_start[i] = run.a; seg_start[i] = run.b; ckpt_start[i] = run.c;
+      run.a += c; run.b += a; run.c += a ? a - 1 : 0;
+    }
   }
   if (threadIdx.x == 0) { tile_start[n] = total.a; seg_start[n] = total.b; ckpt_start[n] = total.c; }
   mx = gip_wave_max_u32(mx);
@@ -199,7 +214,7 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   const int n = kp.V * kp.T;
-  const size_t lds = n <= SCAN_LDS_TILES ? (size_t)n * 4 : 0;
+  const size_t lds = n <= SCAN_LDS_TILES ? (size_t)(2 * n <= SCAN_LDS_TILES ? 2 * n : n) * 4 : 0;
   // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process)
   static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(gip_scan_kernel),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_TILES * 4);
@@ -372,7 +387,8 @@ __device__ void sort_big_tile(unsigned long long* a, uint32_t n, unsigned long l
 
 __global__ void __launch_bounds__(GIP_BLOCK)
 gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
-                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys) {
+                     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ seg_start,
+                     uint32_t* __restrict__ seg_tile, unsigned long long* __restrict__ keys) {
   __shared__ unsigned long long s_keys[BIG_CHUNK];
   uint32_t pos_lo, pos_hi, first, stride;
   bool big = false;
@@ -389,8 +405,15 @@ gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ hea
     const uint32_t start = tile_start[t];
     uint32_t end = tile_start[t + 1];
     if (end > kp.capacity) end = kp.capacity;
-    if (end <= start + 1) continue;
+    if (end <= start) continue;
     const uint32_t n = end - start;
+    // segment -> tile map of this tile's segments (work list of the backward kernel)
+    {
+      const uint32_t s0 = seg_start[t], ns = (n + GIP_SEGMENT - 1) / GIP_SEGMENT;
+      for (uint32_t b = threadIdx.x; b < ns; b += GIP_BLOCK)
+        if (s0 + b < kp.seg_capacity) seg_tile[s0 + b] = t;
+    }
+    if (n <= 1) continue;
     if (big) {
       sort_big_tile(keys + start, n, s_keys);
     } else {
@@ -405,5 +428,5 @@ gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ hea
 
 void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   hipLaunchKernelGGL(gip_tile_sort_kernel, dim3(SORT_WG_BIG + SORT_WG_MID + SORT_WG_SMALL), dim3(GIP_BLOCK), 0, s, kp,
-                     st.header, st.tile_order, st.tile_start, st.keys);
+                     st.header, st.tile_order, st.tile_start, st.seg_start, st.seg_tile, st.keys);
 }
