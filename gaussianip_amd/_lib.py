@@ -111,6 +111,28 @@ def knn_lib():
     return _knn
 
 
+_nn = None
+
+
+def nn_lib():
+    global _nn
+    if _nn is None:
+        path = os.path.join(LIB_DIR, "libgip_nn.so")
+        if not os.path.exists(path):
+            raise _missing("libgip_nn.so")
+        lib = ctypes.CDLL(path)
+        lib.gip_gn_workspace_bytes.restype = ctypes.c_size_t
+        lib.gip_gn_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        lib.gip_gn_silu_forward.restype = ctypes.c_int
+        lib.gip_gn_silu_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_float, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]
+        lib.gip_gn_silu_backward.restype = ctypes.c_int
+        lib.gip_gn_silu_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64,
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]
+        _nn = lib
+    return _nn
+
+
 def status_string(rc):
     return raster_lib().gip_status_string(int(rc)).decode()
 

@@ -1,0 +1,251 @@
+// groupnorm.hip — fused GroupNorm(+SiLU) forward / backward for channels-last fp16 tensors on gfx950.
+//
+// See include/gip_nn.h.  Memory-bound: one statistics pass (read x) and one apply pass (read x, write y) with 16-byte
+// (8 x half) accesses per lane, fp32 accumulation.  A lane owns one fixed 8-channel chunk and walks rows, so its eight
+// per-channel accumulators live in registers; channel sums are folded into group sums through LDS once per workgroup
+// and the per-split partials are reduced by the apply kernel's prologue (no atomics on global memory, deterministic).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/gip_nn.h"
+
+#define GN_BLOCK 256
+#define GN_MAX_SPLITS 64
+
+struct alignas(16) half8 { __half2 a, b, c, d; };
+
+__device__ __forceinline__ void unpack8(const half8& h, float* f) {
+  const float2 x = __half22float2(h.a), y = __half22float2(h.b), z = __half22float2(h.c), w = __half22float2(h.d);
+  f[0] = x.x; f[1] = x.y; f[2] = y.x; f[3] = y.y; f[4] = z.x; f[5] = z.y; f[6] = w.x; f[7] = w.y;
+}
+__device__ __forceinline__ half8 pack8(const float* f) {
+  half8 h;
+  h.a = __floats2half2_rn(f[0], f[1]); h.b = __floats2half2_rn(f[2], f[3]);
+  h.c = __floats2half2_rn(f[4], f[5]); h.d = __floats2half2_rn(f[6], f[7]);
+  return h;
+}
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float dsilu_f(float v) { const float s = 1.f / (1.f + __expf(-v)); return s * (1.f + v * (1.f - s)); }
+
+// geometry shared by all kernels: lanes are laid out as (chunk, row-lane); tpr = C / 8 chunks per row
+struct GnGeom { int tpr, chunks_per_thread, rows_per_iter; };
+__device__ __forceinline__ GnGeom geom(int C) {
+  GnGeom g;
+  g.tpr = C >> 3;
+  g.chunks_per_thread = (g.tpr + GN_BLOCK - 1) / GN_BLOCK;                 // > 1 only for C > 2048
+  const int lanes_x = (g.tpr + g.chunks_per_thread - 1) / g.chunks_per_thread;
+  g.rows_per_iter = max(1, GN_BLOCK / lanes_x);
+  return g;
+}
+
+// MODE 0: sum(x), sum(x^2)                         -> forward statistics
+// MODE 1: sum(dxh), sum(dxh * xh), dxh = dy * dsilu?(gamma xh + beta) * gamma   -> backward reductions
+template <int MODE>
+__global__ void __launch_bounds__(GN_BLOCK)
+gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const __half* __restrict__ gamma,
+                 const __half* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
+                 float* __restrict__ partial /* [N, splits, G, 2] */, long long HW, int C, int G, int splits, int silu) {
+  extern __shared__ float s_ch[];   // [rows_per_iter][C][2]: one slot per (row-lane, channel) -> fixed-order sums
+  const int n = blockIdx.y, split = blockIdx.x;
+  const GnGeom gm = geom(C);
+  const int lanes_x = (gm.tpr + gm.chunks_per_thread - 1) / gm.chunks_per_thread;
+  const int cx = threadIdx.x % lanes_x, ry = threadIdx.x / lanes_x;
+  const bool active = ry < gm.rows_per_iter;
+  const long long rows_per_split = (HW + splits - 1) / splits;
+  const long long r0 = (long long)split * rows_per_split, r1 = min(HW, r0 + rows_per_split);
+  const int cg = C / G;
+  for (int i = threadIdx.x; i < 2 * C * gm.rows_per_iter; i += GN_BLOCK) s_ch[i] = 0.f;
+  __syncthreads();
+  for (int k = 0; k < gm.chunks_per_thread; k++) {
+    const int chunk = cx + k * lanes_x;
+    if (!active || chunk >= gm.tpr) continue;
+    float a0[8], a1[8], ga[8], be[8], mu[8], rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { a0[j] = 0.f; a1[j] = 0.f; }
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int c = chunk * 8 + j;
+        ga[j] = __half2float(gamma[c]); be[j] = __half2float(beta[c]);
+        mu[j] = mean[n * G + c / cg]; rs[j] = rstd[n * G + c / cg];
+      }
+    }
+    const half8* xp = x + ((long long)n * HW) * gm.tpr + chunk;
+    const half8* dp = MODE == 1 ? dy + ((long long)n * HW) * gm.tpr + chunk : nullptr;
+    for (long long r = r0 + ry; r < r1; r += gm.rows_per_iter) {
+      float v[8];
+      unpack8(xp[r * gm.tpr], v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { a0[j] += v[j]; a1[j] += v[j] * v[j]; }
+      } else {
+        float d[8];
+        unpack8(dp[r * gm.tpr], d);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float xh = (v[j] - mu[j]) * rs[j];
+          float g = d[j];
+          if (silu) g *= dsilu_f(ga[j] * xh + be[j]);
+          const float dxh = g * ga[j];
+          a0[j] += dxh; a1[j] += dxh * xh;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      s_ch[2 * ((size_t)ry * C + chunk * 8 + j)] = a0[j];
+      s_ch[2 * ((size_t)ry * C + chunk * 8 + j) + 1] = a1[j];
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += GN_BLOCK) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; c++)
+      for (int r = 0; r < gm.rows_per_iter; r++) { s0 += s_ch[2 * ((size_t)r * C + c)]; s1 += s_ch[2 * ((size_t)r * C + c) + 1]; }
+    float* o = partial + (((long long)n * splits + split) * G + g) * 2;
+    o[0] = s0; o[1] = s1;
+  }
+}
+
+// apply: MODE 0 forward (writes y, and mean / rstd once per sample), MODE 1 backward (writes dx)
+template <int MODE>
+__global__ void __launch_bounds__(GN_BLOCK)
+gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const __half* __restrict__ gamma,
+                const __half* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
+                const float* __restrict__ partial, half8* __restrict__ out, long long HW, int C, int G, int splits,
+                int out_splits, float eps, int silu) {
+  extern __shared__ float s_g[];   // [G][2]: forward mean, rstd ; backward S1/m, S2/m
+  const int n = blockIdx.y, split = blockIdx.x;
+  const GnGeom gm = geom(C);
+  const int lanes_x = (gm.tpr + gm.chunks_per_thread - 1) / gm.chunks_per_thread;
+  const int cx = threadIdx.x % lanes_x, ry = threadIdx.x / lanes_x;
+  const bool active = ry < gm.rows_per_iter;
+  const int cg = C / G;
+  const float inv_m = 1.f / ((float)HW * (float)cg);
+  for (int g = threadIdx.x; g < G; g += GN_BLOCK) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int s = 0; s < splits; s++) {
+      const float* p = partial + (((long long)n * splits + s) * G + g) * 2;
+      s0 += p[0]; s1 += p[1];
+    }
+    if (MODE == 0) {
+      const float mu = s0 * inv_m;
+      const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
+      const float rs = rsqrtf(var + eps);
+      s_g[2 * g] = mu; s_g[2 * g + 1] = rs;
+      if (split == 0) { mean[n * G + g] = mu; rstd[n * G + g] = rs; }
+    } else {
+      s_g[2 * g] = s0 * inv_m; s_g[2 * g + 1] = s1 * inv_m;
+    }
+  }
+  __syncthreads();
+  const long long rows_per_split = (HW + out_splits - 1) / out_splits;
+  const long long r0 = (long long)split * rows_per_split, r1 = min(HW, r0 + rows_per_split);
+  for (int k = 0; k < gm.chunks_per_thread; k++) {
+    const int chunk = cx + k * lanes_x;
+    if (!active || chunk >= gm.tpr) continue;
+    float sc[8], sh[8], ga[8], be[8], mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int c = chunk * 8 + j, g = c / cg;
+      ga[j] = __half2float(gamma[c]); be[j] = __half2float(beta[c]);
+      if (MODE == 0) {
+        sc[j] = s_g[2 * g + 1] * ga[j];
+        sh[j] = be[j] - s_g[2 * g] * sc[j];
+      } else {
+        mu[j] = mean[n * G + g]; rs[j] = rstd[n * G + g];
+        m1[j] = s_g[2 * g]; m2[j] = s_g[2 * g + 1];
+      }
+    }
+    const long long base = ((long long)n * HW) * gm.tpr + chunk;
+    for (long long r = r0 + ry; r < r1; r += gm.rows_per_iter) {
+      float v[8], o[8];
+      unpack8(x[base + r * gm.tpr], v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float y = sc[j] * v[j] + sh[j];
+          o[j] = silu ? silu_f(y) : y;
+        }
+      } else {
+        float d[8];
+        unpack8(dy[base + r * gm.tpr], d);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float xh = (v[j] - mu[j]) * rs[j];
+          float g = d[j];
+          if (silu) g *= dsilu_f(ga[j] * xh + be[j]);
+          const float dxh = g * ga[j];
+          o[j] = rs[j] * (dxh - m1[j] - xh * m2[j]);
+        }
+      }
+      out[base + r * gm.tpr] = pack8(o);
+    }
+  }
+}
+
+static size_t reduce_lds_bytes(int C) {
+  const int tpr = C >> 3, cpt = (tpr + GN_BLOCK - 1) / GN_BLOCK, lanes_x = (tpr + cpt - 1) / cpt;
+  const int rpi = GN_BLOCK / lanes_x > 0 ? GN_BLOCK / lanes_x : 1;
+  return (size_t)rpi * C * 2 * sizeof(float);
+}
+
+static int pick_splits(int N, long long HW, int C) {
+  // enough workgroups to fill the chip (256 CUs x a few), at least ~64 rows each
+  long long want = (2048 + N - 1) / N;
+  long long by_rows = (HW + 63) / 64;
+  long long s = want < by_rows ? want : by_rows;
+  if (s < 1) s = 1;
+  (void)C;
+  return (int)s;
+}
+
+extern "C" size_t gip_gn_workspace_bytes(int32_t N, int32_t G) {
+  return (size_t)N * GN_MAX_SPLITS * G * 2 * sizeof(float);
+}
+
+static int check(const void* a, const void* b, int32_t N, long long HW, int32_t C, int32_t G, size_t ws) {
+  if (!a || !b || N < 1 || HW < 1 || C < 8 || (C & 7) || G < 1 || C % G || C > 8192) return 1;
+  if (ws < gip_gn_workspace_bytes(N, G)) return 2;
+  return 0;
+}
+
+extern "C" int gip_gn_silu_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                                   int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t apply_silu,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check(x, y, N, HW, C, G, workspace_bytes);
+  if (rc) return rc;
+  if (!gamma || !beta || !mean || !rstd || !workspace) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  int splits = pick_splits(N, HW, C);
+  const int rsplits = splits > GN_MAX_SPLITS ? GN_MAX_SPLITS : splits;
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL((gn_reduce_kernel<0>), dim3(rsplits, N), dim3(GN_BLOCK), reduce_lds_bytes(C), s,
+                     (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta,
+                     (const float*)nullptr, (const float*)nullptr, partial, (long long)HW, C, G, rsplits, apply_silu);
+  hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)G * 2 * sizeof(float), s,
+                     (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
+                     (const float*)partial, (half8*)y, (long long)HW, C, G, rsplits, splits, eps, apply_silu);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
+                                    const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G,
+                                    int32_t apply_silu, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check(x, dx, N, HW, C, G, workspace_bytes);
+  if (rc) return rc;
+  if (!dy || !gamma || !beta || !mean || !rstd || !workspace) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  int splits = pick_splits(N, HW, C);
+  const int rsplits = splits > GN_MAX_SPLITS ? GN_MAX_SPLITS : splits;
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL((gn_reduce_kernel<1>), dim3(rsplits, N), dim3(GN_BLOCK), reduce_lds_bytes(C), s,
+                     (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta, mean, rstd, partial,
+                     (long long)HW, C, G, rsplits, apply_silu);
+  hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(splits, N), dim3(GN_BLOCK), (size_t)G * 2 * sizeof(float), s,
+                     (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta,
+                     const_cast<float*>(mean), const_cast<float*>(rstd), (const float*)partial, (half8*)dx,
+                     (long long)HW, C, G, rsplits, splits, 0.f, apply_silu);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

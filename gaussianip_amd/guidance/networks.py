@@ -25,6 +25,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused import GroupNormAct
+
 TEXT_TOKENS = 77
 IP_TOKENS = 4
 
@@ -40,18 +42,18 @@ def timestep_embedding(t, dim=320, max_period=10000.0):
 class ResBlock(nn.Module):
     def __init__(self, cin, cout, temb_dim=1280, eps=1e-5):
         super().__init__()
-        self.norm1 = nn.GroupNorm(32, cin, eps=eps)
+        self.norm1 = GroupNormAct(32, cin, eps=eps, act=True)       # GroupNorm + SiLU fused (csrc/groupnorm.hip)
         self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
         self.time_emb_proj = nn.Linear(temb_dim, cout) if temb_dim else None
-        self.norm2 = nn.GroupNorm(32, cout, eps=eps)
+        self.norm2 = GroupNormAct(32, cout, eps=eps, act=True)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv1(self.norm1(x))
         if self.time_emb_proj is not None:
             h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv2(self.norm2(h))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 
@@ -131,7 +133,7 @@ class TransformerBlock(nn.Module):
 class SpatialTransformer(nn.Module):
     def __init__(self, dim, ctx_dim=768, heads=8, lora_rank=0, ip=False, ip_scale=1.0):
         super().__init__()
-        self.norm = nn.GroupNorm(32, dim, eps=1e-6)
+        self.norm = GroupNormAct(32, dim, eps=1e-6, act=False)
         self.proj_in = nn.Conv2d(dim, dim, 1)
         self.block = TransformerBlock(dim, ctx_dim, heads, lora_rank, ip, ip_scale)
         self.proj_out = nn.Conv2d(dim, dim, 1)
@@ -218,7 +220,7 @@ class UNet(_Encoder):
                 self.up_attn.append(SpatialTransformer(w, 768, 8, lora_rank, ip_adapter, ip_scale) if i > 0 else nn.Identity())
                 c = w
             self.up_sample.append(Upsample(w) if i < 3 else nn.Identity())
-        self.norm_out = nn.GroupNorm(32, 320)
+        self.norm_out = GroupNormAct(32, 320, act=True)
         self.conv_out = nn.Conv2d(320, 4, 3, padding=1)
 
     def forward(self, x, t, ctx, down_residuals: Optional[List[torch.Tensor]] = None, mid_residual=None):
@@ -237,7 +239,7 @@ class UNet(_Encoder):
                 k += 1
             if i < 3:
                 h = self.up_sample[i](h)
-        return self.conv_out(F.silu(self.norm_out(h)))
+        return self.conv_out(self.norm_out(h))
 
     @torch.no_grad()
     def fold_lora(self, scale=1.0):
@@ -289,10 +291,10 @@ class VAEEncoder(nn.Module):
                 c = w
             self.down.append(Downsample(w, asymmetric=True) if i < 3 else nn.Identity())
         self.mid_res1, self.mid_res2 = ResBlock(512, 512, 0, 1e-6), ResBlock(512, 512, 0, 1e-6)
-        self.mid_norm = nn.GroupNorm(32, 512, eps=1e-6)
+        self.mid_norm = GroupNormAct(32, 512, eps=1e-6, act=False)
         self.mid_attn = Attention(512, None, heads=1)
         self.mid_attn.to_q, self.mid_attn.to_k, self.mid_attn.to_v = nn.Linear(512, 512), nn.Linear(512, 512), nn.Linear(512, 512)
-        self.norm_out = nn.GroupNorm(32, 512, eps=1e-6)
+        self.norm_out = GroupNormAct(32, 512, eps=1e-6, act=True)
         self.conv_out = nn.Conv2d(512, 8, 3, padding=1)
         self.quant_conv = nn.Conv2d(8, 8, 1)
 
@@ -306,7 +308,7 @@ class VAEEncoder(nn.Module):
         a = self.mid_attn(self.mid_norm(h).permute(0, 2, 3, 1).reshape(B, H * W, C))
         h = h + a.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = self.mid_res2(h)
-        return self.quant_conv(self.conv_out(F.silu(self.norm_out(h))))
+        return self.quant_conv(self.conv_out(self.norm_out(h)))
 
     def encode(self, x, generator=None):
         """latent_dist.sample() * scaling_factor — stochastic and differentiable, like ipa_guidance.py:522-531."""
@@ -328,6 +330,6 @@ def init_for_benchmark(module, seed=0):
             else:
                 p.zero_()
         for m in module.modules():
-            if isinstance(m, (nn.GroupNorm, nn.LayerNorm)):
+            if isinstance(m, (nn.GroupNorm, nn.LayerNorm)):   # GroupNormAct is an nn.GroupNorm
                 m.weight.fill_(1.0)
     return module

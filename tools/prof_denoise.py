@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance
 from gaussianip_amd.guidance.ahds import AHDSSchedule
 dev = torch.device("cuda")
-g = StableDiffusionGuidance(GuidanceConfig(channels_last=False), schedule=AHDSSchedule(list(range(2400))))
+g = StableDiffusionGuidance(GuidanceConfig(channels_last=(os.environ.get("CL","0")=="1")), schedule=AHDSSchedule(list(range(2400))))
 B = 4
 lat = torch.randn(B, 4, 64, 64, device=dev); ctrl = torch.rand(B, 3, 512, 512, device=dev)
 emb = torch.randn(3 * B, 81, 768, device=dev, dtype=torch.float16) * 0.1
