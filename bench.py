@@ -12,6 +12,10 @@ Gaussian state (weak scaling, view-sharded data parallelism) and the per-step ex
 timed region over RCCL: all_reduce(sum) of the parameter gradients (one flat 14*P-float bucket), all_reduce(sum) of the
 view-space gradient norms and all_reduce(max) of the radii.
 
+"ahds": the full AHDS stage-1 training step of BASELINE.json configs[2] (render 4 views -> VAE encode -> ControlNet +
+U-Net ANPG at batch 12 -> SDS -> backward -> Adam), measured by tools/bench_ahds.py after the raster timing; steps/s,
+views/s and the denoise MFMA fraction.  Random-initialised SD1.5-shaped networks (no checkpoints without a network).
+
 Extra objects: "roofline" (dominant kernel, live hipEvent durations on the launch stream) and "cpu_baseline" (the CPU
 oracle = "port" of the reference algorithm, timed on this box's host cores on a bounded sample: 1 view fwd+bwd).
 """
@@ -58,6 +62,8 @@ def main():
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=10)
+    ap.add_argument("--no-ahds", action="store_true", help="skip the full AHDS training-step measurement (configs[2])")
+    ap.add_argument("--ahds-steps", type=int, default=10)
     args = ap.parse_args()
 
     import numpy as np
@@ -129,6 +135,13 @@ def main():
     views_total = world * V * args.steps
     mpix_s = views_total * H * W / elapsed / 1e6
 
+    # ---- metric (i) of BASELINE.json: full AHDS training steps/s (configs[2]; at N>1 configs[3]'s view sharding) ----
+    ahds = None
+    if not args.no_ahds:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_ahds
+        ahds = bench_ahds.measure(steps=args.ahds_steps, warmup=4, gaussians=P, flops=(rank == 0), rank=rank, world=world,
+                                  device=dev)
     out = None
     if rank == 0:
         # ---- roofline: live per-kernel durations (hipEvents on the launch stream) ----
@@ -193,6 +206,8 @@ def main():
                           "parallelism": "view-sharded dp%d" % world},
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
                "roofline": roofline, "cpu_baseline": cpu}
+    if rank == 0:
+        out["ahds"] = ahds
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,214 @@
+// conv3x3.hip — 3x3 / stride 1 / pad 1 convolution, NHWC fp16 -> fp16 with fp32 accumulation, as an implicit GEMM on
+// the gfx950 matrix cores (v_mfma_f32_16x16x32_f16).  See include/gip_nn.h (gip_conv3x3_nhwc_f16).
+//
+// GEMM view: D[co][m] = sum_k W[co][k] * X[m][k],  m = (n, y, x) output pixel, k = (tap, ci), K = 9 * Cin.
+//   * workgroup tile 128 pixels x BN output channels (BN = 128, or 160 so that Cout = 320 splits without waste),
+//     4 waves as 2 (pixel halves) x 2 (channel halves), K step 64 = one tap x 64 input channels;
+//   * both operands are staged global -> LDS by 16-byte LDS-DMA (global_load_lds): a pixel row of the K step is the 128
+//     contiguous bytes x[n, y+dy-1, x+dx-1, c0:c0+64] of the NHWC tensor; taps that fall outside the image read a
+//     zero page instead (per-lane source select — the LDS side of the DMA is lane-linear, the global side is free);
+//   * the LDS image keeps 128-byte rows; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 ON THE SOURCE
+//     ADDRESS, which makes every 16-lane group of a ds_read_b128 fragment read cover all 64 banks once;
+//   * two LDS stages: the DMA of K step t+1 is in flight while the MFMAs of step t run; one barrier per step;
+//   * the MFMA's A operand is the weight tile (rows = output channels) and B the pixel tile, so a lane's four
+//     accumulator registers are four consecutive output channels of one pixel = one 8-byte NHWC store;
+//   * blockIdx -> tile is remapped so that the tiles sharing a pixel block (same activations, different channel
+//     blocks) are consecutive on ONE XCD and hit in its L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gip_nn.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CV_BM 128
+#define CV_BK 64
+#define CV_THREADS 256
+
+__device__ __attribute__((aligned(256))) unsigned int g_conv_zero_page[64];   // 256 bytes of zeros
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN>
+__global__ void __launch_bounds__(CV_THREADS, 2)
+conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
+               const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
+               int m_tiles, int n_tiles) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int A_BYTES = CV_BM * 128;          // pixel tile: 128 rows x 64 halves
+  constexpr int B_BYTES = BN * 128;             // weight tile: BN rows x 64 halves
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int B_ROUNDS = BN / 32;
+  constexpr int NI = BN / 32;                   // 16-channel MFMA tiles per wave (its half of BN)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // tile of this workgroup (bijective XCD remap: ids congruent mod 8 share an XCD)
+  const int total = m_tiles * n_tiles, id = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = id & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const long long M = (long long)N * H * W;
+  const long long m0 = (long long)mt * CV_BM;
+  const int co0 = nt * BN;
+  const int HW = H * W;
+
+  // ---- per-thread DMA descriptors (fixed over the K loop) ----
+  const int sub_row = wave * 8 + (lane >> 3);            // row inside a 32-row round
+  const int pchunk = lane & 7;                           // physical 16-byte chunk this lane fills
+  const char* zero = (const char*)g_conv_zero_page;
+  int a_off[4];                                          // byte offset of the centre pixel's channel 0 (+ swizzled chunk)
+  unsigned a_mask[4];                                    // 9 validity bits, one per tap
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = i * 32 + sub_row;
+    const long long m = m0 + row;
+    const int lchunk = pchunk ^ ((row >> 1) & 7);
+    unsigned mask = 0;
+    int off = 0;
+    if (m < M) {
+      const int n = (int)(m / HW), rem = (int)(m - (long long)n * HW);
+      const int y = rem / W, xx = rem - y * W;
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+          if ((unsigned)(y + dy - 1) < (unsigned)H && (unsigned)(xx + dx - 1) < (unsigned)W) mask |= 1u << (dy * 3 + dx);
+      off = (int)(m * Cin + lchunk * 8) * 2;
+    }
+    a_off[i] = off;
+    a_mask[i] = mask;
+  }
+  int b_off[B_ROUNDS];
+  bool b_ok[B_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; i++) {
+    const int row = i * 32 + sub_row;
+    const int lchunk = pchunk ^ ((row >> 1) & 7);
+    b_ok[i] = co0 + row < Cout;
+    b_off[i] = ((co0 + row) * 9 * Cin + lchunk * 8) * 2;
+  }
+
+  const int cblocks = Cin / CV_BK;
+  const int KT = 9 * cblocks;
+  const char* xb = (const char*)x;
+  const char* wb = (const char*)w;
+
+  auto stage = [&](int tap, int cb, int buf) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int tap_off = (((dy - 1) * W + (dx - 1)) * Cin + cb * CV_BK) * 2;
+    const int wtap_off = (tap * Cin + cb * CV_BK) * 2;
+    unsigned char* sa = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const char* src = ((a_mask[i] >> tap) & 1u) ? xb + a_off[i] + tap_off : zero + pchunk * 16;
+      dma16(src, sa + i * 4096);
+    }
+    unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; i++) {
+      const char* src = b_ok[i] ? wb + b_off[i] + wtap_off : zero + pchunk * 16;
+      dma16(src, sb + i * 4096);
+    }
+  };
+
+  f32x4 acc[NI][4];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: row = tile base + (lane & 15); swizzle term (row >> 1) & 7 == (lane >> 1) & 7 for every tile
+  const int frag_row = lane & 15, swz = (lane >> 1) & 7, kq = lane >> 4;
+  const int pix_base = (wm * 64 + frag_row) * 128;
+  const int ch_base = A_BYTES + (wn * (BN / 2) + frag_row) * 128;
+
+  int tap = 0, cb = 0;
+  stage(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt++) {
+    const int buf = kt & 1;
+    int ntap = tap, ncb = cb + 1;
+    if (ncb == cblocks) { ncb = 0; ntap = tap + 1; }
+    if (kt + 1 < KT) stage(ntap, ncb, buf ^ 1);
+    const unsigned char* sbuf = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int pc = ((ks * 4 + kq) ^ swz) * 16;
+      f16x8 pix[4], wt[NI];
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) pix[mi] = *(const f16x8*)(sbuf + pix_base + mi * 2048 + pc);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) wt[ni] = *(const f16x8*)(sbuf + ch_base + ni * 2048 + pc);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[ni], pix[mi], acc[ni][mi], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tap = ntap;
+    cb = ncb;
+  }
+
+  // ---- epilogue: lane holds out[pixel = lane & 15][co = (lane >> 4) * 4 + 0..3] of each 16x16 tile ----
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) {
+    const long long m = m0 + wm * 64 + mi * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      const int co = co0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+      if (co >= Cout) continue;
+      f32x4 v = acc[ni][mi];
+      if (bias) {
+        const f16x4 b = *(const f16x4*)(bias + co);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+      }
+      if (residual) {
+        const f16x4 rr = *(const f16x4*)(residual + m * Cout + co);
+        v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+      }
+      f16x4 o;
+      o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+      *(f16x4*)(out + m * Cout + co) = o;
+    }
+  }
+}
+
+template <int BN>
+static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
+                  int Cin, int Cout, hipStream_t s) {
+  const long long M = (long long)N * H * W;
+  const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + BN - 1) / BN;
+  const size_t lds = 2 * (size_t)(CV_BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return 3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<BN>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds, s, (const _Float16*)x,
+                     (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin,
+                     Cout, m_tiles, n_tiles);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                                    int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+  if (!x || !w || !out || N < 1 || H < 1 || W < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 4 || (Cout & 3)) return 1;
+  if ((long long)N * H * W * (long long)(Cin > Cout ? Cin : Cout) * 2 >= (1ll << 31)) return 1;   // 32-bit byte offsets
+  if ((long long)Cout * 9 * Cin * 2 >= (1ll << 31)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout % 160 == 0 && Cout % 128 != 0) return launch<160>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+  return launch<128>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+}

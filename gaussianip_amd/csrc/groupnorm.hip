@@ -45,7 +45,8 @@ template <int MODE>
 __global__ void __launch_bounds__(GN_BLOCK)
 gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const __half* __restrict__ gamma,
                  const __half* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
-                 float* __restrict__ partial /* [N, splits, G, 2] */, long long HW, int C, int G, int splits, int silu) {
+                 float* __restrict__ partial /* [N, splits, G, 2] */, long long HW, int C, int G, int splits, int silu,
+                 const __half* __restrict__ addend, int addend_stride) {
   extern __shared__ float s_ch[];   // [rows_per_iter][C][2]: one slot per (row-lane, channel) -> fixed-order sums
   const int n = blockIdx.y, split = blockIdx.x;
   const GnGeom gm = geom(C);
@@ -60,9 +61,12 @@ gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, cons
   for (int k = 0; k < gm.chunks_per_thread; k++) {
     const int chunk = cx + k * lanes_x;
     if (!active || chunk >= gm.tpr) continue;
-    float a0[8], a1[8], ga[8], be[8], mu[8], rs[8];
+    float a0[8], a1[8], ga[8], be[8], mu[8], rs[8], ad[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { a0[j] = 0.f; a1[j] = 0.f; }
+    for (int j = 0; j < 8; j++) {
+      a0[j] = 0.f; a1[j] = 0.f;
+      ad[j] = addend ? __half2float(addend[(long long)n * addend_stride + chunk * 8 + j]) : 0.f;
+    }
     if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -76,6 +80,8 @@ gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, cons
     for (long long r = r0 + ry; r < r1; r += gm.rows_per_iter) {
       float v[8];
       unpack8(xp[r * gm.tpr], v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] += ad[j];
       if (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < 8; j++) { a0[j] += v[j]; a1[j] += v[j] * v[j]; }
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(GN_BLOCK)
 gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const __half* __restrict__ gamma,
                 const __half* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
                 const float* __restrict__ partial, half8* __restrict__ out, long long HW, int C, int G, int splits,
-                int out_splits, float eps, int silu) {
+                int out_splits, float eps, int silu, const __half* __restrict__ addend, int addend_stride) {
   extern __shared__ float s_g[];   // [G][2]: forward mean, rstd ; backward S1/m, S2/m
   const int n = blockIdx.y, split = blockIdx.x;
   const GnGeom gm = geom(C);
@@ -145,14 +151,15 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
   for (int k = 0; k < gm.chunks_per_thread; k++) {
     const int chunk = cx + k * lanes_x;
     if (!active || chunk >= gm.tpr) continue;
-    float sc[8], sh[8], ga[8], be[8], mu[8], rs[8], m1[8], m2[8];
+    float sc[8], sh[8], ga[8], be[8], mu[8], rs[8], m1[8], m2[8], ad[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int c = chunk * 8 + j, g = c / cg;
       ga[j] = __half2float(gamma[c]); be[j] = __half2float(beta[c]);
+      ad[j] = addend ? __half2float(addend[(long long)n * addend_stride + c]) : 0.f;
       if (MODE == 0) {
         sc[j] = s_g[2 * g + 1] * ga[j];
-        sh[j] = be[j] - s_g[2 * g] * sc[j];
+        sh[j] = be[j] - (s_g[2 * g] - ad[j]) * sc[j];      // sc * (x + ad - mean) + beta
       } else {
         mu[j] = mean[n * G + g]; rs[j] = rstd[n * G + g];
         m1[j] = s_g[2 * g]; m2[j] = s_g[2 * g + 1];
@@ -173,7 +180,7 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
         unpack8(dy[base + r * gm.tpr], d);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const float xh = (v[j] - mu[j]) * rs[j];
+          const float xh = (v[j] + ad[j] - mu[j]) * rs[j];
           float g = d[j];
           if (silu) g *= dsilu_f(ga[j] * xh + be[j]);
           const float dxh = g * ga[j];
@@ -213,6 +220,7 @@ static int check(const void* a, const void* b, int32_t N, long long HW, int32_t 
 
 extern "C" int gip_gn_silu_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                    int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t apply_silu,
+                                   const void* addend, int32_t addend_stride,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check(x, y, N, HW, C, G, workspace_bytes);
   if (rc) return rc;
@@ -223,16 +231,19 @@ extern "C" int gip_gn_silu_forward(const void* x, const void* gamma, const void*
   float* partial = (float*)workspace;
   hipLaunchKernelGGL((gn_reduce_kernel<0>), dim3(rsplits, N), dim3(GN_BLOCK), reduce_lds_bytes(C), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta,
-                     (const float*)nullptr, (const float*)nullptr, partial, (long long)HW, C, G, rsplits, apply_silu);
+                     (const float*)nullptr, (const float*)nullptr, partial, (long long)HW, C, G, rsplits, apply_silu,
+                     (const __half*)addend, addend_stride);
   hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)G * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
-                     (const float*)partial, (half8*)y, (long long)HW, C, G, rsplits, splits, eps, apply_silu);
+                     (const float*)partial, (half8*)y, (long long)HW, C, G, rsplits, splits, eps, apply_silu,
+                     (const __half*)addend, addend_stride);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 extern "C" int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
                                     const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G,
-                                    int32_t apply_silu, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int32_t apply_silu, const void* addend, int32_t addend_stride,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check(x, dx, N, HW, C, G, workspace_bytes);
   if (rc) return rc;
   if (!dy || !gamma || !beta || !mean || !rstd || !workspace) return 1;
@@ -242,10 +253,67 @@ extern "C" int gip_gn_silu_backward(const void* x, const void* dy, const void* g
   float* partial = (float*)workspace;
   hipLaunchKernelGGL((gn_reduce_kernel<1>), dim3(rsplits, N), dim3(GN_BLOCK), reduce_lds_bytes(C), s,
                      (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta, mean, rstd, partial,
-                     (long long)HW, C, G, rsplits, apply_silu);
+                     (long long)HW, C, G, rsplits, apply_silu, (const __half*)addend, addend_stride);
   hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(splits, N), dim3(GN_BLOCK), (size_t)G * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta,
                      const_cast<float*>(mean), const_cast<float*>(rstd), (const float*)partial, (half8*)dx,
-                     (long long)HW, C, G, rsplits, splits, 0.f, apply_silu);
+                     (long long)HW, C, G, rsplits, splits, 0.f, apply_silu, (const __half*)addend, addend_stride);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pointwise companions (include/gip_nn.h): out = a + b + bias[c]   and   GEGLU out = value * gelu(gate).
+// 16-byte accesses, grid-stride; C % 8 == 0.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+add_bias_residual_kernel(const half8* __restrict__ a, const half8* __restrict__ b, const __half* __restrict__ bias,
+                         half8* __restrict__ out, long long n8, int tpr) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float x[8], y[8], o[8];
+    unpack8(a[i], x);
+    unpack8(b[i], y);
+    const int c = (int)(i % tpr) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = x[j] + y[j] + (bias ? __half2float(bias[c + j]) : 0.f);
+    out[i] = pack8(o);
+  }
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+
+__global__ void __launch_bounds__(256)
+geglu_kernel(const half8* __restrict__ in /* [M, 2D] */, half8* __restrict__ out /* [M, D] */, long long M, int d8) {
+  const long long total = M * d8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / d8;
+    const int k = (int)(i % d8);
+    float v[8], g[8], o[8];
+    unpack8(in[r * 2 * d8 + k], v);
+    unpack8(in[r * 2 * d8 + d8 + k], g);
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = v[j] * gelu_erf(g[j]);
+    out[i] = pack8(o);
+  }
+}
+
+static int grid_for(long long n) {
+  long long g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+extern "C" int gip_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t M, int32_t C,
+                                     void* stream) {
+  if (!a || !b || !out || M < 1 || C < 8 || (C & 7)) return 1;
+  const long long n8 = (long long)M * (C >> 3);
+  hipLaunchKernelGGL(add_bias_residual_kernel, dim3(grid_for(n8)), dim3(256), 0, (hipStream_t)stream, (const half8*)a,
+                     (const half8*)b, (const __half*)bias, (half8*)out, n8, C >> 3);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream) {
+  if (!in || !out || M < 1 || D < 8 || (D & 7)) return 1;
+  hipLaunchKernelGGL(geglu_kernel, dim3(grid_for((long long)M * (D >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const half8*)in, (half8*)out, (long long)M, D >> 3);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -1,8 +1,10 @@
-"""GroupNorm(+SiLU) as one fused HIP op for channels-last fp16 tensors (include/gip_nn.h, csrc/groupnorm.hip).
+"""Fused HIP ops for the channels-last fp16 denoiser / VAE (include/gip_nn.h, csrc/groupnorm.hip).
 
-`GroupNormAct` is a drop-in nn.GroupNorm that optionally applies SiLU.  On a GPU, for fp16 channels-last inputs, it
-runs the fused kernels through the C-ABI (forward: statistics pass + apply pass; backward: dL/dx only — the guidance
-networks are frozen).  Any other input (CPU tests, fp32) takes the plain PyTorch ops with identical semantics.
+`GroupNormAct` is a drop-in nn.GroupNorm that optionally applies SiLU and optionally adds a per-(sample, channel)
+vector to its input on load (conv bias + time-embedding projection of ResnetBlock2D).  On a GPU, for fp16
+channels-last inputs, it runs the fused kernels through the C-ABI (forward: statistics pass + apply pass; backward:
+dL/dx only — the guidance networks are frozen).  `add_bias_residual` (shortcut + conv2 + biases) and `geglu` are the
+pointwise companions.  Any other input (CPU tests, fp32) takes the plain PyTorch ops with identical semantics.
 """
 import ctypes
 
@@ -28,8 +30,11 @@ def _p(t):
 
 class _FusedGN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, act):
+    def forward(ctx, x, weight, bias, groups, eps, act, addend):
         N, C, H, W = x.shape
+        ad_ptr, ad_stride = ctypes.c_void_p(None), 0
+        if addend is not None:
+            ad_ptr, ad_stride = _p(addend), (addend.stride(0) if addend.dim() == 2 and addend.shape[0] > 1 else 0)
         lib = _lib.nn_lib()
         y = torch.empty_like(x, memory_format=torch.channels_last)
         mean = torch.empty((N, groups), dtype=torch.float32, device=x.device)
@@ -37,17 +42,18 @@ class _FusedGN(torch.autograd.Function):
         nb = lib.gip_gn_workspace_bytes(N, groups)
         ws = _workspace(x.device, nb)
         rc = lib.gip_gn_silu_forward(_p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), N, H * W, C, groups,
-                                     float(eps), int(act), _p(ws), ws.numel(),
+                                     float(eps), int(act), ad_ptr, ad_stride, _p(ws), ws.numel(),
                                      ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("gip_gn_silu_forward failed with status %d" % rc)
-        ctx.save_for_backward(x, weight, bias, mean, rstd)
-        ctx.groups, ctx.act = groups, act
+        ctx.save_for_backward(x, weight, bias, mean, rstd, addend)
+        ctx.groups, ctx.act, ctx.ad_stride = groups, act, ad_stride
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, bias, mean, rstd = ctx.saved_tensors
+        x, weight, bias, mean, rstd, addend = ctx.saved_tensors
+        ad_ptr = ctypes.c_void_p(None) if addend is None else _p(addend)
         N, C, H, W = x.shape
         lib = _lib.nn_lib()
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -55,11 +61,11 @@ class _FusedGN(torch.autograd.Function):
         nb = lib.gip_gn_workspace_bytes(N, ctx.groups)
         ws = _workspace(x.device, nb)
         rc = lib.gip_gn_silu_backward(_p(x), _p(dy), _p(weight), _p(bias), _p(mean), _p(rstd), _p(dx), N, H * W, C,
-                                      ctx.groups, int(ctx.act), _p(ws), ws.numel(),
+                                      ctx.groups, int(ctx.act), ad_ptr, ctx.ad_stride, _p(ws), ws.numel(),
                                       ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("gip_gn_silu_backward failed with status %d" % rc)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class GroupNormAct(nn.GroupNorm):
@@ -67,10 +73,134 @@ class GroupNormAct(nn.GroupNorm):
         super().__init__(num_groups, num_channels, eps=eps)
         self.act = act
 
-    def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.shape[1] % 8 == 0 and
-                x.is_contiguous(memory_format=torch.channels_last) and self.weight.dtype == torch.float16 and
-                not self.weight.requires_grad):
-            return _FusedGN.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.act)
+    def forward(self, x, addend=None):
+        """`addend` ([N, C], [1, C] or [C], unit stride on C) is added to x before the normalisation."""
+        if fusable(x) and self.weight.dtype == torch.float16 and not self.weight.requires_grad and \
+                (addend is None or (addend.dtype == torch.float16 and addend.stride(-1) == 1 and not addend.requires_grad)):
+            return _FusedGN.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.act, addend)
+        if addend is not None:
+            x = x + addend.reshape(-1 if addend.dim() == 2 and addend.shape[0] > 1 else 1, x.shape[1], 1, 1)
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         return F.silu(y) if self.act else y
+
+
+def fusable(x):
+    """fp16 NHWC activations on a GPU: the layout / dtype the HIP kernels are written for."""
+    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.shape[1] % 8 == 0 and
+            x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _AddBiasResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, bias):
+        N, C, H, W = a.shape
+        out = torch.empty_like(a, memory_format=torch.channels_last)
+        rc = _lib.nn_lib().gip_add_bias_residual(_p(a), _p(b), ctypes.c_void_p(None) if bias is None else _p(bias), _p(out),
+                                                 N * H * W, C, ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_add_bias_residual failed with status %d" % rc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy, None
+
+
+def add_bias_residual(a, b, bias=None):
+    """a + b + bias[None, :, None, None] in one pass (biases are frozen: no gradient for them)."""
+    if fusable(a) and fusable(b) and a.shape == b.shape and (bias is None or (bias.dtype == torch.float16 and not bias.requires_grad)):
+        return _AddBiasResidual.apply(a, b, bias)
+    out = a + b
+    return out if bias is None else out + bias.reshape(1, -1, 1, 1)
+
+
+def geglu(x):
+    """diffusers GEGLU on the projected tensor: value, gate = x.chunk(2, -1); value * gelu(gate)."""
+    D = x.shape[-1] // 2
+    if x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and D % 8 == 0 and not (x.requires_grad and torch.is_grad_enabled()):
+        out = torch.empty(x.shape[:-1] + (D,), dtype=x.dtype, device=x.device)
+        rc = _lib.nn_lib().gip_geglu(_p(x), _p(out), x.numel() // (2 * D), D,
+                                     ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_geglu failed with status %d" % rc)
+        return out
+    a, g = x.chunk(2, dim=-1)
+    return a * F.gelu(g)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3x3 / stride 1 / pad 1 convolution on the matrix cores (csrc/conv3x3.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+_MIN_CONV_TILES = 200        # below this many 128 x BN output tiles the chip is under-filled: MIOpen's split-K kernels win
+_wt_cache = {}
+
+
+def _conv_tiles(N, H, W, cout):
+    bn = 160 if (cout % 160 == 0 and cout % 128 != 0) else 128
+    return ((N * H * W + 127) // 128) * ((cout + bn - 1) // bn)
+
+
+def _conv_call(x, w, cout, bias=None, residual=None):
+    N, C, H, W = x.shape
+    out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    null = ctypes.c_void_p(None)
+    rc = _lib.nn_lib().gip_conv3x3_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias),
+                                            null if residual is None else _p(residual), _p(out), N, H, W, C, cout,
+                                            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("gip_conv3x3_nhwc_f16 failed with status %d" % rc)
+    return out
+
+
+def _transposed_weight(w):
+    """Weight of the data-gradient convolution: w_t[ci][2-dy][2-dx][co] = w[co][dy][dx][ci] (frozen weights: cached)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    wt = _wt_cache.get(key)
+    if wt is None:
+        wt = _wt_cache[key] = w.detach().flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    return wt
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, residual):
+        ctx.save_for_backward(w)
+        ctx.x_shape, ctx.has_res = tuple(x.shape), residual is not None
+        return _conv_call(x, w, w.shape[0], bias, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        N, _, H, W = ctx.x_shape
+        if w.shape[0] % 64 == 0 and _conv_tiles(N, H, W, w.shape[1]) >= _MIN_CONV_TILES:
+            dx = _conv_call(dy, _transposed_weight(w), w.shape[1])
+        else:
+            dx = torch.nn.grad.conv2d_input(ctx.x_shape, w, dy, padding=1)
+        return dx, None, None, (dy if ctx.has_res else None)
+
+
+def conv3x3(x, w, bias=None, residual=None):
+    """F.conv2d(x, w, bias, padding=1) (+ residual) for a 3x3 kernel.  fp16 NHWC activations with Cin % 64 == 0 and
+    enough output tiles to fill the chip run on the hand-written MFMA implicit GEMM with bias / residual in its
+    epilogue; everything else goes to MIOpen."""
+    if (fusable(x) and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0 and w.dtype == torch.float16 and
+            not w.requires_grad and w.is_contiguous(memory_format=torch.channels_last) and
+            (bias is None or not bias.requires_grad) and (residual is None or fusable(residual)) and
+            _conv_tiles(x.shape[0], x.shape[2], x.shape[3], w.shape[0]) >= _MIN_CONV_TILES and
+            x.numel() * 2 < (1 << 31) and x.shape[0] * x.shape[2] * x.shape[3] * w.shape[0] * 2 < (1 << 31)):
+        return _Conv3x3.apply(x, w, bias, residual)
+    out = F.conv2d(x, w, None, padding=1)
+    if residual is not None:
+        return add_bias_residual(residual, out, bias)
+    return out if bias is None else out + bias.reshape(1, -1, 1, 1)
+
+
+def conv1x1(x, w, bias=None):
+    """1x1 convolution.  For NHWC fp16 activations it IS a dense GEMM on the [N*H*W, Cin] view: one hipBLASLt call
+    with the bias in its epilogue (the library path for plain GEMMs) instead of MIOpen's conv + fill + bias kernels."""
+    if fusable(x) and w.is_contiguous(memory_format=torch.channels_last):
+        N, C, H, W = x.shape
+        y = F.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w.reshape(w.shape[0], C), bias)
+        return y.view(N, H, W, w.shape[0]).permute(0, 3, 1, 2)
+    return F.conv2d(x, w, bias)

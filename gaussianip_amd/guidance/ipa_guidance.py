@@ -76,6 +76,9 @@ class StableDiffusionGuidance:
             m.to(self.device, self.weights_dtype).eval().requires_grad_(False)
             if self.cfg.channels_last:
                 m.to(memory_format=torch.channels_last)
+        if self.device.type == "cuda" and self.weights_dtype == torch.float16:
+            self.unet.prepare_inference()          # one batched time-embedding projection per forward
+            self.controlnet.prepare_inference()
         self.num_train_timesteps = 1000
         self.alphas = sds.alphas_cumprod(device=self.device)
         self.schedule = schedule or AHDSSchedule()
@@ -135,7 +138,8 @@ class StableDiffusionGuidance:
         with torch.no_grad():
             noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
-            noise_pred = self.forward_unet(torch.cat([latents_noisy] * 3, dim=0), torch.cat([control_img] * 3, dim=0),
+            # the three branches share their pose maps: the ControlNet hint stem runs on the B distinct maps and tiles
+            noise_pred = self.forward_unet(torch.cat([latents_noisy] * 3, dim=0), control_img,
                                            torch.cat([t] * 3), embeds, use_pose_controlnet)
             direction = sds.anpg_direction(noise_pred, t, self.cfg.guidance_scale)
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
@@ -149,7 +153,7 @@ class StableDiffusionGuidance:
         with torch.no_grad():
             noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
-            noise_pred = self.forward_unet(torch.cat([latents_noisy] * 2, dim=0), torch.cat([control_img] * 2, dim=0),
+            noise_pred = self.forward_unet(torch.cat([latents_noisy] * 2, dim=0), control_img,
                                            torch.cat([t] * 2), embeds, use_pose_controlnet)
             direction = sds.cfg_direction(noise_pred, noise, self.cfg.guidance_scale, self.cfg.guidance_rescale)
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction

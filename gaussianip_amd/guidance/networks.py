@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import GroupNormAct
+from .fused import GroupNormAct, add_bias_residual, conv1x1, conv3x3, fusable, geglu
 
 TEXT_TOKENS = 77
 IP_TOKENS = 4
@@ -50,11 +50,31 @@ class ResBlock(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb=None):
+        if fusable(x) and not self.conv1.weight.requires_grad:
+            return self._forward_fused(x, temb)
         h = self.conv1(self.norm1(x))
         if self.time_emb_proj is not None:
             h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
         h = self.conv2(self.norm2(h))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+    def _forward_fused(self, x, temb):
+        """Same block with the pointwise work folded into the HIP kernels: conv1's bias and the time-embedding
+        projection enter norm2 as its per-(sample, channel) addend; conv2's bias, the shortcut's bias and the residual
+        add are one pass.  `self.staged_addend` (set by _Encoder.stage_time_embedding) already holds
+        conv1.bias + time_emb_proj(silu(temb)) for this block when the batched projection is in use."""
+        addend, self.staged_addend = self.staged_addend, None
+        if addend is None:
+            addend = self.conv1.bias
+            if self.time_emb_proj is not None:
+                addend = F.linear(F.silu(temb), self.time_emb_proj.weight, self.time_emb_proj.bias + addend)
+        h = conv3x3(self.norm1(x), self.conv1.weight)
+        if self.conv_shortcut is None:
+            return conv3x3(self.norm2(h, addend), self.conv2.weight, self.conv2.bias, x)
+        return conv3x3(self.norm2(h, addend), self.conv2.weight, self.conv2.bias,
+                       conv1x1(x, self.conv_shortcut.weight, self.conv_shortcut.bias))
+
+    staged_addend = None
 
 
 class Attention(nn.Module):
@@ -126,8 +146,7 @@ class TransformerBlock(nn.Module):
     def forward(self, x, ctx):
         x = x + self.attn1(self.norm1(x))
         x = x + self.attn2(self.norm2(x), ctx)
-        a, g = self.ff_in(self.norm3(x)).chunk(2, dim=-1)
-        return x + self.ff_out(a * F.gelu(g))
+        return x + self.ff_out(geglu(self.ff_in(self.norm3(x))))
 
 
 class SpatialTransformer(nn.Module):
@@ -140,6 +159,10 @@ class SpatialTransformer(nn.Module):
 
     def forward(self, x, ctx):
         B, C, H, W = x.shape
+        if fusable(x):      # NHWC: the 1x1 projections are GEMMs on the token view, no layout change anywhere
+            t = F.linear(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
+            t = F.linear(self.block(t, ctx), self.proj_out.weight.reshape(C, C), self.proj_out.bias)
+            return x + t.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.block(h, ctx).reshape(B, H, W, C).permute(0, 3, 1, 2)
         return x + self.proj_out(h)
@@ -163,7 +186,7 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return conv3x3(F.interpolate(x, scale_factor=2.0, mode="nearest"), self.conv.weight, self.conv.bias)
 
 
 class _Encoder(nn.Module):
@@ -186,7 +209,33 @@ class _Encoder(nn.Module):
 
     def temb(self, t, dtype):
         e = timestep_embedding(t).to(dtype)
-        return self.time_l2(F.silu(self.time_l1(e)))
+        temb = self.time_l2(F.silu(self.time_l1(e)))
+        self.stage_time_embedding(temb)
+        return temb
+
+    _temb_pack = None
+
+    @torch.no_grad()
+    def prepare_inference(self):
+        """Call once the (frozen) weights are final: packs every ResnetBlock2D's time_emb_proj into ONE [sum(C), 1280]
+        projection whose bias also carries conv1's bias, so a forward runs a single GEMM for all the blocks' addends."""
+        blocks = [m for m in self.modules() if isinstance(m, ResBlock) and m.time_emb_proj is not None]
+        W = torch.cat([b.time_emb_proj.weight for b in blocks]).contiguous()
+        bias = torch.cat([b.time_emb_proj.bias + b.conv1.bias for b in blocks]).contiguous()
+        offs, o = [], 0
+        for b in blocks:
+            offs.append((o, o + b.conv1.out_channels))
+            o += b.conv1.out_channels
+        self._temb_pack = (blocks, W, bias, offs)
+        return self
+
+    def stage_time_embedding(self, temb):
+        if self._temb_pack is None or not (temb.is_cuda and temb.dtype == torch.float16):
+            return
+        blocks, W, bias, offs = self._temb_pack
+        allp = F.linear(F.silu(temb), W, bias)          # [N, sum(C)]; each block reads its column range in place
+        for b, (lo, hi) in zip(blocks, offs):
+            b.staged_addend = allp[:, lo:hi]
 
     def encode(self, h, temb, ctx):
         skips = [h]
@@ -265,15 +314,23 @@ class ControlNet(_Encoder):
         self.mid_zero = nn.Conv2d(1280, 1280, 1)
 
     def forward(self, x, t, ctx, cond, conditioning_scale=1.0) -> Tuple[List[torch.Tensor], torch.Tensor]:
+        """`cond` may hold fewer samples than x (B / k): the hint stem then runs once per distinct hint and its output
+        is tiled k times — the three guidance branches of compute_grad_anpg share their pose maps (ipa_guidance.py:397-399)."""
         temb = self.temb(t, x.dtype)
         c = cond
         for i, conv in enumerate(self.cond_stem):
             c = conv(c)
             if i < len(self.cond_stem) - 1:
                 c = F.silu(c)
+        if c.shape[0] != x.shape[0]:
+            c = c.repeat(x.shape[0] // c.shape[0], 1, 1, 1)
         h, skips = self.encode(self.conv_in(x) + c, temb, ctx)
         h = self.mid(h, temb, ctx)
-        return [z(s) * conditioning_scale for z, s in zip(self.zero_convs, skips)], self.mid_zero(h) * conditioning_scale
+        down = [conv1x1(s, z.weight, z.bias) for z, s in zip(self.zero_convs, skips)]
+        mid = conv1x1(h, self.mid_zero.weight, self.mid_zero.bias)
+        if conditioning_scale != 1.0:
+            down, mid = [d * conditioning_scale for d in down], mid * conditioning_scale
+        return down, mid
 
 
 class VAEEncoder(nn.Module):

@@ -10,6 +10,13 @@
  *   gip_gn_silu_forward   y = silu?( (x - mean_g) * rstd_g * gamma_c + beta_c )
  *   gip_gn_silu_backward  dL/dx of the same (weights are frozen in this path: no dgamma / dbeta)
  *
+ * Both take an optional per-(sample, channel) `addend` (half, row stride `addend_stride` elements; stride 0 = one row
+ * shared by all samples; NULL = none) that is added to x on load: ResnetBlock2D's `conv1(x) + bias + time_emb_proj(...)`
+ * feeds norm2, so the bias / time-embedding adds never run as separate passes over the activation.
+ *
+ *   gip_add_bias_residual  out = a + b + bias[c]            (ResnetBlock2D output: shortcut + conv2 + biases; out may alias a)
+ *   gip_geglu              out[m, :D] = in[m, :D] * gelu(in[m, D:2D])   (diffusers GEGLU, exact erf GELU)
+ *
  * Plain C, raw device pointers, caller-owned buffers (workspace sized by gip_gn_workspace_bytes), work enqueued on
  * `stream` (hipStream_t as void*), integer status (0 ok, 1 bad argument, 2 workspace too small, 3 HIP error).
  * Layout: x, y, dy, dx are [N, HW, C] half-precision with C fastest (torch channels_last memory of an NCHW tensor);
@@ -25,10 +32,22 @@ extern "C" {
 size_t gip_gn_workspace_bytes(int32_t N, int32_t G);
 int gip_gn_silu_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                         int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t apply_silu,
+                        const void* addend, int32_t addend_stride,
                         void* workspace, size_t workspace_bytes, void* stream);
 int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
                          const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu,
+                         const void* addend, int32_t addend_stride,
                          void* workspace, size_t workspace_bytes, void* stream);
+int gip_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t M, int32_t C, void* stream);
+int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution as an MFMA implicit GEMM (csrc/conv3x3.hip): x [N,H,W,Cin] half (NHWC),
+ * w [Cout,3,3,Cin] half (the channels_last memory of a torch [Cout,Cin,3,3] weight), out [N,H,W,Cout] half, fp32
+ * accumulation.  Epilogue (fp32, before the single rounding to half): + bias[Cout] (NULL = none) + residual
+ * [N,H,W,Cout] (NULL = none; ResnetBlock2D's shortcut).  Cin % 64 == 0, Cout % 4 == 0.
+ * Replaces the MIOpen call behind diffusers' ResnetBlock2D / Upsample2D convolutions in the denoiser and the VAE. */
+int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
+                         int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,55 @@
+"""gip_conv3x3_nhwc_f16 (MFMA implicit GEMM, csrc/conv3x3.hip) against torch's fp32 convolution of the same fp16
+operands: forward with bias / residual epilogue, data gradient (same kernel on the flipped-transposed weight), image
+borders, ragged M (N*H*W not a multiple of the 128-pixel tile), both channel-tile widths (128, 160).
+Tolerance: one rounding of the fp32 accumulator to half => |err| <= 2^-11 * |out| + accumulation-order noise."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # N, Cin, Cout, H, W
+    (2, 64, 64, 9, 7), (1, 64, 128, 1, 1), (3, 128, 320, 17, 5), (12, 320, 320, 64, 64), (12, 640, 320, 64, 64),
+    (12, 1280, 640, 32, 32), (4, 128, 128, 96, 80), (4, 512, 512, 64, 64), (2, 192, 72, 33, 31), (12, 1280, 1280, 16, 16)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv3x3_forward_backward(shape, monkeypatch):
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setattr(fused, "_MIN_CONV_TILES", 0)          # always take the HIP kernel, also for tiny shapes
+    N, ci, co, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(ci * 7 + co + H)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, ci, H, W, device="cuda", generator=g).half().contiguous(**cl).requires_grad_(True)
+    w = (torch.randn(co, ci, 3, 3, device="cuda", generator=g) / (3 * ci ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(co, device="cuda", generator=g).half()
+    r = torch.randn(N, co, H, W, device="cuda", generator=g).half().contiguous(**cl).requires_grad_(True)
+    calls = []
+    orig = fused._conv_call
+    monkeypatch.setattr(fused, "_conv_call", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    out = fused.conv3x3(x, w, b, r)
+    assert calls, "the HIP convolution did not run"
+    ref = F.conv2d(x.detach().float(), w.float(), b.float(), padding=1) + r.detach().float()
+    scale = float(ref.abs().max())
+    assert float((out.float() - ref).abs().max()) <= 1.5e-3 * scale
+    plain = fused.conv3x3(x, w)
+    ref_p = F.conv2d(x.detach().float(), w.float(), None, padding=1)
+    assert float((plain.float() - ref_p).abs().max()) <= 1.5e-3 * float(ref_p.abs().max())
+    if co % 64 == 0:
+        dy = torch.randn(N, co, H, W, device="cuda", generator=g).half().contiguous(**cl)
+        n0 = len(calls)
+        dx, dr = torch.autograd.grad(out, [x, r], dy)
+        assert len(calls) > n0 and torch.equal(dr, dy)
+        dx_ref = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), padding=1)
+        assert float((dx.float() - dx_ref).abs().max()) <= 1.5e-3 * float(dx_ref.abs().max())
+    # bitwise reproducible
+    assert torch.equal(fused.conv3x3(x, w, b, r), out)
+
+
+def test_small_problems_stay_on_miopen():
+    from gaussianip_amd.guidance import fused
+    x = torch.randn(12, 1280, 8, 8, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(1280, 1280, 3, 3, device="cuda").half().contiguous(memory_format=torch.channels_last) * 0.01
+    assert fused._conv_tiles(12, 8, 8, 1280) < fused._MIN_CONV_TILES
+    out = fused.conv3x3(x, w)
+    assert torch.allclose(out.float(), F.conv2d(x, w, padding=1).float(), atol=2e-2)

@@ -56,3 +56,57 @@ def test_fused_path_refuses_silently_falling_back_on_gpu():
     finally:
         fused._FusedGN.apply = orig
     assert calls
+
+
+def test_groupnorm_addend_and_pointwise_companions():
+    """addend path (conv bias + time embedding folded into the norm), add_bias_residual and geglu vs plain torch."""
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N, C, H, W = 6, 640, 32, 32
+    x = (torch.randn(N, C, H, W, device="cuda", generator=g)).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    big = torch.randn(N, 3 * C, device="cuda", generator=g).half()
+    for addend in (big[:, C:2 * C], torch.randn(C, device="cuda", generator=g).half()):   # strided [N, C] view, shared [C]
+        m = fused.GroupNormAct(32, C, act=True).cuda().half().requires_grad_(False)
+        y = m(x, addend)
+        dy = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+        (dx,) = torch.autograd.grad(y, x, dy)
+        xr = x.detach().float().contiguous().requires_grad_(True)
+        ad = addend.float().reshape(-1 if addend.dim() == 2 else 1, C, 1, 1)
+        yr = F.silu(F.group_norm(xr + ad, 32, m.weight.float(), m.bias.float(), 1e-5))
+        (dxr,) = torch.autograd.grad(yr, xr, dy.float().contiguous())
+        assert float((y.float() - yr).abs().max()) < 4e-3 * max(1.0, float(yr.abs().max()))
+        assert float((dx.float() - dxr).abs().max()) < 4e-3 * max(1.0, float(dxr.abs().max()))
+    a = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bias = torch.randn(C, device="cuda", generator=g).half()
+    out = fused.add_bias_residual(a, b, bias)
+    ref = (a.float() + b.float() + bias.float().reshape(1, C, 1, 1))
+    assert float((out.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    ga, gb = torch.autograd.grad(out, [a, b], torch.ones_like(out))
+    assert torch.equal(ga, torch.ones_like(a)) and torch.equal(gb, ga)
+    with torch.no_grad():
+        z = torch.randn(12, 1024, 2 * 1280, device="cuda", generator=g).half()
+        o = fused.geglu(z)
+        v, gate = z.float().chunk(2, dim=-1)
+        r = v * F.gelu(gate)
+        assert o.shape == (12, 1024, 1280) and float((o.float() - r).abs().max()) <= 2e-3 * float(r.abs().max())
+
+
+def test_resblock_fused_equals_unfused():
+    """The fused ResnetBlock2D path (addend + one-pass residual) against the module's own plain-torch path in fp32."""
+    from gaussianip_amd.guidance import networks as nw
+    torch.manual_seed(0)
+    for cin, cout in ((320, 320), (640, 320)):
+        blk = nw.init_for_benchmark(nw.ResBlock(cin, cout)).cuda()
+        with torch.no_grad():
+            for p in blk.parameters():
+                if p.ndim == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+        ref = blk.float()
+        x = torch.randn(3, cin, 32, 32, device="cuda")
+        temb = torch.randn(3, 1280, device="cuda")
+        want = ref(x, temb)
+        import copy
+        h = copy.deepcopy(ref).half().requires_grad_(False).to(memory_format=torch.channels_last)
+        got = h(x.half().contiguous(memory_format=torch.channels_last), temb.half())
+        assert float((got.float() - want).abs().max()) < 2e-2 * float(want.abs().max())

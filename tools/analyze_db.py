@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-step kernel-family breakdown from a rocprofv3 rocpd database (runs on the GPU box; prints text only).
+usage: analyze_db.py results.db [marker_kernel_substring] [top_n]  — steps are delimited by the marker's launches."""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+marker = sys.argv[2] if len(sys.argv) > 2 else "gip_preprocess_kernel"
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+marks = [r[0] for r in db.execute("select start from kernels where name like ? order by start", ("%" + marker + "%",))]
+lo, hi, nstep = marks[-5], marks[-1], 4
+rows = db.execute("select name, count(*), sum(end-start) from kernels where start>=? and start<? group by name", (lo, hi)).fetchall()
+FAM = [("raster(gip)", r"gip_"), ("gn_fused", r"gn_reduce|gn_apply"), ("conv_bwd", r"igemm_bwd|igemm_wrw|bwd_data|wrw"),
+       ("conv_fwd", r"igemm_fwd|Conv|conv"), ("miopen_aux", r"SubTensorOp|batched_transpose|transpose"),
+       ("gemm", r"Cijk|gemm|GEMM"), ("attention", r"attn|fmha|flash|Fmha"), ("layernorm", r"layer_norm|LayerNorm"),
+       ("groupnorm_torch", r"RowwiseMoments|GroupNorm|group_norm"), ("softmax", r"softmax"), ("adam", r"adam|Adam|multi_tensor"),
+       ("elementwise", r"elementwise|vectorized|CatArray|index|copy|fill|upsample|reduce")]
+tot = sum(r[2] for r in rows)
+agg = {}
+for n, c, ns in rows:
+    fam = next((f for f, pat in FAM if re.search(pat, n)), "other")
+    a = agg.setdefault(fam, [0, 0])
+    a[0] += ns
+    a[1] += c
+print("wall per step %.2f ms, GPU busy per step %.2f ms, %d kernels per step" % ((hi - lo) / nstep / 1e6, tot / nstep / 1e6, sum(r[1] for r in rows) // nstep))
+for f, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print("%-18s %9.3f ms %6.1f%% %7d" % (f, ns / nstep / 1e6, 100 * ns / tot, c // nstep))
+for n, c, ns in sorted(rows, key=lambda r: -r[2])[:top]:
+    print("%8.3f ms %5d  %s" % (ns / nstep / 1e6, c // nstep, n[:130]))

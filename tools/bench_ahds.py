@@ -18,14 +18,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gaussians", type=int, default=100000)
-    ap.add_argument("--no-channels-last", action="store_true")
-    ap.add_argument("--flops", action="store_true")
-    args = ap.parse_args()
+def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None):
+    """Runs the step `warmup + steps` times and returns the result dict.  With world > 1 (process group initialised by
+    the caller) every rank trains on its own 4 cameras of the replicated Gaussians and the per-step exchange of
+    parallel.exchange_step (gradients, densification statistics, depth maximum) runs inside the timed step."""
     import numpy as np
     import torch
     import scenes
@@ -36,10 +32,12 @@ def main():
     from gaussianip_amd.scene import Camera, GaussianModel
     from gaussianip_amd.utils import BasicPointCloud
 
-    dev = torch.device("cuda")
+    from gaussianip_amd import parallel
+    dev = torch.device("cuda") if device is None else device
     torch.manual_seed(42)
     rng = np.random.default_rng(42)
-    P, H, W, B = args.gaussians, 1024, 1024, 4
+    cam_rng = np.random.default_rng(42 + rank)     # replicated Gaussians, rank-specific cameras
+    P, H, W, B = gaussians, 1024, 1024, 4
     gm = GaussianModel(0)
     pts = scenes.human_points(P, rng).astype(np.float32)
     gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
@@ -47,7 +45,7 @@ def main():
     pipe = PipelineParams(ArgumentParser())
     bg = torch.zeros(3, device=dev)
     t0 = time.time()
-    guidance = StableDiffusionGuidance(GuidanceConfig(channels_last=not args.no_channels_last))
+    guidance = StableDiffusionGuidance(GuidanceConfig(channels_last=channels_last))
     g = torch.Generator(device=dev).manual_seed(1)
     tabs = [torch.randn(13, 77, 768, device=dev, generator=g) * 0.1 for _ in range(3)]
     prompts = PromptEmbeddings(*tabs, direction_fn=lambda el, az, c, v, d: ((az % 360) / 90).long())
@@ -58,6 +56,7 @@ def main():
 
     def step(i):
         gm.update_learning_rate(i)
+        rng = cam_rng
         el = torch.tensor(rng.uniform(-30, 30, B), dtype=torch.float32, device=dev)
         az0 = rng.uniform(-180, 180)
         az = torch.tensor([az0 + 90.0 * k for k in range(B)], dtype=torch.float32, device=dev)
@@ -67,25 +66,38 @@ def main():
         rgb = pkg["render"].permute(0, 2, 3, 1)
         depth = pkg["depth_3dgs"].permute(0, 2, 3, 1)
         out = guidance(i, rgb, pose, prompts, True, torch.ones(B, device=dev), el, az, None, None)
-        opacity = depth / (depth.max() + 1e-5)
+        dmax = depth.detach().max()
+        if world > 1:
+            torch.distributed.all_reduce(dmax, op=torch.distributed.ReduceOp.MAX)   # GaussianIP.py:225: batch-global max
+        opacity = depth / (dmax + 1e-5)
         loss = out["loss_sds"] + torch.sqrt(opacity ** 2 + 0.01).mean()
         gm.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        vs = pkg["viewspace_points"].grad
+        vs = pkg["viewspace_points"].grad.sum(0)
         radii = pkg["radii"].max(dim=0).values
+        if world > 1:
+            parallel.exchange_step([g_["params"][0] for g_ in gm.optimizer.param_groups], vs, radii, None, average=True)
         gm.max_radii2D = torch.max(gm.max_radii2D, radii.float())
-        gm.add_densification_stats(vs.sum(0), radii > 0)
+        gm.add_densification_stats(vs, radii > 0)
         gm.optimizer.step()
         return loss
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
+    if world > 1:
+        torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
+    if world > 1:
+        torch.distributed.barrier()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
+    if world > 1:
+        et = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
+        dt = float(et.item())
 
     # time the pieces (events on the current stream)
     def timed(fn, n=5):
@@ -110,18 +122,31 @@ def main():
         z = guidance.encode_images(img)
         z.sum().backward()
     vae_ms = timed(vae_fb)
-    flops = None
-    if args.flops:
+    nflops = None
+    if flops:
         from torch.utils.flop_counter import FlopCounterMode
         with FlopCounterMode(display=False) as fc:
             guidance.forward_unet(torch.cat([lat] * 3), torch.cat([ctrl] * 3), torch.cat([tt] * 3), emb, True)
-        flops = fc.get_total_flops()
-    out = {"metric": "ahds_train_steps_per_s", "value": round(1.0 / dt, 3), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2),
-           "n_gpus": 1, "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
+        nflops = fc.get_total_flops()
+    flops = nflops
+    out = {"metric": "ahds_train_steps_per_s", "value": round(world / dt, 3), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2),
+           "views_per_s": round(world * B / dt, 2), "n_gpus": world, "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
            "denoise_ms": round(den_ms, 2), "vae_enc_fwd_bwd_ms": round(vae_ms, 2), "setup_s": round(setup_s, 1),
            "denoise_flops": flops, "denoise_tflops_per_s": None if not flops else round(flops / (den_ms * 1e-3) / 1e12, 1),
+           "denoise_mfma_frac": None if not flops else round(flops / (den_ms * 1e-3) / 2.5e15, 4),   # fp16 dense peak ~2.5 PFLOP/s
            "data": "synthetic", "dtype": "f16 (networks) / f32 (raster)"}
-    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=100000)
+    ap.add_argument("--no-channels-last", action="store_true")
+    ap.add_argument("--flops", action="store_true")
+    args = ap.parse_args()
+    print(json.dumps(measure(args.steps, args.warmup, args.gaussians, not args.no_channels_last, args.flops)), flush=True)
 
 
 if __name__ == "__main__":
