@@ -1,0 +1,238 @@
+// attention.hip — softmax(Q K^T * scale) V forward for the denoiser's self-attention (no mask, no dropout, no
+// gradient: the U-Net / ControlNet are frozen and run under no_grad), fp16 in / fp16 out, fp32 softmax and accumulation,
+// on the gfx950 matrix cores.  See include/gip_nn.h (gip_attention_fwd_f16).
+//
+// Layout: q, k, v, o are the [B, N, H*D] tensors the to_q / to_k / to_v projections produce and to_out consumes — the
+// head split / merge transposes of the reference (attention_processor_faceid.py:300-318) never materialise.
+//
+// One workgroup = 128 query rows of one (batch, head); 4 waves x 32 rows; keys / values stream through LDS in blocks of
+// 64 rows (two stages; the next block's global loads are in flight during the current block's math).  Per block and wave:
+//   S^T = K Q^T      v_mfma_f32_32x32x16_f16, A = K rows (ds_read_b128 from a chunk-swizzled row image), B = Q^T kept
+//                    in registers for the whole kernel.  The result has the QUERY on the lane and the 32 keys of the
+//                    tile in the 16 registers of the two lane halves, so the online softmax (max, exp2, sum, rescale)
+//                    is lane-local except for one exchange with lane ^ 32 per block.
+//   O^T += V^T P^T   P^T is consumed straight from the S^T accumulators as the B operand (register pairs -> half); the
+//                    matching k-permuted A operand V^T comes from the row-major V image by ds_read_b64_tr_b16, the
+//                    hardware transposing LDS read.  O^T again has the query on the lane: rescaling is lane-local.
+// The running maximum is only raised when a block exceeds it by more than 2^8 (in the exp2 domain), which removes
+// almost all accumulator rescales; probabilities stay <= 256, well inside half range.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gip_nn.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+#define AT_BQ 128
+#define AT_BKV 64
+#define AT_ROW 128                       // bytes per LDS row (64 halves: D <= 64)
+#define AT_TILE (AT_BKV * AT_ROW)        // one K or V stage: 8 KB
+#define AT_DEFER 8.0f
+
+union Frag8 {
+  f16x8 v;
+  s16x4 h[2];
+  uint4 u;
+};
+
+template <int D>
+__global__ void __launch_bounds__(256, 2)
+attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
+                _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */) {
+  static_assert(D % 8 == 0 && D <= 64, "head dim");
+  constexpr int NS = (D + 15) / 16;      // k-steps of the S^T product
+  constexpr int ND = (D + 31) / 32;      // 32-row tiles of O^T
+  constexpr int CH = D / 8;              // 16-byte chunks per row
+  constexpr int PER = (AT_BKV * CH + 255) / 256;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 2 * AT_TILE];   // [stage][K | V]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y / H, h = blockIdx.y - b * H;
+  const int C = H * D;
+  const int q0 = blockIdx.x * AT_BQ + wave * 32;
+
+  // Q^T fragments (B operand): lane = query column, element j = feature 16 s + 8 hh + j; zero beyond D
+  f16x8 qf[NS];
+  {
+    const _Float16* qp = q + ((size_t)b * Nq + q0 + r) * C + h * D;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int d0 = 16 * s + 8 * hh;
+      Frag8 f;
+      f.u = make_uint4(0, 0, 0, 0);
+      if (d0 < D) f.u = *(const uint4*)(qp + d0);
+      qf[s] = f.v;
+    }
+  }
+  // the padding columns of the images must be finite zeros (0 * garbage would poison S^T): clear everything once
+  for (int i = tid * 16; i < 2 * 2 * AT_TILE; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
+
+  // staging descriptors: every thread moves two chunks of K and of V per block; the tail indices wrap around (a few
+  // chunks are moved twice with identical data) so that no load or LDS store is predicated
+  static_assert(PER == 2, "two staging chunks per thread");
+  int idx0 = tid, idx1 = tid + 256;
+  if (idx1 >= AT_BKV * CH) idx1 -= AT_BKV * CH;
+  const int row0 = idx0 / CH, ch0 = idx0 - row0 * CH, row1 = idx1 / CH, ch1 = idx1 - row1 * CH;
+  const int g0 = row0 * C + ch0 * 8, g1 = row1 * C + ch1 * 8;
+  const int kl0 = row0 * AT_ROW + ((ch0 ^ ((row0 >> 1) & 7)) << 4), kl1 = row1 * AT_ROW + ((ch1 ^ ((row1 >> 1) & 7)) << 4);
+  const int vl0 = AT_TILE + row0 * AT_ROW + ((ch0 ^ (((row0 >> 1) & 1) << 2)) << 4);
+  const int vl1 = AT_TILE + row1 * AT_ROW + ((ch1 ^ (((row1 >> 1) & 1) << 2)) << 4);
+  const _Float16* kp = k + (size_t)b * Nkv * C + h * D;
+  const _Float16* vp = v + (size_t)b * Nkv * C + h * D;
+  uint4 kr0, kr1, vr0, vr1;
+#define AT_FETCH(blk_)                                                     \
+  {                                                                        \
+    const size_t base_ = (size_t)(blk_) * AT_BKV * C;                      \
+    kr0 = *(const uint4*)(kp + base_ + g0);                                \
+    kr1 = *(const uint4*)(kp + base_ + g1);                                \
+    vr0 = *(const uint4*)(vp + base_ + g0);                                \
+    vr1 = *(const uint4*)(vp + base_ + g1);                                \
+  }
+#define AT_DEPOSIT(stage_)                                                 \
+  {                                                                        \
+    unsigned char* st_ = smem + (stage_) * 2 * AT_TILE;                    \
+    *(uint4*)(st_ + kl0) = kr0;                                            \
+    *(uint4*)(st_ + kl1) = kr1;                                            \
+    *(uint4*)(st_ + vl0) = vr0;                                            \
+    *(uint4*)(st_ + vl1) = vr1;                                            \
+  }
+
+  f32x16 O[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) O[dt][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // fragment addressing
+  const int k_row_off = r * AT_ROW, k_swz = (r >> 1) & 7;
+  const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, half16 = (lane >> 4) & 1;
+
+  AT_FETCH(0);
+  __syncthreads();        // clears done
+  AT_DEPOSIT(0);
+  __syncthreads();
+  const int NB = Nkv / AT_BKV;
+  for (int blk = 0; blk < NB; blk++) {
+    const int stage = blk & 1;
+    const unsigned char* sk = smem + stage * 2 * AT_TILE;
+    const int nblk = blk + 1 < NB ? blk + 1 : blk;      // the last iteration re-fetches its own block (never deposited)
+    AT_FETCH(nblk);
+
+    // ---- S^T = K Q^T for the two 32-key tiles ----
+    f32x16 S[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) S[t][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
+        S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+      }
+    }
+
+    // ---- V^T fragments: issued now, they land while the softmax runs ----
+    const unsigned char* sv = sk + AT_TILE;
+    Frag8 vt[ND][2][2];
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++) {
+      const int col = dt * 32 + 16 * half16 + 4 * p4;          // first feature this lane addresses
+      const int lch = col >> 3, sub = (p4 & 1) * 8;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          const int row = t * 32 + 16 * s2 + 4 * hh + q4;
+          const int off = row * AT_ROW + ((lch ^ (((row >> 1) & 1) << 2)) << 4) + sub;
+          vt[dt][t][s2].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off));
+          vt[dt][t][s2].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off + 8 * AT_ROW));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- online softmax on the lane's query column ----
+    float mloc = S[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, S[t][i]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const bool raise = (mloc - m_run) * c > AT_DEFER;     // true on the first block (m_run = -inf)
+    if (__any(raise)) {
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) O[dt][i] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
+    Frag8 P[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
+          l_run += p;
+          P[t][s2].v[j] = (_Float16)p;
+        }
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+          O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
+
+    if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O^T[d = 32 dt + 8 i + 4 hh + 0..3][query r] in registers 4i..4i+3 ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  _Float16* op = o + ((size_t)b * Nq + q0 + r) * C + h * D;
+#pragma unroll
+  for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int d = dt * 32 + 8 * i + 4 * hh;
+      if (d < D) {
+        f16x4 w;
+        w[0] = (_Float16)(O[dt][4 * i] * inv); w[1] = (_Float16)(O[dt][4 * i + 1] * inv);
+        w[2] = (_Float16)(O[dt][4 * i + 2] * inv); w[3] = (_Float16)(O[dt][4 * i + 3] * inv);
+        *(f16x4*)(op + d) = w;
+      }
+    }
+}
+
+extern "C" int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
+                                     int32_t Nq, int32_t Nkv, int32_t D, float scale, void* stream) {
+  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < AT_BQ || Nq % AT_BQ || Nkv < AT_BKV || Nkv % AT_BKV) return 1;
+  const float c = scale * 1.4426950408889634f;
+  const dim3 grid(Nq / AT_BQ, B * H), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 40:
+      hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, block, 0, s, (const _Float16*)q, (const _Float16*)k,
+                         (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c);
+      break;
+    case 64:
+      hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, s, (const _Float16*)q, (const _Float16*)k,
+                         (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c);
+      break;
+    default:
+      return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

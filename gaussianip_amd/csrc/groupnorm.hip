@@ -11,7 +11,7 @@
 #include "../../include/gip_nn.h"
 
 #define GN_BLOCK 256
-#define GN_MAX_SPLITS 64
+#define GN_MAX_SPLITS 128
 
 struct alignas(16) half8 { __half2 a, b, c, d; };
 
@@ -77,6 +77,7 @@ gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, cons
     }
     const half8* xp = x + ((long long)n * HW) * gm.tpr + chunk;
     const half8* dp = MODE == 1 ? dy + ((long long)n * HW) * gm.tpr + chunk : nullptr;
+#pragma unroll 4
     for (long long r = r0 + ry; r < r1; r += gm.rows_per_iter) {
       float v[8];
       unpack8(xp[r * gm.tpr], v);
@@ -166,6 +167,7 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
       }
     }
     const long long base = ((long long)n * HW) * gm.tpr + chunk;
+#pragma unroll 4
     for (long long r = r0 + ry; r < r1; r += gm.rows_per_iter) {
       float v[8], o[8];
       unpack8(x[base + r * gm.tpr], v);

@@ -204,3 +204,21 @@ def conv1x1(x, w, bias=None):
         y = F.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w.reshape(w.shape[0], C), bias)
         return y.view(N, H, W, w.shape[0]).permute(0, 3, 1, 2)
     return F.conv2d(x, w, bias)
+
+
+def attention_supported(q, k, heads):
+    D = q.shape[-1] // heads
+    return (q.is_cuda and q.dtype == torch.float16 and D in (40, 64) and q.shape[1] % 128 == 0 and k.shape[1] % 64 == 0 and
+            q.is_contiguous() and k.is_contiguous() and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
+
+
+def attention(q, k, v, heads):
+    """softmax(q k^T / sqrt(D)) v on [B, N, heads * D] projections; returns [B, Nq, heads * D] (csrc/attention.hip)."""
+    B, Nq, C = q.shape
+    D = C // heads
+    o = torch.empty_like(q)
+    rc = _lib.nn_lib().gip_attention_fwd_f16(_p(q), _p(k), _p(v.contiguous()), _p(o), B, heads, Nq, k.shape[1], D,
+                                             float(D) ** -0.5, ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("gip_attention_fwd_f16 failed with status %d" % rc)
+    return o

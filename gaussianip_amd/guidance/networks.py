@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from .fused import GroupNormAct, add_bias_residual, conv1x1, conv3x3, fusable, geglu
 
 TEXT_TOKENS = 77
@@ -120,6 +121,10 @@ class Attention(nn.Module):
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if self.lora_rank:
             q, k, v = q + self.lora_q(x), k + self.lora_k(ctx), v + self.lora_v(ctx)
+        if ip_ctx is None and fused.attention_supported(q, k, self.heads):
+            h = fused.attention(q, k, v, self.heads)          # [B, N, C] in and out: no head transposes
+            out = self.to_out(h)
+            return out + self.lora_out(h) if self.lora_rank else out
         q = self._split(q)
         h = F.scaled_dot_product_attention(q, self._split(k), self._split(v))
         if ip_ctx is not None:

@@ -48,6 +48,14 @@ int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
  * Replaces the MIOpen call behind diffusers' ResnetBlock2D / Upsample2D convolutions in the denoiser and the VAE. */
 int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
+
+/* Self-attention forward softmax(q k^T * scale) v (csrc/attention.hip): q, o [B, Nq, H*D], k, v [B, Nkv, H*D] half —
+ * the projection outputs / to_out input, heads interleaved along the last axis (no head transposes).  fp32 softmax and
+ * accumulation.  No mask, no gradient (the denoiser is frozen).  D in {40, 64}; Nq % 128 == 0; Nkv % 64 == 0.
+ * Replaces torch SDPA inside LoRAAttnProcessor2_0 (attention_processor_faceid.py:300-318) for the U-Net / ControlNet
+ * self-attention at the 64x64 latent level, which holds ~90 % of the denoiser's attention FLOPs. */
+int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t Nq,
+                          int32_t Nkv, int32_t D, float scale, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,40 @@
+"""gip_attention_fwd_f16 (csrc/attention.hip) against an fp32 softmax(QK^T/sqrt(D))V of the same fp16 operands.
+Tolerance: probabilities and the output are rounded to half once each => ~1e-3 relative to max|out|."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,H,Nq,Nkv,D", [(1, 1, 128, 64, 40), (2, 8, 256, 256, 40), (2, 3, 1024, 1024, 64), (12, 8, 4096, 4096, 40),
+                                          (1, 2, 384, 1152, 40)])
+@pytest.mark.parametrize("spread", [1.0, 6.0])
+def test_attention_matches_fp32_reference(B, H, Nq, Nkv, D, spread):
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(Nq + D)
+    q = (torch.randn(B, Nq, H * D, device="cuda", generator=g) * spread).half()
+    k = (torch.randn(B, Nkv, H * D, device="cuda", generator=g) * spread).half()
+    v = torch.randn(B, Nkv, H * D, device="cuda", generator=g).half()
+    assert fused.attention_supported(q, k, H)
+    with torch.no_grad():
+        o = fused.attention(q, k, v, H)
+        sp = lambda t, n: t.float().view(B, n, H, D).transpose(1, 2)  # noqa: E731
+        ref = F.scaled_dot_product_attention(sp(q, Nq), sp(k, Nkv), sp(v, Nkv)).transpose(1, 2).reshape(B, Nq, H * D)
+    err = float((o.float() - ref).abs().max())
+    assert err <= 3e-3 * max(1.0, float(ref.abs().max())), err
+    assert torch.equal(fused.attention(q, k, v, H), o)
+
+
+def test_attention_module_uses_the_hip_kernel(monkeypatch):
+    from gaussianip_amd.guidance import fused, networks as nw
+    calls = []
+    orig = fused.attention
+    monkeypatch.setattr(fused, "attention", lambda *a: (calls.append(1), orig(*a))[1])
+    att = nw.init_for_benchmark(nw.Attention(320, None, 8)).cuda().half().requires_grad_(False)
+    x = torch.randn(2, 1024, 320, device="cuda").half()
+    with torch.no_grad():
+        got = att(x)
+        q, k, v = att.to_q(x), att.to_k(x), att.to_v(x)
+        ref = att.to_out(F.scaled_dot_product_attention(att._split(q), att._split(k), att._split(v)).transpose(1, 2).reshape(2, 1024, 320))
+    assert calls and float((got.float() - ref.float()).abs().max()) < 5e-3 * max(1.0, float(ref.abs().max()))
