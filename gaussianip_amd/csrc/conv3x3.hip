@@ -4,9 +4,11 @@
 // GEMM view: D[co][m] = sum_k W[co][k] * X[m][k],  m = (n, y, x) output pixel, k = (tap, ci), K = 9 * Cin.
 //   * workgroup tile 128 pixels x BN output channels (BN = 128, or 160 so that Cout = 320 splits without waste),
 //     4 waves as 2 (pixel halves) x 2 (channel halves), K step 64 = one tap x 64 input channels;
-//   * both operands are staged global -> LDS by 16-byte LDS-DMA (global_load_lds): a pixel row of the K step is the 128
-//     contiguous bytes x[n, y+dy-1, x+dx-1, c0:c0+64] of the NHWC tensor; taps that fall outside the image read a
-//     zero page instead (per-lane source select — the LDS side of the DMA is lane-linear, the global side is free);
+//   * both operands are staged global -> LDS by 16-byte LDS-DMA (buffer_load_dwordx4 ... lds): a pixel row of the K step
+//     is the 128 contiguous bytes x[n, y+dy-1, x+dx-1, c0:c0+64] of the NHWC tensor.  The lane's byte offset of the
+//     CENTRE pixel is a loop-invariant VGPR, the tap / channel-block displacement is the instruction's SGPR offset, and a
+//     tap that falls outside the image gets an out-of-range offset, for which the buffer unit returns zeros — the
+//     zero padding costs one v_cndmask per load and no memory;
 //   * the LDS image keeps 128-byte rows; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 ON THE SOURCE
 //     ADDRESS, which makes every 16-lane group of a ds_read_b128 fragment read cover all 64 banks once;
 //   * two LDS stages: the DMA of K step t+1 is in flight while the MFMAs of step t run; one barrier per step;
@@ -27,13 +29,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CV_BK 64
 #define CV_THREADS 256
 
-__device__ __attribute__((aligned(256))) unsigned int g_conv_zero_page[64];   // 256 bytes of zeros
+#define CV_OOB 0xFFFF0000u                // voffset beyond any num_records: the buffer load returns 0
+#define CV_RSRC_FLAGS 0x00020000         // raw buffer, 32-bit data format (gfx9 family)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-__device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
 template <int BN>
@@ -63,8 +65,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   // ---- per-thread DMA descriptors (fixed over the K loop) ----
   const int sub_row = wave * 8 + (lane >> 3);            // row inside a 32-row round
   const int pchunk = lane & 7;                           // physical 16-byte chunk this lane fills
-  const char* zero = (const char*)g_conv_zero_page;
-  int a_off[4];                                          // byte offset of the centre pixel's channel 0 (+ swizzled chunk)
+  unsigned a_off[4];                                     // byte offset of the centre pixel's channel 0 (+ swizzled chunk)
   unsigned a_mask[4];                                    // 9 validity bits, one per tap
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -72,7 +73,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     const long long m = m0 + row;
     const int lchunk = pchunk ^ ((row >> 1) & 7);
     unsigned mask = 0;
-    int off = 0;
+    unsigned off = 0;
     if (m < M) {
       const int n = (int)(m / HW), rem = (int)(m - (long long)n * HW);
       const int y = rem / W, xx = rem - y * W;
@@ -81,42 +82,38 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #pragma unroll
         for (int dx = 0; dx < 3; dx++)
           if ((unsigned)(y + dy - 1) < (unsigned)H && (unsigned)(xx + dx - 1) < (unsigned)W) mask |= 1u << (dy * 3 + dx);
-      off = (int)(m * Cin + lchunk * 8) * 2;
+      off = (unsigned)(m * Cin + lchunk * 8) * 2u;
     }
     a_off[i] = off;
     a_mask[i] = mask;
   }
-  int b_off[B_ROUNDS];
-  bool b_ok[B_ROUNDS];
+  unsigned b_off[B_ROUNDS];
 #pragma unroll
   for (int i = 0; i < B_ROUNDS; i++) {
     const int row = i * 32 + sub_row;
     const int lchunk = pchunk ^ ((row >> 1) & 7);
-    b_ok[i] = co0 + row < Cout;
-    b_off[i] = ((co0 + row) * 9 * Cin + lchunk * 8) * 2;
+    b_off[i] = co0 + row < Cout ? (unsigned)((co0 + row) * 9 * Cin + lchunk * 8) * 2u : CV_OOB;
   }
+  // buffer resources: activations based one row + one pixel BEFORE x so that every tap displacement is >= 0
+  const unsigned shift = (unsigned)(W + 1) * Cin * 2u;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)x - shift), 0, (int)((unsigned)(M * Cin) * 2u + 2u * shift + (unsigned)Cin * 2u), CV_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t wr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * 9u * Cin * 2u), CV_RSRC_FLAGS);
 
   const int cblocks = Cin / CV_BK;
   const int KT = 9 * cblocks;
-  const char* xb = (const char*)x;
-  const char* wb = (const char*)w;
 
   auto stage = [&](int tap, int cb, int buf) {
     const int dy = tap / 3, dx = tap - dy * 3;
-    const int tap_off = (((dy - 1) * W + (dx - 1)) * Cin + cb * CV_BK) * 2;
-    const int wtap_off = (tap * Cin + cb * CV_BK) * 2;
+    const unsigned tap_off = (unsigned)((dy * W + dx) * Cin + cb * CV_BK) * 2u;      // relative to the shifted base
+    const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
     unsigned char* sa = smem + buf * STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const char* src = ((a_mask[i] >> tap) & 1u) ? xb + a_off[i] + tap_off : zero + pchunk * 16;
-      dma16(src, sa + i * 4096);
-    }
+    for (int i = 0; i < 4; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 4096);
     unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < B_ROUNDS; i++) {
-      const char* src = b_ok[i] ? wb + b_off[i] + wtap_off : zero + pchunk * 16;
-      dma16(src, sb + i * 4096);
-    }
+    for (int i = 0; i < B_ROUNDS; i++) dma16(wr, b_off[i], wtap_off, sb + i * 4096);
   };
 
   f32x4 acc[NI][4];

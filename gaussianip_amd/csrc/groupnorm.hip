@@ -130,20 +130,33 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
   const bool active = ry < gm.rows_per_iter;
   const int cg = C / G;
   const float inv_m = 1.f / ((float)HW * (float)cg);
-  for (int g = threadIdx.x; g < G; g += GN_BLOCK) {
-    float s0 = 0.f, s1 = 0.f;
-    for (int s = 0; s < splits; s++) {
-      const float* p = partial + (((long long)n * splits + s) * G + g) * 2;
-      s0 += p[0]; s1 += p[1];
+  // per-group totals from the per-split partials: all 256 threads take part (group = t % G, split slice = t / G),
+  // fixed summation order
+  {
+    float* s_part = s_g + 2 * G;                      // [slices][G][2]
+    const int slices = GN_BLOCK / G > 0 ? GN_BLOCK / G : 1;
+    const int g = threadIdx.x % G, sl = threadIdx.x / G;
+    if (sl < slices) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int s = sl; s < splits; s += slices) {
+        const float* p = partial + (((long long)n * splits + s) * G + g) * 2;
+        s0 += p[0]; s1 += p[1];
+      }
+      s_part[(sl * G + g) * 2] = s0; s_part[(sl * G + g) * 2 + 1] = s1;
     }
-    if (MODE == 0) {
-      const float mu = s0 * inv_m;
-      const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
-      const float rs = rsqrtf(var + eps);
-      s_g[2 * g] = mu; s_g[2 * g + 1] = rs;
-      if (split == 0) { mean[n * G + g] = mu; rstd[n * G + g] = rs; }
-    } else {
-      s_g[2 * g] = s0 * inv_m; s_g[2 * g + 1] = s1 * inv_m;
+    __syncthreads();
+    for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int k = 0; k < slices; k++) { s0 += s_part[(k * G + gg) * 2]; s1 += s_part[(k * G + gg) * 2 + 1]; }
+      if (MODE == 0) {
+        const float mu = s0 * inv_m;
+        const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
+        const float rs = rsqrtf(var + eps);
+        s_g[2 * gg] = mu; s_g[2 * gg + 1] = rs;
+        if (split == 0) { mean[n * G + gg] = mu; rstd[n * G + gg] = rs; }
+      } else {
+        s_g[2 * gg] = s0 * inv_m; s_g[2 * gg + 1] = s1 * inv_m;
+      }
     }
   }
   __syncthreads();
@@ -201,9 +214,9 @@ static size_t reduce_lds_bytes(int C) {
 }
 
 static int pick_splits(int N, long long HW, int C) {
-  // enough workgroups to fill the chip (256 CUs x a few), at least ~64 rows each
+  // enough workgroups to fill the chip (256 CUs x a few), at least 8 rows each
   long long want = (2048 + N - 1) / N;
-  long long by_rows = (HW + 63) / 64;
+  long long by_rows = (HW + 7) / 8;
   long long s = want < by_rows ? want : by_rows;
   if (s < 1) s = 1;
   (void)C;
@@ -215,7 +228,7 @@ extern "C" size_t gip_gn_workspace_bytes(int32_t N, int32_t G) {
 }
 
 static int check(const void* a, const void* b, int32_t N, long long HW, int32_t C, int32_t G, size_t ws) {
-  if (!a || !b || N < 1 || HW < 1 || C < 8 || (C & 7) || G < 1 || C % G || C > 8192) return 1;
+  if (!a || !b || N < 1 || HW < 1 || C < 8 || (C & 7) || G < 1 || G > GN_BLOCK || C % G || C > 8192) return 1;
   if (ws < gip_gn_workspace_bytes(N, G)) return 2;
   return 0;
 }
@@ -235,7 +248,7 @@ extern "C" int gip_gn_silu_forward(const void* x, const void* gamma, const void*
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta,
                      (const float*)nullptr, (const float*)nullptr, partial, (long long)HW, C, G, rsplits, apply_silu,
                      (const __half*)addend, addend_stride);
-  hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)G * 2 * sizeof(float), s,
+  hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
                      (const float*)partial, (half8*)y, (long long)HW, C, G, rsplits, splits, eps, apply_silu,
                      (const __half*)addend, addend_stride);
@@ -256,7 +269,7 @@ extern "C" int gip_gn_silu_backward(const void* x, const void* dy, const void* g
   hipLaunchKernelGGL((gn_reduce_kernel<1>), dim3(rsplits, N), dim3(GN_BLOCK), reduce_lds_bytes(C), s,
                      (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta, mean, rstd, partial,
                      (long long)HW, C, G, rsplits, apply_silu, (const __half*)addend, addend_stride);
-  hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(splits, N), dim3(GN_BLOCK), (size_t)G * 2 * sizeof(float), s,
+  hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta,
                      const_cast<float*>(mean), const_cast<float*>(rstd), (const float*)partial, (half8*)dx,
                      (long long)HW, C, G, rsplits, splits, 0.f, apply_silu, (const __half*)addend, addend_stride);
