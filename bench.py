@@ -78,11 +78,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    local_rank %= max(torch.cuda.device_count(), 1)     # (a 2-rank functional check can share one GPU over gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("GIP_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     P, H, W, V = args.gaussians, args.size, args.size, args.views
     K = 1  # SH coefficients per channel at the shipped sh_degree 0
@@ -140,8 +145,11 @@ def main():
     if not args.no_ahds:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_ahds
-        ahds = bench_ahds.measure(steps=args.ahds_steps, warmup=4, gaussians=P, flops=(rank == 0), rank=rank, world=world,
-                                  device=dev)
+        try:
+            ahds = bench_ahds.measure(steps=args.ahds_steps, warmup=4, gaussians=P, flops=(rank == 0), rank=rank,
+                                      world=world, device=dev)
+        except Exception as e:  # the raster line above is the contract metric: never lose it to the secondary measurement
+            ahds = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     out = None
     if rank == 0:
         # ---- roofline: live per-kernel durations (hipEvents on the launch stream) ----
