@@ -111,6 +111,27 @@ def knn_lib():
     return _knn
 
 
+_model = None
+
+
+class GipGatherTensor(ctypes.Structure):
+    _fields_ = [("old_rows", ctypes.c_void_p), ("new_rows", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+                ("row_bytes", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def model_lib():
+    global _model
+    if _model is None:
+        path = os.path.join(LIB_DIR, "libgip_model.so")
+        if not os.path.exists(path):
+            raise _missing("libgip_model.so")
+        lib = ctypes.CDLL(path)
+        lib.gip_gather_rows.restype = ctypes.c_int
+        lib.gip_gather_rows.argtypes = [ctypes.POINTER(GipGatherTensor), ctypes.c_int32, _vp, ctypes.c_int64, ctypes.c_int64, _vp]
+        _model = lib
+    return _model
+
+
 _nn = None
 
 

@@ -18,6 +18,7 @@
 //     blocks) are consecutive on ONE XCD and hit in its L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gip_nn.h"
 
@@ -38,8 +39,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-template <int BN>
-__global__ void __launch_bounds__(CV_THREADS, 2)
+template <int BN, int STAGES>
+__global__ void __launch_bounds__(CV_THREADS, STAGES == 2 ? 2 : 1)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles) {
@@ -127,16 +128,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   const int pix_base = (wm * 64 + frag_row) * 128;
   const int ch_base = A_BYTES + (wn * (BN / 2) + frag_row) * 128;
 
-  int tap = 0, cb = 0;
-  stage(0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < KT; kt++) {
-    const int buf = kt & 1;
-    int ntap = tap, ncb = cb + 1;
-    if (ncb == cblocks) { ncb = 0; ntap = tap + 1; }
-    if (kt + 1 < KT) stage(ntap, ncb, buf ^ 1);
-    const unsigned char* sbuf = smem + buf * STAGE;
+  auto compute = [&](const unsigned char* sbuf) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const int pc = ((ks * 4 + kq) ^ swz) * 16;
@@ -151,10 +143,42 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         for (int mi = 0; mi < 4; mi++)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[ni], pix[mi], acc[ni][mi], 0, 0, 0);
     }
+  };
+
+  int tap = 0, cb = 0;                     // K step the NEXT stage() call loads
+  auto advance = [&]() {
+    if (++cb == cblocks) { cb = 0; ++tap; }
+  };
+  if constexpr (STAGES == 2) {
+    stage(0, 0, 0);
+    advance();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    tap = ntap;
-    cb = ncb;
+    for (int kt = 0; kt < KT; kt++) {
+      const int buf = kt & 1;
+      if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
+      compute(smem + buf * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // three stages, one workgroup per CU: the DMA of step t+2 is issued before the math of step t, the wait at the top
+    // of a step is COUNTED (the newest tile stays in flight across the barrier), one raw s_barrier per step
+    constexpr int NDMA = 4 + B_ROUNDS;
+    stage(0, 0, 0);
+    advance();
+    if (KT > 1) { stage(tap, cb, 1); advance(); }
+    int buf = 0, fill = 2;
+    for (int kt = 0; kt < KT; kt++) {
+      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < KT) { stage(tap, cb, fill); advance(); }
+      compute(smem + buf * STAGE);
+      buf = buf == 2 ? 0 : buf + 1;
+      fill = fill == 2 ? 0 : fill + 1;
+    }
   }
 
   // ---- epilogue: lane holds out[pixel = lane & 15][co = (lane >> 4) * 4 + 0..3] of each 16x16 tile ----
@@ -182,19 +206,19 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   }
 }
 
-template <int BN>
+template <int BN, int STAGES>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
                   int Cin, int Cout, hipStream_t s) {
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + BN - 1) / BN;
-  const size_t lds = 2 * (size_t)(CV_BM + BN) * 128;
+  const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return 3;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<BN>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds, s, (const _Float16*)x,
+  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds, s, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin,
                      Cout, m_tiles, n_tiles);
   return hipGetLastError() == hipSuccess ? 0 : 3;
@@ -206,6 +230,11 @@ extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
   if ((long long)N * H * W * (long long)(Cin > Cout ? Cin : Cout) * 2 >= (1ll << 31)) return 1;   // 32-bit byte offsets
   if ((long long)Cout * 9 * Cin * 2 >= (1ll << 31)) return 1;
   hipStream_t s = (hipStream_t)stream;
-  if (Cout % 160 == 0 && Cout % 128 != 0) return launch<160>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
-  return launch<128>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+  static const int stages = [] { const char* e = getenv("GIP_CONV_STAGES"); return e && e[0] == '3' ? 3 : 2; }();
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  if (stages == 3)
+    return wide ? launch<160, 3>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
+                : launch<128, 3>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+  return wide ? launch<160, 2>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
+              : launch<128, 2>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
 }

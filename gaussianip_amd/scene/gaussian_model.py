@@ -306,6 +306,101 @@ class GaussianModel:
                                    self._scaling[sel], self._rotation[sel])
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, max_world_size):
+        if self._xyz.is_cuda:
+            return self._densify_and_prune_fused(max_grad, min_opacity, extent, max_screen_size, max_world_size)
+        return self._densify_and_prune_stepwise(max_grad, min_opacity, extent, max_screen_size, max_world_size)
+
+    def _gather_all(self, index, n_old, new_rows):
+        """One launch (include/gip_model.h) rebuilds the six parameters and their Adam moments:
+        row j <- old[index[j]] if index[j] < n_old else new_rows[name][index[j] - n_old] (moments of new rows: zeros)."""
+        import ctypes
+        from .. import _lib
+        lib = _lib.model_lib()
+        n_out = int(index.numel())
+        descs, outs, keep_alive = [], {}, []
+        for group in self.optimizer.param_groups:
+            name, old = group["name"], group["params"][0]
+            new = new_rows[name].contiguous()
+            dst = torch.empty((n_out,) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
+            rb = dst[0:1].numel() * dst.element_size() if n_out else 0     # zero for SH degree 0's empty f_rest rows
+            if rb:
+                descs.append((old.data.contiguous(), new, dst, rb))
+            state = self.optimizer.state.get(old, None)
+            moments = {}
+            if state is not None and "exp_avg" in state:
+                for key in ("exp_avg", "exp_avg_sq"):
+                    mdst = torch.empty_like(dst)
+                    if rb:
+                        descs.append((state[key].contiguous(), None, mdst, rb))
+                    moments[key] = mdst
+            outs[name] = (dst, moments)
+        arr = (_lib.GipGatherTensor * len(descs))()
+        for i, (o, nw, d, rb) in enumerate(descs):
+            arr[i].old_rows = o.data_ptr() if o.numel() else None
+            arr[i].new_rows = nw.data_ptr() if (nw is not None and nw.numel()) else None
+            arr[i].dst, arr[i].row_bytes = d.data_ptr(), rb
+            keep_alive.append((o, nw, d))
+        rc = 0
+        if descs:
+            rc = lib.gip_gather_rows(arr, len(descs), ctypes.c_void_p(index.data_ptr()), n_out, n_old,
+                                     ctypes.c_void_p(torch.cuda.current_stream(index.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_gather_rows failed with status %d" % rc)
+        rebuilt = {}
+        for group in self.optimizer.param_groups:
+            old = group["params"][0]
+            dst, moments = outs[group["name"]]
+            state = self.optimizer.state.pop(old, None)
+            new = nn.Parameter(dst.requires_grad_(True))
+            if state is not None:
+                state.update(moments)
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            rebuilt[group["name"]] = new
+        return rebuilt
+
+    def _densify_and_prune_fused(self, max_grad, min_opacity, extent, max_screen_size, max_world_size, N=2):
+        """densify_and_clone -> densify_and_split -> prune_points x2 of the reference (gaussian_model.py:357-411) with
+        the same selections, the same torch.normal draw and the same final row order, but every tensor rebuilt ONCE:
+        the survivors of [old | clones | split children] are described by one index list and moved by gip_gather_rows."""
+        P, dev = self.get_xyz.shape[0], self.get_xyz.device
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        scaling = self.get_scaling
+        big = scaling.max(dim=1).values > self.percent_dense * extent
+        clone_sel = (torch.norm(grads, dim=-1) >= max_grad) & ~big
+        split_sel = (grads.squeeze(-1) >= max_grad) & big
+        stds = scaling[split_sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
+        rots = build_rotation(self._rotation[split_sel]).repeat(N, 1, 1)
+        child_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[split_sel].repeat(N, 1)
+        child_scaling = self.scaling_inverse_activation(scaling[split_sel].repeat(N, 1) / (0.8 * N))
+        new_rows = {
+            "xyz": torch.cat((self._xyz[clone_sel], child_xyz)),
+            "f_dc": torch.cat((self._features_dc[clone_sel], self._features_dc[split_sel].repeat(N, 1, 1))),
+            "f_rest": torch.cat((self._features_rest[clone_sel], self._features_rest[split_sel].repeat(N, 1, 1))),
+            "opacity": torch.cat((self._opacity[clone_sel], self._opacity[split_sel].repeat(N, 1))),
+            "scaling": torch.cat((self._scaling[clone_sel], child_scaling)),
+            "rotation": torch.cat((self._rotation[clone_sel], self._rotation[split_sel].repeat(N, 1))),
+        }
+
+        def pruned(opacity_raw, scaling_raw):
+            m = (self.opacity_activation(opacity_raw) < min_opacity).squeeze(-1)
+            if max_screen_size:     # max_radii2D was reset to zeros by the densification: only the world-size test can fire
+                m = m | (torch.zeros_like(m, dtype=torch.float32) > max_screen_size) | \
+                    (self.scaling_activation(scaling_raw).max(dim=1).values > max_world_size)
+            return m
+        keep_old = ~split_sel & ~pruned(self._opacity, self._scaling)
+        keep_new = ~pruned(new_rows["opacity"], new_rows["scaling"])
+        index = torch.cat((torch.nonzero(keep_old).squeeze(-1), P + torch.nonzero(keep_new).squeeze(-1))).contiguous()
+        self._adopt(self._gather_all(index, P, new_rows))
+        n = int(index.numel())
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        self.max_radii2D = torch.zeros((n,), device=dev)
+        torch.cuda.empty_cache()
+
+    def _densify_and_prune_stepwise(self, max_grad, min_opacity, extent, max_screen_size, max_world_size):
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
         self.densify_and_clone(grads, max_grad, extent)

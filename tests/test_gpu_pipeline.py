@@ -172,3 +172,53 @@ def test_stage_one_step_schedule_and_loss():
             assert gm.get_xyz.shape[0] != n0 or fired[step] == "prune_only"
     assert fired == {499: None, 500: "densify_and_prune", 1000: "densify_and_prune", 1500: "densify_and_prune",
                      1700: None, 1800: "prune_only"}
+
+
+def test_fused_densify_matches_stepwise_reference_semantics():
+    """densify_and_prune through ONE gip_gather_rows launch (include/gip_model.h) against the step-by-step
+    mask / cat path that mirrors gaussian_model.py:357-411: same survivors, same order, same Adam moments — bitwise."""
+    from argparse import ArgumentParser
+    import copy
+    from gaussianip_amd.arguments import OptimizationParams
+    from gaussianip_amd.scene import GaussianModel
+    from gaussianip_amd.utils import BasicPointCloud
+
+    def build():
+        rng = np.random.default_rng(7)
+        P = 20000
+        pts = rng.normal(0, 0.3, (P, 3)).astype(np.float32)
+        gm = GaussianModel(1)
+        gm.create_from_pcd(BasicPointCloud(pts, rng.uniform(0, 1, (P, 3)).astype(np.float32), None), 4.0)
+        gm.training_setup(OptimizationParams(ArgumentParser()))
+        g = torch.Generator(device="cuda").manual_seed(3)
+        with torch.no_grad():
+            gm._scaling.add_(torch.randn(gm._scaling.shape, device="cuda", generator=g) * 0.8)
+            gm._opacity.add_(torch.randn(gm._opacity.shape, device="cuda", generator=g) * 2.0)
+            gm._rotation.copy_(torch.randn(gm._rotation.shape, device="cuda", generator=g))
+        for grp in gm.optimizer.param_groups:          # one Adam step so that the moments are non-trivial
+            p = grp["params"][0]
+            p.grad = torch.randn(p.shape, device="cuda", generator=g) * 1e-3
+        gm.optimizer.step()
+        gm.xyz_gradient_accum = torch.rand((P, 1), device="cuda", generator=g) * 4e-3
+        gm.denom = torch.randint(0, 3, (P, 1), device="cuda", generator=g).float()      # zeros -> NaN -> 0 path
+        gm.max_radii2D = torch.rand((P,), device="cuda", generator=g) * 100
+        return gm
+
+    args = dict(max_grad=1e-3, min_opacity=0.05, extent=4.0, max_screen_size=20, max_world_size=0.5)
+    a, b = build(), build()
+    torch.manual_seed(11)
+    a._densify_and_prune_stepwise(**args)
+    torch.manual_seed(11)
+    b.densify_and_prune(**args)
+    assert a.get_xyz.shape[0] == b.get_xyz.shape[0] and a.get_xyz.shape[0] != 20000
+    for attr in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "xyz_gradient_accum", "denom", "max_radii2D"):
+        assert torch.equal(getattr(a, attr), getattr(b, attr)), attr
+    for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
+        sa, sb = a.optimizer.state[ga["params"][0]], b.optimizer.state[gb["params"][0]]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), ga["name"]
+        assert ga["params"][0] is getattr(a, dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling", rotation="_rotation")[ga["name"]])
+    # the rebuilt model trains on: one more optimizer step works and keeps shapes
+    for grp in b.optimizer.param_groups:
+        p = grp["params"][0]
+        p.grad = torch.zeros_like(p)
+    b.optimizer.step()
