@@ -128,6 +128,8 @@ def model_lib():
         lib = ctypes.CDLL(path)
         lib.gip_gather_rows.restype = ctypes.c_int
         lib.gip_gather_rows.argtypes = [ctypes.POINTER(GipGatherTensor), ctypes.c_int32, _vp, ctypes.c_int64, ctypes.c_int64, _vp]
+        lib.gip_openpose_draw.restype = ctypes.c_int
+        lib.gip_openpose_draw.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]
         _model = lib
     return _model
 

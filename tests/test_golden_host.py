@@ -264,7 +264,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.gip_raster_state_bytes(ctypes.byref(cfg)) > 0 and lib.gip_raster_scratch_bytes(ctypes.byref(cfg)) == (1 << 16) * 64
     cfg.V = 99
     assert lib.gip_raster_state_bytes(ctypes.byref(cfg)) == 0
-    for header, loader in (("gip_knn.h", _lib.knn_lib), ("gip_nn.h", _lib.nn_lib), ("gip_model.h", _lib.model_lib)):
+    for header, loader in (("gip_knn.h", _lib.knn_lib), ("gip_nn.h", _lib.nn_lib), ("gip_model.h", _lib.model_lib), ("gip_pose.h", _lib.model_lib)):
         other = loader()
         for sym in set(re.findall(r"\b(gip_[a-z_0-9]+)\s*\(", open(os.path.join(root, "include", header)).read())):
             assert hasattr(other, sym), (header, sym)

@@ -1,0 +1,66 @@
+"""OpenPose control maps (include/gip_pose.h): the HIP drawer against oracle/pose_oracle.py (bit-exact, uint8 canvas)
+and the batched visibility rules against a per-view loop written like poser.py:843-876."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _loop_visibility(ndc, xs, ys, H, W, azimuth, head_zoom):
+    mask = (xs >= 0) & (xs < W) & (ys >= 0) & (ys < H)
+    if head_zoom:
+        mask = np.full_like(mask, False)
+        for i in (0, 1, 3, 6, -1, -2, -3, -4):
+            mask[i] = True
+    if 0 < azimuth < 60:
+        mask[-2] = False
+    if 120 < azimuth < 180:
+        mask[-1] = False
+    if ndc[0, 2] > ndc[-1, 2] and ndc[0, 2] < ndc[-2, 2]:
+        mask[-2] = False
+        mask[-4] = False
+        if azimuth < 0:
+            mask[-3] = False
+    elif ndc[0, 2] < ndc[-1, 2] and ndc[0, 2] > ndc[-2, 2]:
+        mask[-1] = False
+        mask[-3] = False
+        if azimuth < 0 and azimuth != -180:
+            mask[-4] = False
+    elif ndc[0, 2] > ndc[-1, 2] and ndc[0, 2] > ndc[-2, 2]:
+        mask[0] = False
+        mask[-3] = False
+        mask[-4] = False
+    return mask
+
+
+def test_pose_maps_match_the_oracle_and_the_loop_rules():
+    import scenes
+    from gaussianip_amd.poser import Skeleton
+    from oracle import pose_oracle
+    sk = Skeleton("cuda")
+    sk.scale(-10)                                           # GaussianIP.py:128
+    H = W = 512
+    azs = [-170.0, -95.0, -30.0, 10.0, 45.0, 100.0, 150.0, 179.0]
+    cams = [scenes.camera(rng_e, az, 1.5, 55.0, H, W) for rng_e, az in zip((-20, 5, 25, 0, -10, 15, 30, -30), azs)]
+    mvp = torch.stack([torch.from_numpy(c["projmatrix"]).T for c in cams]).cuda()       # row-vector layout -> column mvp
+    head_zoom = [False, False, True, False, False, True, False, False]
+    canvas, all_vis, xy = sk.openpose_draw(mvp, H, W, azs, head_zoom)
+    assert canvas.shape == (8, H, W, 3) and float(canvas.max()) <= 1.0 and float(canvas.sum()) > 0
+    ndc, xs, ys = sk.project(mvp, H, W)
+    mask = sk.visibility(ndc, xs, ys, H, W, azs, head_zoom)
+    limbs = sk.limb_parameters(xs, ys, mask).cpu().numpy()
+    pts_px = torch.stack([xs.trunc(), ys.trunc()], -1).to(torch.int32).cpu().numpy()
+    for v in range(8):
+        ref_mask = _loop_visibility(ndc[v].cpu().numpy(), xs[v].cpu().numpy(), ys[v].cpu().numpy(), H, W, azs[v], head_zoom[v])
+        assert np.array_equal(ref_mask, mask[v].cpu().numpy()), v
+        assert int(all_vis[v]) == int(ref_mask.all())
+        want = pose_oracle.draw(pts_px[v], ref_mask, limbs[v], H, W)
+        got = canvas[v].cpu().numpy()
+        assert np.array_equal(np.rint(got * 255).astype(np.uint8), np.rint(want * 255).astype(np.uint8)), v
+        assert np.array_equal(got, want), v
+    # single-view form, as the reference calls it
+    c0, v0, xy0 = sk.openpose_draw(mvp[0], H, W, azs[0], head_zoom[0])
+    assert torch.equal(c0, canvas[0]) and int(v0) == int(all_vis[0])
