@@ -112,9 +112,61 @@ class Attention(nn.Module):
         B, N, C = x.shape
         return x.view(B, N, self.heads, C // self.heads).transpose(1, 2)
 
+    def _qkv(self, x, ctx):
+        q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
+        if self.lora_rank:
+            q, k, v = q + self.lora_q(x), k + self.lora_k(ctx), v + self.lora_v(ctx)
+        return q, k, v
+
+    def _kv(self, ctx):
+        k, v = self.to_k(ctx), self.to_v(ctx)
+        if self.lora_rank:
+            k, v = k + self.lora_k(ctx), v + self.lora_v(ctx)
+        return k, v
+
+    def _sdpa(self, q, k, v):
+        """[B, N, C] projections -> [B, Nq, C]; the HIP kernel where it applies, torch SDPA otherwise."""
+        if fused.attention_supported(q, k, self.heads):
+            return fused.attention(q, k, v, self.heads)
+        h = F.scaled_dot_product_attention(self._split(q), self._split(k), self._split(v))
+        return h.transpose(1, 2).reshape(q.shape)
+
+    refine = None        # RefineAttentionState when this layer is one of the VCR target self-attentions
+
+    def _forward_refine(self, x):
+        """Self-attention in the 'refine' state of LoRAAttnProcessor2_0 (attention_processor_faceid.py:291-364):
+        key views store their tokens per denoising step; k0..k3 attend over [own | front-or-back] tokens (mutual
+        self-attention); every other view blends its own attention with the attentions over its two neighbouring key
+        views' stored tokens: lambda_self * self + (1 - lambda_self) * (w_l * left + w_r * right)."""
+        st = self.refine
+        name, step = st.ctl.cur_view_name, st.cur_denoise_step
+        if "v" not in name:
+            st.stored_zt.setdefault(name, []).append(x)
+        if name in ("front", "back", "left", "right"):
+            q, k, v = self._qkv(x, x)
+            h = self._sdpa(q, k, v)
+        elif name in ("k0", "k1", "k2", "k3"):
+            other = st.stored_zt["front" if name in ("k0", "k1") else "back"][step]
+            q, k, v = self._qkv(x, torch.cat([x, other], dim=1))
+            h = self._sdpa(q, k, v)
+        else:
+            (ln, rn), (lw, rw) = st.ctl.cur_key_view_name_pair, st.ctl.cur_key_view_weight_pair
+            q, k, v = self._qkv(x, x)
+            kl, vl = self._kv(st.stored_zt[ln][step])
+            kr, vr = self._kv(st.stored_zt[rn][step])
+            h = st.ctl.lambda_self * self._sdpa(q, k, v) + (1.0 - st.ctl.lambda_self) * (
+                lw * self._sdpa(q, kl, vl) + rw * self._sdpa(q, kr, vr))
+        st.cur_denoise_step += 1
+        if st.cur_denoise_step == st.ctl.total_denoise_step:
+            st.cur_denoise_step = 0
+        out = self.to_out(h)
+        return out + self.lora_out(h) if self.lora_rank else out
+
     def forward(self, x, ctx=None):
         ip_ctx = None
         if ctx is None:
+            if self.refine is not None and self.refine.ctl.state == "refine":
+                return self._forward_refine(x)
             ctx = x
         elif self.ip:
             ctx, ip_ctx = ctx[:, :-IP_TOKENS], ctx[:, -IP_TOKENS:]
@@ -378,6 +430,43 @@ class VAEEncoder(nn.Module):
         std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
         noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
         return (mean + std * noise) * self.scaling_factor
+
+
+class VAEDecoder(nn.Module):
+    """AutoencoderKL.decode (sd-vae-ft-mse shape): post_quant_conv, 4 -> 512, mid attention, up blocks 512/512/256/128
+    with three ResnetBlock2D each and nearest-2x upsampling after the first three, 128 -> 3.  Used by the VCR refine pass
+    (refine.py:220-239 -> pipeline_ipa_controlnet.py:1856-1859)."""
+
+    def __init__(self):
+        super().__init__()
+        self.post_quant_conv = nn.Conv2d(4, 4, 1)
+        self.conv_in = nn.Conv2d(4, 512, 3, padding=1)
+        self.mid_res1, self.mid_res2 = ResBlock(512, 512, 0, 1e-6), ResBlock(512, 512, 0, 1e-6)
+        self.mid_norm = GroupNormAct(32, 512, eps=1e-6, act=False)
+        self.mid_attn = Attention(512, None, heads=1)
+        self.mid_attn.to_q, self.mid_attn.to_k, self.mid_attn.to_v = nn.Linear(512, 512), nn.Linear(512, 512), nn.Linear(512, 512)
+        self.res, self.up = nn.ModuleList(), nn.ModuleList()
+        c = 512
+        for i, w in enumerate((512, 512, 256, 128)):
+            for _ in range(3):
+                self.res.append(ResBlock(c, w, temb_dim=0, eps=1e-6))
+                c = w
+            self.up.append(Upsample(w) if i < 3 else nn.Identity())
+        self.norm_out = GroupNormAct(32, 128, eps=1e-6, act=True)
+        self.conv_out = nn.Conv2d(128, 3, 3, padding=1)
+
+    def forward(self, z):
+        h = self.conv_in(self.post_quant_conv(z))
+        h = self.mid_res1(h)
+        B, C, H, W = h.shape
+        a = self.mid_attn(self.mid_norm(h).permute(0, 2, 3, 1).reshape(B, H * W, C))
+        h = h + a.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        h = self.mid_res2(h)
+        for i in range(4):
+            for j in range(3):
+                h = self.res[3 * i + j](h)
+            h = self.up[i](h)
+        return self.conv_out(self.norm_out(h))
 
 
 def init_for_benchmark(module, seed=0):

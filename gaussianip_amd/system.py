@@ -113,3 +113,41 @@ class StageOneStep:
                 g.prune_only(min_opacity=c.prune_opacity_threshold, max_world_size=c.prune_world_size_threshold)
                 action = "prune_only"
         return action
+
+
+class StageThreeStep:
+    """Stage 3 (GaussianIP.py:424-436): RGB-only reconstruction of the refined orbit images.  Renders a random subset of
+    the refine cameras, crops [60:890, 220:800], halves the resolution (bilinear) and takes
+    lambda_l1 * L1 + lambda_lpips * perceptual against the equally prepared refined images.  LPIPS needs pretrained
+    VGG weights that are not shippable: `perceptual` is a callable (default None = term omitted, stated in DESIGN.md)."""
+
+    CROP = (slice(60, 890), slice(220, 800))
+
+    def __init__(self, gaussian, pipe, background, cameras, refined_rgbs, view_idx_all, lambda_l1=1.0, lambda_lpips=0.0,
+                 perceptual=None, train_bs=4):
+        import torch.nn.functional as F
+        self.gaussian, self.pipe, self.background, self.cameras = gaussian, pipe, background, cameras
+        self.lambda_l1, self.lambda_lpips, self.perceptual, self.train_bs = lambda_l1, lambda_lpips, perceptual, train_bs
+        # refined_rgbs come in refinement order; put them back into orbit order (GaussianIP.py:418 idx_mapper)
+        order = torch.argsort(torch.as_tensor(view_idx_all))
+        gt = refined_rgbs[order.to(refined_rgbs.device)].permute(0, 3, 1, 2)
+        gt = gt[:, :, self.CROP[0], self.CROP[1]] if gt.shape[2] >= 890 and gt.shape[3] >= 800 else gt
+        self.gt_small = F.interpolate(gt, scale_factor=0.5, mode="bilinear", align_corners=False)
+        self.orbit_ids = torch.as_tensor(view_idx_all)[order].tolist()
+
+    def training_step(self, id_list=None, generator=None):
+        import random
+        import torch.nn.functional as F
+        from .renderer import render_views
+        if id_list is None:
+            id_list = random.sample(range(len(self.orbit_ids)), min(self.train_bs, len(self.orbit_ids)))
+        cams = [self.cameras[self.orbit_ids[i]] for i in id_list]
+        pkg = render_views(cams, self.gaussian, self.pipe, self.background)
+        img = pkg["render"]
+        img = img[:, :, self.CROP[0], self.CROP[1]] if img.shape[2] >= 890 and img.shape[3] >= 800 else img
+        small = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=False)
+        gt = self.gt_small[torch.as_tensor(id_list, device=self.gt_small.device)]
+        loss = self.lambda_l1 * (small - gt).abs().mean()
+        if self.perceptual is not None and self.lambda_lpips:
+            loss = loss + self.lambda_lpips * self.perceptual(small, gt).mean()
+        return {"loss": loss, "render_pkg": pkg, "id_list": id_list}

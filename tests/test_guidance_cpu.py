@@ -93,3 +93,72 @@ def test_guidance_plugin_token_layout_and_gradient_path():
     loss, gfix = sds.sds_loss(latents, grad)
     loss.backward()
     assert torch.allclose(latents.grad, gfix / B, atol=1e-6)
+
+    # ---- VCR refine pass on the same networks (tiny images, 2 of the 8 steps, one view of each attention branch) ----
+    from gaussianip_amd.guidance import refine as rf
+    from gaussianip_amd.guidance.networks import VAEDecoder, init_for_benchmark
+    dec = init_for_benchmark(VAEDecoder(), 5).eval().requires_grad_(False)
+    vcr = rf.ViewConsistentRefiner(gd, dec, num_steps=2)
+    rgb = torch.rand(32, 64, 64, 3, generator=g)
+    ctrl = torch.rand(32, 64, 64, 3, generator=g)
+    cond, uncond = torch.randn(1, 77, 768, generator=g) * 0.1, torch.randn(1, 77, 768, generator=g) * 0.1
+    seen = []
+    def prompt_fn(name):
+        seen.append(name)
+        return cond, uncond
+    views = ["front", "k0", "v3"]                       # v3 blends k0 and front (0.75 / 0.25)
+    out, idx = vcr.refine_rgb(rgb, ctrl, prompt_fn, views=views, generator=torch.Generator().manual_seed(1))
+    assert out.shape == (3, 64, 64, 3) and idx == [24, 20, 21] and seen == views
+    assert torch.isfinite(out).all() and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    assert vcr.ctl.state == "normal" and all(len(a.refine.stored_zt) == 0 for a in vcr.targets)
+    assert all(a.ip_scale == gd.cfg.ipa_faceid_scale for a in gd.unet.modules() if getattr(a, "ip", False))
+    out2, _ = vcr.refine_rgb(rgb, ctrl, prompt_fn, views=views, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(out, out2)                       # same seed, same result; the state machine resets cleanly
+
+
+def test_refine_tables_ddim_and_attention_state_machine():
+    import torch.nn.functional as F
+    from gaussianip_amd.guidance import refine as rf, sds
+    from gaussianip_amd.guidance.networks import Attention, init_for_benchmark
+    assert rf.refine_timesteps(8).tolist() == [143, 122, 102, 82, 61, 41, 20, 0]
+    assert len(rf.VIEW_IDX_ALL) == 32 and sorted(rf.VIEW_IDX_ALL) == list(range(32)) and rf.VIEW_NAME_ALL[8] == "v0"
+    assert rf.KEY_VIEW_NAME_PAIR["v0"] == ("left", "k0") and rf.KEY_VIEW_NAME_PAIR["v5"] == ("k0", "front")
+    assert rf.KEY_VIEW_NAME_PAIR["v17"] == ("k2", "back") and rf.KEY_VIEW_NAME_PAIR["v23"] == ("k3", "left")
+    assert rf.KEY_VIEW_WEIGHT_PAIR["v9"] == (0.75, 0.25) and rf.KEY_VIEW_WEIGHT_PAIR["v10"] == (0.5, 0.5) and rf.KEY_VIEW_WEIGHT_PAIR["v11"] == (0.25, 0.75)
+    # DDIM (eta 0): stepping from t with the true noise recovers the x0-consistent sample at t - 20
+    acp = sds.alphas_cumprod()
+    g = torch.Generator().manual_seed(0)
+    x0, eps = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    xt = sds.add_noise(x0, eps, torch.tensor([143]), acp)
+    prev = rf.ddim_step(xt, eps, 143, acp)
+    assert torch.allclose(prev, acp[123].sqrt() * x0 + (1 - acp[123]).sqrt() * eps, atol=1e-5)
+    last = rf.ddim_step(sds.add_noise(x0, eps, torch.tensor([0]), acp), eps, 0, acp)          # prev < 0 -> alphas[0]
+    assert torch.allclose(last, acp[0].sqrt() * x0 + (1 - acp[0]).sqrt() * eps, atol=1e-5)
+    # attention state machine against a direct restatement with torch SDPA
+    att = init_for_benchmark(Attention(64, None, 8), 3)
+    ctl = rf.RefineController(state="refine", total_denoise_step=2, lambda_self=0.55)
+    att.refine = rf.RefineAttentionState(ctl)
+    xs = {n: [torch.randn(2, 16, 64, generator=g) for _ in range(2)] for n in ("front", "left", "k0", "v1")}
+
+    def plain(q_src, kv_src):
+        q, k, v = att.to_q(q_src), att.to_k(kv_src), att.to_v(kv_src)
+        h = F.scaled_dot_product_attention(att._split(q), att._split(k), att._split(v)).transpose(1, 2).reshape(q.shape)
+        return h
+    outs = {}
+    for name in ("front", "left", "k0", "v1"):
+        ctl.cur_view_name = name
+        att.refine.stored_zt[name] = []
+        if name == "v1":
+            ctl.cur_key_view_name_pair, ctl.cur_key_view_weight_pair = rf.KEY_VIEW_NAME_PAIR[name], rf.KEY_VIEW_WEIGHT_PAIR[name]
+        outs[name] = [att(xs[name][s]) for s in range(2)]
+        assert att.refine.cur_denoise_step == 0                      # wraps after total_denoise_step calls
+    for s in range(2):
+        assert torch.allclose(outs["front"][s], att.to_out(plain(xs["front"][s], xs["front"][s])), atol=1e-5)
+        mutual = att.to_out(plain(xs["k0"][s], torch.cat([xs["k0"][s], xs["front"][s]], dim=1)))
+        assert torch.allclose(outs["k0"][s], mutual, atol=1e-5)
+        x = xs["v1"][s]
+        blend = 0.55 * plain(x, x) + 0.45 * (0.5 * plain(x, xs["left"][s]) + 0.5 * plain(x, xs["k0"][s]))
+        assert torch.allclose(outs["v1"][s], att.to_out(blend), atol=1e-5)
+    assert "v1" not in att.refine.stored_zt or att.refine.stored_zt["v1"] == []       # non-key views store nothing
+    ctl.state = "normal"
+    assert torch.allclose(att(xs["front"][0]), att.to_out(plain(xs["front"][0], xs["front"][0])), atol=1e-5)
