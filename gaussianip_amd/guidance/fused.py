@@ -84,9 +84,25 @@ class GroupNormAct(nn.GroupNorm):
         return F.silu(y) if self.act else y
 
 
+_DISABLED = False
+
+
+class disabled:
+    """Context manager: route everything through the plain PyTorch ops (used to COUNT algorithmic FLOPs with
+    torch.utils.flop_counter, which cannot see the ctypes-launched HIP kernels, and by A/B tests)."""
+
+    def __enter__(self):
+        global _DISABLED
+        self._old, _DISABLED = _DISABLED, True
+
+    def __exit__(self, *exc):
+        global _DISABLED
+        _DISABLED = self._old
+
+
 def fusable(x):
     """fp16 NHWC activations on a GPU: the layout / dtype the HIP kernels are written for."""
-    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.shape[1] % 8 == 0 and
+    return (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.shape[1] % 8 == 0 and
             x.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -117,7 +133,7 @@ def add_bias_residual(a, b, bias=None):
 def geglu(x):
     """diffusers GEGLU on the projected tensor: value, gate = x.chunk(2, -1); value * gelu(gate)."""
     D = x.shape[-1] // 2
-    if x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and D % 8 == 0 and not (x.requires_grad and torch.is_grad_enabled()):
+    if not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and D % 8 == 0 and not (x.requires_grad and torch.is_grad_enabled()):
         out = torch.empty(x.shape[:-1] + (D,), dtype=x.dtype, device=x.device)
         rc = _lib.nn_lib().gip_geglu(_p(x), _p(out), x.numel() // (2 * D), D,
                                      ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
@@ -208,7 +224,7 @@ def conv1x1(x, w, bias=None):
 
 def attention_supported(q, k, heads):
     D = q.shape[-1] // heads
-    return (q.is_cuda and q.dtype == torch.float16 and D in (40, 64) and q.shape[1] % 128 == 0 and k.shape[1] % 64 == 0 and
+    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64) and q.shape[1] % 128 == 0 and k.shape[1] % 64 == 0 and
             q.is_contiguous() and k.is_contiguous() and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
 
 

@@ -29,9 +29,9 @@ def test_refine_pass_hip_path_matches_torch_path(monkeypatch):
     assert out.shape == (4, H, W, 3) and idx == [24, 16, 20, 18] and torch.isfinite(out).all()
     assert 2048 in calls, "the mutual self-attention (own + front tokens = 2 x 1024 keys) did not reach the HIP kernel"
     # same pass through plain PyTorch ops
-    monkeypatch.setattr(fused, "attention_supported", lambda *a: False)
-    monkeypatch.setattr(fused, "fusable", lambda x: False)
-    monkeypatch.setattr(networks, "fusable", lambda x: False)
-    ref, _ = vcr.refine_rgb(rgb, ctrl, lambda n: (cond, uncond), views=views, generator=torch.Generator(device="cuda").manual_seed(3))
+    n_calls = len(calls)
+    with fused.disabled():
+        ref, _ = vcr.refine_rgb(rgb, ctrl, lambda n: (cond, uncond), views=views, generator=torch.Generator(device="cuda").manual_seed(3))
+    assert len(calls) == n_calls, "fused.disabled() must keep the pass on plain PyTorch ops"
     d = (out - ref).abs()
     assert float(d.mean()) < 4e-3 and float(d.max()) < 0.15, (float(d.mean()), float(d.max()))

@@ -125,7 +125,8 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     nflops = None
     if flops:
         from torch.utils.flop_counter import FlopCounterMode
-        with FlopCounterMode(display=False) as fc:
+        from gaussianip_amd.guidance import fused
+        with fused.disabled(), FlopCounterMode(display=False) as fc:     # count on the plain-PyTorch path: the counter cannot see HIP launches
             guidance.forward_unet(torch.cat([lat] * 3), torch.cat([ctrl] * 3), torch.cat([tt] * 3), emb, True)
         nflops = fc.get_total_flops()
     flops = nflops
