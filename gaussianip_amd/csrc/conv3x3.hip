@@ -39,7 +39,10 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-template <int BN, int STAGES>
+// TAPS = 9: the 3x3 convolution.  TAPS = 1: the same machinery as a plain GEMM out[m][co] = sum_k x[m][k] w[co][k]
+// (nn.Linear / 1x1 convolution on the NHWC token view; H = 1, W = M).  GEGLU (TAPS = 1 only): w has 2 * Cout rows
+// [value | gate]; a workgroup computes 64 value and the matching 64 gate columns and writes value * gelu(gate).
+template <int BN, int STAGES, int TAPS, bool GEGLU>
 __global__ void __launch_bounds__(CV_THREADS, STAGES == 2 ? 2 : 1)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
@@ -60,7 +63,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   const int mt = t / n_tiles, nt = t - mt * n_tiles;
   const long long M = (long long)N * H * W;
   const long long m0 = (long long)mt * CV_BM;
-  const int co0 = nt * BN;
+  const int co0 = nt * (GEGLU ? BN / 2 : BN);      // first OUTPUT channel of the tile
   const int HW = H * W;
 
   // ---- per-thread DMA descriptors (fixed over the K loop) ----
@@ -76,13 +79,17 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     unsigned mask = 0;
     unsigned off = 0;
     if (m < M) {
-      const int n = (int)(m / HW), rem = (int)(m - (long long)n * HW);
-      const int y = rem / W, xx = rem - y * W;
+      if constexpr (TAPS == 9) {
+        const int n = (int)(m / HW), rem = (int)(m - (long long)n * HW);
+        const int y = rem / W, xx = rem - y * W;
 #pragma unroll
-      for (int dy = 0; dy < 3; dy++)
+        for (int dy = 0; dy < 3; dy++)
 #pragma unroll
-        for (int dx = 0; dx < 3; dx++)
-          if ((unsigned)(y + dy - 1) < (unsigned)H && (unsigned)(xx + dx - 1) < (unsigned)W) mask |= 1u << (dy * 3 + dx);
+          for (int dx = 0; dx < 3; dx++)
+            if ((unsigned)(y + dy - 1) < (unsigned)H && (unsigned)(xx + dx - 1) < (unsigned)W) mask |= 1u << (dy * 3 + dx);
+      } else {
+        mask = 1u;
+      }
       off = (unsigned)(m * Cin + lchunk * 8) * 2u;
     }
     a_off[i] = off;
@@ -93,21 +100,29 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   for (int i = 0; i < B_ROUNDS; i++) {
     const int row = i * 32 + sub_row;
     const int lchunk = pchunk ^ ((row >> 1) & 7);
-    b_off[i] = co0 + row < Cout ? (unsigned)((co0 + row) * 9 * Cin + lchunk * 8) * 2u : CV_OOB;
+    int wrow = co0 + row;                                  // row of w this tile row holds
+    bool ok = wrow < Cout;
+    if constexpr (GEGLU) {                                 // per channel half: [32 value rows | 32 gate rows]
+      const int half = row / (BN / 2), j = row - half * (BN / 2);
+      const int ch = co0 + half * (BN / 4) + (j % (BN / 4));
+      ok = ch < Cout;
+      wrow = j < BN / 4 ? ch : Cout + ch;
+    }
+    b_off[i] = ok ? (unsigned)(wrow * TAPS * Cin + lchunk * 8) * 2u : CV_OOB;
   }
   // buffer resources: activations based one row + one pixel BEFORE x so that every tap displacement is >= 0
-  const unsigned shift = (unsigned)(W + 1) * Cin * 2u;
+  const unsigned shift = TAPS == 9 ? (unsigned)(W + 1) * Cin * 2u : 0u;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)x - shift), 0, (int)((unsigned)(M * Cin) * 2u + 2u * shift + (unsigned)Cin * 2u), CV_RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t wr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * 9u * Cin * 2u), CV_RSRC_FLAGS);
+      __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * (GEGLU ? 2u : 1u) * TAPS * Cin * 2u), CV_RSRC_FLAGS);
 
   const int cblocks = Cin / CV_BK;
-  const int KT = 9 * cblocks;
+  const int KT = TAPS * cblocks;
 
   auto stage = [&](int tap, int cb, int buf) {
     const int dy = tap / 3, dx = tap - dy * 3;
-    const unsigned tap_off = (unsigned)((dy * W + dx) * Cin + cb * CV_BK) * 2u;      // relative to the shifted base
+    const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * W + dx) * Cin : 0) + cb * CV_BK) * 2u;   // relative to the shifted base
     const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
     unsigned char* sa = smem + buf * STAGE + wave * 1024;
 #pragma unroll
@@ -182,59 +197,87 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   }
 
   // ---- epilogue: lane holds out[pixel = lane & 15][co = (lane >> 4) * 4 + 0..3] of each 16x16 tile ----
+  auto add4 = [](f32x4& v, const _Float16* p) {
+    const f16x4 b = *(const f16x4*)p;
+    v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+  };
 #pragma unroll
   for (int mi = 0; mi < 4; mi++) {
     const long long m = m0 + wm * 64 + mi * 16 + (lane & 15);
     if (m >= M) continue;
+    if constexpr (GEGLU) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++) {
-      const int co = co0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
-      if (co >= Cout) continue;
-      f32x4 v = acc[ni][mi];
-      if (bias) {
-        const f16x4 b = *(const f16x4*)(bias + co);
-        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+      for (int ni = 0; ni < NI / 2; ni++) {
+        const int co = co0 + wn * (BN / 4) + ni * 16 + (lane >> 4) * 4;
+        if (co >= Cout) continue;
+        f32x4 v = acc[ni][mi], g = acc[ni + NI / 2][mi];
+        if (bias) { add4(v, bias + co); add4(g, bias + Cout + co); }
+        f16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = (_Float16)(v[j] * (0.5f * g[j] * (1.f + erff(g[j] * 0.70710678118654752f))));
+        *(f16x4*)(out + m * Cout + co) = o;
       }
-      if (residual) {
-        const f16x4 rr = *(const f16x4*)(residual + m * Cout + co);
-        v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) {
+        const int co = co0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+        if (co >= Cout) continue;
+        f32x4 v = acc[ni][mi];
+        if (bias) add4(v, bias + co);
+        if (residual) add4(v, residual + m * Cout + co);
+        f16x4 o;
+        o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+        *(f16x4*)(out + m * Cout + co) = o;
       }
-      f16x4 o;
-      o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
-      *(f16x4*)(out + m * Cout + co) = o;
     }
   }
 }
 
-template <int BN, int STAGES>
+template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
                   int Cin, int Cout, hipStream_t s) {
   const long long M = (long long)N * H * W;
-  const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + BN - 1) / BN;
+  const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN, STAGES, TAPS, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
       return 3;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds, s, (const _Float16*)x,
-                     (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin,
-                     Cout, m_tiles, n_tiles);
+  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds, s,
+                     (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
+                     N, H, W, Cin, Cout, m_tiles, n_tiles);
   return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+static bool fits32(long long M, int Cin, int Cout, int wrows, int taps) {
+  return M * (long long)(Cin > Cout ? Cin : Cout) * 2 < (1ll << 31) && (long long)wrows * taps * Cin * 2 < (1ll << 31);
 }
 
 extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                     int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
   if (!x || !w || !out || N < 1 || H < 1 || W < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 4 || (Cout & 3)) return 1;
-  if ((long long)N * H * W * (long long)(Cin > Cout ? Cin : Cout) * 2 >= (1ll << 31)) return 1;   // 32-bit byte offsets
-  if ((long long)Cout * 9 * Cin * 2 >= (1ll << 31)) return 1;
+  if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;   // 32-bit byte offsets
   hipStream_t s = (hipStream_t)stream;
   static const int stages = [] { const char* e = getenv("GIP_CONV_STAGES"); return e && e[0] == '3' ? 3 : 2; }();
   const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
   if (stages == 3)
-    return wide ? launch<160, 3>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
-                : launch<128, 3>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
-  return wide ? launch<160, 2>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
-              : launch<128, 2>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+    return wide ? launch<160, 3, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
+                : launch<128, 3, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+  return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
+              : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+}
+
+extern "C" int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                              int32_t K, int32_t Nout, int32_t geglu, void* stream) {
+  if (!x || !w || !out || M < 1 || M >= (1ll << 31) || K < CV_BK || K % CV_BK || Nout < 4 || (Nout & 3)) return 1;
+  if (geglu && (residual || Nout % 64)) return 1;
+  if (!fits32(M, K, Nout, geglu ? 2 * Nout : Nout, 1)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (geglu) return launch<128, 2, 1, true>(x, w, bias, nullptr, out, 1, 1, (int)M, K, Nout, s);
+  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
+  return wide ? launch<160, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s)
+              : launch<128, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s);
 }

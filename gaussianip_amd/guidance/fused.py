@@ -238,3 +238,31 @@ def attention(q, k, v, heads):
     if rc != 0:
         raise RuntimeError("gip_attention_fwd_f16 failed with status %d" % rc)
     return o
+
+
+def linear_supported(x, w):
+    return (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and w.dtype == torch.float16 and x.is_contiguous() and
+            w.is_contiguous() and x.shape[-1] % 64 == 0 and x.shape[-1] >= 64 and
+            not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and
+            x.numel() * 2 < (1 << 31) and (x.numel() // x.shape[-1]) * w.shape[0] * 2 < (1 << 31))
+
+
+def linear(x, w, bias=None, residual=None, geglu_act=False):
+    """F.linear(x, w, bias) (+ residual) or, with geglu_act, GEGLU(F.linear(x, w, bias)) — one MFMA kernel with the bias /
+    residual / activation in its epilogue (csrc/conv3x3.hip, TAPS = 1).  Inference only (frozen denoiser under no_grad);
+    anything else goes to hipBLASLt through F.linear."""
+    n_out = w.shape[0] // 2 if geglu_act else w.shape[0]
+    if linear_supported(x, w) and n_out % (64 if geglu_act else 4) == 0 and (residual is None or residual.is_contiguous()):
+        M = x.numel() // x.shape[-1]
+        out = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
+        null = ctypes.c_void_p(None)
+        rc = _lib.nn_lib().gip_linear_f16(_p(x), _p(w), null if bias is None else _p(bias), null if residual is None else _p(residual),
+                                          _p(out), M, x.shape[-1], n_out, int(geglu_act),
+                                          ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_linear_f16 failed with status %d" % rc)
+        return out
+    y = F.linear(x, w, bias)
+    if geglu_act:
+        return geglu(y)
+    return y if residual is None else y + residual

@@ -49,6 +49,14 @@ int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
 int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 
+/* nn.Linear on the same MFMA machinery (TAPS = 1): out[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]) (+ residual[m][n]),
+ * x [M,K], w [Nout,K] (torch Linear weight), out [M,Nout] half, fp32 accumulation, K % 64 == 0.  geglu != 0: w has
+ * 2*Nout rows [value | gate], bias 2*Nout, out = (xWv + bv) * gelu(xWg + bg) — diffusers' GEGLU feed-forward input
+ * projection with the activation in the GEMM epilogue (the 2*Nout-wide intermediate never reaches HBM); Nout % 64 == 0.
+ * Replaces hipBLASLt + separate bias / residual / GEGLU kernels for the transformer blocks' memory-bound projections. */
+int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int32_t K,
+                   int32_t Nout, int32_t geglu, void* stream);
+
 /* Self-attention forward softmax(q k^T * scale) v (csrc/attention.hip): q, o [B, Nq, H*D], k, v [B, Nkv, H*D] half —
  * the projection outputs / to_out input, heads interleaved along the last axis (no head transposes).  fp32 softmax and
  * accumulation.  No mask, no gradient (the denoiser is frozen).  D in {40, 64}; Nq % 128 == 0; Nkv % 64 == 0.

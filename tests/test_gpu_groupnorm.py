@@ -110,3 +110,30 @@ def test_resblock_fused_equals_unfused():
         h = copy.deepcopy(ref).half().requires_grad_(False).to(memory_format=torch.channels_last)
         got = h(x.half().contiguous(memory_format=torch.channels_last), temb.half())
         assert float((got.float() - want).abs().max()) < 2e-2 * float(want.abs().max())
+
+
+def test_mfma_linear_residual_and_geglu_epilogues():
+    """gip_linear_f16 (conv3x3.hip, TAPS = 1) against fp32 F.linear: bias + residual epilogue, GEGLU epilogue, ragged M."""
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():
+        for M, K, N in ((1000, 320, 320), (4096, 640, 1280), (130, 64, 72)):
+            x = torch.randn(M, K, device="cuda", generator=g).half()
+            w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).half()
+            b = torch.randn(N, device="cuda", generator=g).half()
+            r = torch.randn(M, N, device="cuda", generator=g).half()
+            assert fused.linear_supported(x, w)
+            ref = F.linear(x.float(), w.float(), b.float()) + r.float()
+            got = fused.linear(x, w, b, r)
+            assert float((got.float() - ref).abs().max()) <= 1.5e-3 * float(ref.abs().max())
+            got2 = fused.linear(x.view(1, M, K), w)            # leading dims, no bias / residual
+            assert got2.shape == (1, M, N)
+            assert float((got2.float() - F.linear(x.float(), w.float())).abs().max()) <= 1.5e-3 * float(ref.abs().max())
+        for M, K, D in ((777, 320, 1280), (2048, 640, 2560)):
+            x = torch.randn(M, K, device="cuda", generator=g).half()
+            w = (torch.randn(2 * D, K, device="cuda", generator=g) / K ** 0.5).half()
+            b = torch.randn(2 * D, device="cuda", generator=g).half()
+            v, gate = F.linear(x.float(), w.float(), b.float()).chunk(2, -1)
+            ref = v * F.gelu(gate)
+            got = fused.linear(x, w, b, None, True)
+            assert got.shape == (M, D) and float((got.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
