@@ -266,3 +266,34 @@ def linear(x, w, bias=None, residual=None, geglu_act=False):
     if geglu_act:
         return geglu(y)
     return y if residual is None else y + residual
+
+
+class _DownsampleAsym(torch.autograd.Function):
+    """VAE Downsample2D: F.pad(x, (0, 1, 0, 1)) -> 3x3 / stride 2 / pad 0 convolution.  Forward stays on MIOpen; the
+    DATA GRADIENT is the stride-1 MFMA convolution of the zero-dilated upstream gradient with the flipped-transposed
+    weight: dx[i, j] = sum_{ky, kx} dy[(i - ky) / 2, (j - kx) / 2] w[:, :, ky, kx] over even (i - ky), (j - kx), which is
+    a pad-1 3x3 correlation over U[2y + 1, 2x + 1] = dy[y, x] (zeros elsewhere).  4x the minimal FLOPs, but on the
+    128-channel 512^2 level it replaces a 54 TFLOP/s library kernel (1.44 ms) by ~0.5 ms."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(w)
+        ctx.x_shape = tuple(x.shape)
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        N, C, H, W = ctx.x_shape
+        up = torch.empty((N, w.shape[0], H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
+        up[:, :, 1::2, 1::2] = dy
+        return _conv_call(up, _transposed_weight(w), w.shape[1]), None, None
+
+
+def downsample_asym(x, w, bias):
+    """Differentiable VAE downsample.  The dilated-gradient route is used where it wins (measured: the 128-channel
+    level; at 256 / 512 channels the library's backward-data kernels are as fast)."""
+    if (fusable(x) and x.requires_grad and torch.is_grad_enabled() and not w.requires_grad and w.shape[0] % 64 == 0 and
+            w.shape[0] <= 128 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and w.is_contiguous(memory_format=torch.channels_last)):
+        return _DownsampleAsym.apply(x, w, bias)
+    return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)

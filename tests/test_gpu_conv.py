@@ -53,3 +53,22 @@ def test_small_problems_stay_on_miopen():
     assert fused._conv_tiles(12, 8, 8, 1280) < fused._MIN_CONV_TILES
     out = fused.conv3x3(x, w)
     assert torch.allclose(out.float(), F.conv2d(x, w, padding=1).float(), atol=2e-2)
+
+
+def test_vae_downsample_gradient_through_the_dilated_convolution():
+    """Data gradient of pad(0,1,0,1) + 3x3/stride-2 via the stride-1 MFMA convolution of the zero-dilated gradient."""
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(2)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(2, 128, 64, 48, device="cuda", generator=g).half().contiguous(**cl).requires_grad_(True)
+    w = (torch.randn(128, 128, 3, 3, device="cuda", generator=g) / 34.0).half().contiguous(**cl)
+    b = torch.randn(128, device="cuda", generator=g).half()
+    y = fused.downsample_asym(x, w, b)
+    assert y.grad_fn is not None and "DownsampleAsym" in type(y.grad_fn).__name__
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+    assert float((y.float() - yr).abs().max()) <= 2e-3 * float(yr.abs().max())
+    dy = torch.randn(y.shape, device="cuda", generator=g).half().contiguous(**cl)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    (dxr,) = torch.autograd.grad(yr, xr, dy.float())
+    assert float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())
