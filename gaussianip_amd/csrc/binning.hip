@@ -19,7 +19,7 @@
 #include "gip_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// scan: one workgroup of 1024 threads, each thread owns a contiguous chunk
+// scan: three workgroups of 1024 threads (one per independent job), each thread owns a contiguous chunk
 // ------------------------------------------------------------------------------------------------
 #ifndef SCAN_SKIP
 #define SCAN_SKIP 0
@@ -121,6 +121,19 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
   // out of LDS instead of issuing serial dependent global loads)
   extern __shared__ uint32_t s_cnt[];
   const int n = kp.V * kp.T;
+  const int role = blockIdx.x;
+  if (role == 2) {
+    const int nb = kp.V * kp.nblk;
+    const int ch = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int l2 = threadIdx.x * ch, h2 = min(nb, l2 + ch);
+    U3 s2 = {0, 0, 0};
+    for (int i = l2; i < h2; i++) s2.a += block_sums[i];
+    U3 t2;
+    U3 r2 = block_excl_scan3(s2, s_wave, &t2);
+    for (int i = l2; i < h2; i++) { block_offset[i] = r2.a; r2.a += block_sums[i]; }
+    if (threadIdx.x == 0) block_offset[nb] = t2.a;
+    return;
+  }
   const bool in_lds = n <= SCAN_LDS_TILES;
   if (in_lds) {
     // 8 independent load pairs in flight per thread (a plain loop would wait for each pair in turn)
@@ -142,6 +155,21 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
   }
   // (beyond SCAN_LDS_TILES tiles the two partial counts are summed on the fly from global memory)
   auto cnt_at = [&](int i) -> uint32_t { return in_lds ? s_cnt[i] : tile_count[i] + tile_count_b[i]; };
+  // Three independent jobs, one workgroup each (blockIdx.x = role), so that their latency chains overlap:
+  //   role 0: tile prefixes (ranges / segments / checkpoint slots) + totals in the header
+  //   role 1: longest-first launch order + class boundaries in the header
+  //   role 2: per-workgroup tiles_touched sums -> instance offsets
+  if (role == 1) {
+#if !(SCAN_SKIP & 1)
+    heavy_first_order(in_lds ? s_cnt : nullptr, tile_count, tile_count_b, tile_order, n, s_bucket, s_class);
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      header->class_end[0] = s_class[0]; header->class_end[1] = s_class[1];
+      header->class_end[2] = s_class[2]; header->class_end[3] = s_class[3];
+    }
+    return;
+  }
   const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
   const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
   U3 sum = {0, 0, 0};
@@ -183,23 +211,6 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
   __syncthreads();
   uint32_t max_tile = 0;
   for (int w = 0; w < SCAN_WAVES; w++) max_tile = s_wave[0][w] > max_tile ? s_wave[0][w] : max_tile;
-  __syncthreads();
-  // ---- Gaussians: per-workgroup sums of tiles_touched -> instance offsets ----
-  {
-    const int nb = kp.V * kp.nblk;
-    const int ch = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int l2 = threadIdx.x * ch, h2 = min(nb, l2 + ch);
-    U3 s2 = {0, 0, 0};
-    for (int i = l2; i < h2; i++) s2.a += block_sums[i];
-    U3 t2;
-    U3 r2 = block_excl_scan3(s2, s_wave, &t2);
-    for (int i = l2; i < h2; i++) { block_offset[i] = r2.a; r2.a += block_sums[i]; }
-    if (threadIdx.x == 0) block_offset[nb] = t2.a;
-  }
-#if !(SCAN_SKIP & 1)
-  heavy_first_order(in_lds ? s_cnt : nullptr, tile_count, tile_count_b, tile_order, n, s_bucket, s_class);
-#endif
-  __syncthreads();
   if (threadIdx.x == 0) {
     header->abi_version = GIP_ABI_VERSION;
     header->num_rendered = total.a;
@@ -207,8 +218,6 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
     header->max_tile_count = max_tile;
     header->num_segments = total.b;
     header->num_checkpoints = total.c;
-    header->class_end[0] = s_class[0]; header->class_end[1] = s_class[1];
-    header->class_end[2] = s_class[2]; header->class_end[3] = s_class[3];
   }
 }
 
@@ -219,7 +228,7 @@ void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) 
   static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(gip_scan_kernel),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_TILES * 4);
   (void)attr_once;
-  hipLaunchKernelGGL(gip_scan_kernel, dim3(1), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
+  hipLaunchKernelGGL(gip_scan_kernel, dim3(3), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
                      st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header);
 }
 
