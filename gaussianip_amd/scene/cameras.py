@@ -4,7 +4,7 @@ Reference: gaussiansplatting/scene/cameras.py:17-51 (Camera), :54-65 (MiniCam). 
 Conventions reproduced: FoVx from the vertical focal length and the image WIDTH (:20); world-to-camera =
 inverse(c2w) with rows 1-2 of the rotation block and the whole translation negated (threestudio -> 3DGS axes, :23-27);
 matrices stored transposed (row-vector convention), full_proj = V^T-stored @ P^T-stored (:48-50); znear 0.01,
-zfar 100 (:42-43).  Tensors live on the device of `c2w` (the reference forces "cuda").
+zfar 100 (:42-43).  Tensors live on `data_device` (default: the device of `c2w`; the reference forces "cuda").
 """
 import torch
 
@@ -26,10 +26,16 @@ class Camera(torch.nn.Module):
         w2c = torch.linalg.inv(c2w.detach().to(torch.float32)).clone()
         w2c[1:3, :3] *= -1
         w2c[:3, 3] *= -1
-        self.world_view_transform = w2c.t().contiguous().float().to(dev)
-        self.projection_matrix = getProjectionMatrix(self.znear, self.zfar, self.FoVx, self.FoVy).t().float().to(dev)
-        self.full_proj_transform = (self.world_view_transform @ self.projection_matrix).float()
-        self.camera_center = torch.linalg.inv(self.world_view_transform)[3, :3].float()
+        # all 4x4 algebra runs where c2w lives and only the results move to `data_device`: with host-side camera
+        # parameters (the data module's) a step then issues no device-side inverse and no host synchronisation
+        wvt = w2c.t().contiguous().float()
+        proj = getProjectionMatrix(self.znear, self.zfar, self.FoVx, self.FoVy).t().float().to(wvt.device)
+        full = (wvt @ proj).float()
+        center = torch.linalg.inv(wvt)[3, :3].float()
+        self.world_view_transform = wvt.to(dev, non_blocking=True)
+        self.projection_matrix = proj.to(dev, non_blocking=True)
+        self.full_proj_transform = full.to(dev, non_blocking=True)
+        self.camera_center = center.to(dev, non_blocking=True)
 
 
 class MiniCam:

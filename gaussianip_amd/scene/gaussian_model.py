@@ -419,5 +419,8 @@ class GaussianModel:
             torch.cuda.empty_cache()
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        """gaussian_model.py:420-422.  Written with a multiplicative mask instead of boolean-mask indexing: the same
+        values (x + 0 == x), but no nonzero() and therefore no host synchronisation inside the training step."""
+        m = update_filter.to(self.xyz_gradient_accum.dtype).unsqueeze(-1)
+        self.xyz_gradient_accum += torch.norm(viewspace_point_tensor[:, :2], dim=-1, keepdim=True) * m
+        self.denom += m

@@ -57,10 +57,12 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     def step(i):
         gm.update_learning_rate(i)
         rng = cam_rng
-        el = torch.tensor(rng.uniform(-30, 30, B), dtype=torch.float32, device=dev)
+        el_h = rng.uniform(-30, 30, B).astype(np.float32)      # camera parameters live on the host (data module), like the reference
         az0 = rng.uniform(-180, 180)
-        az = torch.tensor([az0 + 90.0 * k for k in range(B)], dtype=torch.float32, device=dev)
-        cams = [Camera(c2w=orbit_c2w(float(el[k]), float(az[k]), rng.uniform(1.3, 1.7)).to(dev), FoVy=math.radians(rng.uniform(40, 70)),
+        az_h = np.array([az0 + 90.0 * k for k in range(B)], np.float32)
+        el = torch.from_numpy(el_h).to(dev, non_blocking=True)
+        az = torch.from_numpy(az_h).to(dev, non_blocking=True)
+        cams = [Camera(c2w=orbit_c2w(float(el_h[k]), float(az_h[k]), rng.uniform(1.3, 1.7)), data_device=dev, FoVy=math.radians(rng.uniform(40, 70)),
                        height=H, width=W) for k in range(B)]
         pkg = render_views(cams, gm, pipe, bg)
         rgb = pkg["render"].permute(0, 2, 3, 1)
