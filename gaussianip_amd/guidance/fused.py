@@ -297,3 +297,36 @@ def downsample_asym(x, w, bias):
             w.shape[0] <= 128 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and w.is_contiguous(memory_format=torch.channels_last)):
         return _DownsampleAsym.apply(x, w, bias)
     return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
+
+
+class _ConvFewInputChannels(torch.autograd.Function):
+    """3x3 / pad 1 convolution whose INPUT has very few channels (the VAE's conv_in: 3 -> 128).  Forward stays on
+    MIOpen; the data gradient (128 -> 3 channels over the full-resolution image, the gradient that flows back into the
+    rasterizer) is the MFMA convolution with the flipped-transposed weight zero-padded to 4 output channels — the
+    library's backward-data kernel for this shape runs at ~5 GFLOP/s-per-CU rates (1.4 ms for 7 GFLOP)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(w)
+        return F.conv2d(x, w, bias, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        key = ("few", w.data_ptr(), w._version, tuple(w.shape))
+        wt = _wt_cache.get(key)
+        if wt is None:
+            wt4 = torch.zeros((4, w.shape[0], 3, 3), dtype=w.dtype, device=w.device)
+            wt4[:w.shape[1]] = w.detach().flip(2, 3).transpose(0, 1)
+            wt = _wt_cache[key] = wt4.contiguous(memory_format=torch.channels_last)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        return _conv_call(dy, wt, 4)[:, :w.shape[1]], None, None
+
+
+def conv3x3_few_inputs(x, w, bias):
+    if (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.requires_grad and torch.is_grad_enabled() and
+            not w.requires_grad and w.shape[1] <= 4 and w.shape[0] % 64 == 0 and
+            _conv_tiles(x.shape[0], x.shape[2], x.shape[3], 4) >= _MIN_CONV_TILES and
+            x.shape[0] * x.shape[2] * x.shape[3] * w.shape[0] * 2 < (1 << 31)):
+        return _ConvFewInputChannels.apply(x, w, bias)
+    return F.conv2d(x, w, bias, padding=1)

@@ -426,7 +426,7 @@ class VAEEncoder(nn.Module):
         self.quant_conv = nn.Conv2d(8, 8, 1)
 
     def moments(self, x):
-        h = self.conv_in(x)
+        h = fused.conv3x3_few_inputs(x, self.conv_in.weight, self.conv_in.bias)
         for i in range(4):
             h = self.res[2 * i + 1](self.res[2 * i](h))
             h = self.down[i](h)

@@ -72,3 +72,18 @@ def test_vae_downsample_gradient_through_the_dilated_convolution():
     (dx,) = torch.autograd.grad(y, x, dy)
     (dxr,) = torch.autograd.grad(yr, xr, dy.float())
     assert float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())
+
+
+def test_conv_in_gradient_through_the_padded_mfma_convolution():
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 160, 96, device="cuda", generator=g).half().contiguous(**cl).requires_grad_(True)
+    w = (torch.randn(128, 3, 3, 3, device="cuda", generator=g) / 5.0).half().contiguous(**cl)
+    b = torch.randn(128, device="cuda", generator=g).half()
+    y = fused.conv3x3_few_inputs(x, w, b)
+    assert "ConvFewInputChannels" in type(y.grad_fn).__name__
+    dy = torch.randn(y.shape, device="cuda", generator=g).half().contiguous(**cl)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    dxr = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), padding=1)
+    assert dx.shape == x.shape and float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())
