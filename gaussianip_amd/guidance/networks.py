@@ -187,6 +187,11 @@ class Attention(nn.Module):
             q, k, v = q + self.lora_q(x), k + self.lora_k(ctx), v + self.lora_v(ctx)
         if ip_ctx is None and fused.attention_supported(q, k, self.heads):
             return self._out(fused.attention(q, k, v, self.heads), residual)     # [B, N, C] in and out: no head transposes
+        if self.heads == 1 and ip_ctx is None and q.is_cuda and q.dtype == torch.float16 and q.shape[-1] >= 256:
+            # single wide head (the VAE's 512-channel mid attention): three dense GEMMs through hipBLASLt beat the
+            # flash kernels at head dim 512 (forward and backward; measured in tools/exp_ab_vae.py)
+            p = torch.softmax(torch.baddbmm(q.new_zeros(()), q, k.transpose(1, 2), beta=0, alpha=q.shape[-1] ** -0.5), dim=-1)
+            return self._out(torch.bmm(p, v), residual)
         q = self._split(q)
         h = F.scaled_dot_product_attention(q, self._split(k), self._split(v))
         if ip_ctx is not None:

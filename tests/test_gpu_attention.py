@@ -38,3 +38,25 @@ def test_attention_module_uses_the_hip_kernel(monkeypatch):
         q, k, v = att.to_q(x), att.to_k(x), att.to_v(x)
         ref = att.to_out(F.scaled_dot_product_attention(att._split(q), att._split(k), att._split(v)).transpose(1, 2).reshape(2, 1024, 320))
     assert calls and float((got.float() - ref.float()).abs().max()) < 5e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_single_wide_head_attention_as_dense_gemms():
+    """The VAE mid-block attention (one head of 512 channels) runs as softmax(QK^T)V through three GEMMs; forward and
+    input gradient against an fp32 SDPA reference."""
+    from gaussianip_amd.guidance import networks as nw
+    att = nw.init_for_benchmark(nw.Attention(512, None, heads=1), 1)
+    att.to_q, att.to_k, att.to_v = torch.nn.Linear(512, 512), torch.nn.Linear(512, 512), torch.nn.Linear(512, 512)
+    att = nw.init_for_benchmark(att, 1).cuda()
+    ref = att.float()
+    x = torch.randn(2, 1024, 512, device="cuda")
+    xr = x.clone().requires_grad_(True)
+    q, k, v = ref.to_q(xr), ref.to_k(xr), ref.to_v(xr)
+    want = ref.to_out(F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0])
+    (gw,) = torch.autograd.grad(want, xr, torch.ones_like(want))
+    import copy
+    h = copy.deepcopy(ref).half().requires_grad_(False)
+    xh = x.half().requires_grad_(True)
+    got = h(xh)
+    (gg,) = torch.autograd.grad(got, xh, torch.ones_like(got))
+    assert float((got.float() - want).abs().max()) < 1e-2 * max(1.0, float(want.abs().max()))
+    assert float((gg.float() - gw).abs().max()) < 2e-2 * max(1.0, float(gw.abs().max()))
