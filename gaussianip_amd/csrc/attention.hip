@@ -39,10 +39,11 @@ union Frag8 {
   uint4 u;
 };
 
-template <int D>
+template <int D, bool TWO>
 __global__ void __launch_bounds__(256, 2)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
-                _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */) {
+                _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
+                const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2) {
   static_assert(D % 8 == 0 && D <= 64, "head dim");
   constexpr int NS = (D + 15) / 16;      // k-steps of the S^T product
   constexpr int ND = (D + 31) / 32;      // 32-row tiles of O^T
@@ -71,25 +72,23 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   for (int i = tid * 16; i < 2 * 2 * AT_TILE; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
 
   // staging descriptors: every thread moves two chunks of K and of V per block; the tail indices wrap around (a few
-  // chunks are moved twice with identical data) so that no load or LDS store is predicated
+  // chunks are moved twice with identical data) so that no load or LDS store is predicated; rows past the end of a
+  // ragged key set are clamped to its last row (they are masked to -inf before the softmax)
   static_assert(PER == 2, "two staging chunks per thread");
   int idx0 = tid, idx1 = tid + 256;
   if (idx1 >= AT_BKV * CH) idx1 -= AT_BKV * CH;
   const int row0 = idx0 / CH, ch0 = idx0 - row0 * CH, row1 = idx1 / CH, ch1 = idx1 - row1 * CH;
-  const int g0 = row0 * C + ch0 * 8, g1 = row1 * C + ch1 * 8;
   const int kl0 = row0 * AT_ROW + ((ch0 ^ ((row0 >> 1) & 7)) << 4), kl1 = row1 * AT_ROW + ((ch1 ^ ((row1 >> 1) & 7)) << 4);
   const int vl0 = AT_TILE + row0 * AT_ROW + ((ch0 ^ (((row0 >> 1) & 1) << 2)) << 4);
   const int vl1 = AT_TILE + row1 * AT_ROW + ((ch1 ^ (((row1 >> 1) & 1) << 2)) << 4);
-  const _Float16* kp = k + (size_t)b * Nkv * C + h * D;
-  const _Float16* vp = v + (size_t)b * Nkv * C + h * D;
   uint4 kr0, kr1, vr0, vr1;
-#define AT_FETCH(blk_)                                                     \
-  {                                                                        \
-    const size_t base_ = (size_t)(blk_) * AT_BKV * C;                      \
-    kr0 = *(const uint4*)(kp + base_ + g0);                                \
-    kr1 = *(const uint4*)(kp + base_ + g1);                                \
-    vr0 = *(const uint4*)(vp + base_ + g0);                                \
-    vr1 = *(const uint4*)(vp + base_ + g1);                                \
+#define AT_FETCH(blk_)                                                                   \
+  {                                                                                      \
+    const int ra_ = min((blk_) * AT_BKV + row0, n_keys - 1), rb_ = min((blk_) * AT_BKV + row1, n_keys - 1);  \
+    kr0 = *(const uint4*)(kp + (size_t)ra_ * C + ch0 * 8);                               \
+    kr1 = *(const uint4*)(kp + (size_t)rb_ * C + ch1 * 8);                               \
+    vr0 = *(const uint4*)(vp + (size_t)ra_ * C + ch0 * 8);                               \
+    vr1 = *(const uint4*)(vp + (size_t)rb_ * C + ch1 * 8);                               \
   }
 #define AT_DEPOSIT(stage_)                                                 \
   {                                                                        \
@@ -100,108 +99,142 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     *(uint4*)(st_ + vl1) = vr1;                                            \
   }
 
-  f32x16 O[ND];
-#pragma unroll
-  for (int dt = 0; dt < ND; dt++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) O[dt][i] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
   // fragment addressing
   const int k_row_off = r * AT_ROW, k_swz = (r >> 1) & 7;
   const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, half16 = (lane >> 4) & 1;
 
-  AT_FETCH(0);
-  __syncthreads();        // clears done
-  AT_DEPOSIT(0);
-  __syncthreads();
-  const int NB = Nkv / AT_BKV;
-  for (int blk = 0; blk < NB; blk++) {
-    const int stage = blk & 1;
-    const unsigned char* sk = smem + stage * 2 * AT_TILE;
-    const int nblk = blk + 1 < NB ? blk + 1 : blk;      // the last iteration re-fetches its own block (never deposited)
-    AT_FETCH(nblk);
+  f32x16 O[ND], Oacc[TWO ? ND : 1];
+  if constexpr (TWO) {
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) Oacc[dt][i] = 0.f;
+  }
+  _Float16* op = o + ((size_t)b * Nq + q0 + r) * C + h * D;
 
-    // ---- S^T = K Q^T for the two 32-key tiles ----
-    f32x16 S[2];
+  for (int seg = 0; seg < (TWO ? 2 : 1); seg++) {
+    const int n_keys = seg == 0 ? Nkv : Nkv2;
+    const _Float16* kp = (seg == 0 ? k : k2) + (size_t)b * n_keys * C + h * D;
+    const _Float16* vp = (seg == 0 ? v : v2) + (size_t)b * n_keys * C + h * D;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int dt = 0; dt < ND; dt++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) S[t][i] = 0.f;
+      for (int i = 0; i < 16; i++) O[dt][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    AT_FETCH(0);
+    __syncthreads();        // the clear (first segment) / every read of the previous segment's stages is done
+    AT_DEPOSIT(0);
+    __syncthreads();
+    const int NB = (n_keys + AT_BKV - 1) / AT_BKV;
+    for (int blk = 0; blk < NB; blk++) {
+      const int stage = blk & 1;
+      const unsigned char* sk = smem + stage * 2 * AT_TILE;
+      const int nblk = blk + 1 < NB ? blk + 1 : blk;      // the last iteration re-fetches its own block (never deposited)
+      AT_FETCH(nblk);
+
+      // ---- S^T = K Q^T for the two 32-key tiles ----
+      f32x16 S[2];
 #pragma unroll
-      for (int s = 0; s < NS; s++) {
-        const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
-        S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+      for (int t = 0; t < 2; t++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) S[t][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+          const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
+          S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+        }
       }
-    }
 
-    // ---- V^T fragments: issued now, they land while the softmax runs ----
-    const unsigned char* sv = sk + AT_TILE;
-    Frag8 vt[ND][2][2];
+      // ---- V^T fragments: issued now, they land while the softmax runs ----
+      const unsigned char* sv = sk + AT_TILE;
+      Frag8 vt[ND][2][2];
 #pragma unroll
-    for (int dt = 0; dt < ND; dt++) {
-      const int col = dt * 32 + 16 * half16 + 4 * p4;          // first feature this lane addresses
-      const int lch = col >> 3, sub = (p4 & 1) * 8;
+      for (int dt = 0; dt < ND; dt++) {
+        const int col = dt * 32 + 16 * half16 + 4 * p4;          // first feature this lane addresses
+        const int lch = col >> 3, sub = (p4 & 1) * 8;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++) {
+            const int row = t * 32 + 16 * s2 + 4 * hh + q4;
+            const int off = row * AT_ROW + ((lch ^ (((row >> 1) & 1) << 2)) << 4) + sub;
+            vt[dt][t][s2].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off));
+            vt[dt][t][s2].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off + 8 * AT_ROW));
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- ragged tail: keys past the end never win the softmax (register i of tile t = key 32 t + (i&3) + 8 (i>>2) + 4 hh)
+      if (blk * AT_BKV + AT_BKV > n_keys) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            if (blk * AT_BKV + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= n_keys) S[t][i] = -INFINITY;
+      }
+
+      // ---- online softmax on the lane's query column ----
+      float mloc = S[0][0];
 #pragma unroll
       for (int t = 0; t < 2; t++)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-          const int row = t * 32 + 16 * s2 + 4 * hh + q4;
-          const int off = row * AT_ROW + ((lch ^ (((row >> 1) & 1) << 2)) << 4) + sub;
-          vt[dt][t][s2].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off));
-          vt[dt][t][s2].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off + 8 * AT_ROW));
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- online softmax on the lane's query column ----
-    float mloc = S[0][0];
+        for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, S[t][i]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const bool raise = (mloc - m_run) * c > AT_DEFER;     // true on the first block (m_run = -inf)
+      if (__any(raise)) {
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        l_run *= alpha;
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+        for (int dt = 0; dt < ND; dt++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, S[t][i]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const bool raise = (mloc - m_run) * c > AT_DEFER;     // true on the first block (m_run = -inf)
-    if (__any(raise)) {
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < ND; dt++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) O[dt][i] *= alpha;
-      m_run = m_new;
-    }
-    const float mc = m_run * c;
-    Frag8 P[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
-          l_run += p;
-          P[t][s2].v[j] = (_Float16)p;
-        }
-
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int dt = 0; dt < ND; dt++)
+          for (int i = 0; i < 16; i++) O[dt][i] *= alpha;
+        m_run = m_new;
+      }
+      const float mc = m_run * c;
+      Frag8 P[2][2];
 #pragma unroll
       for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++)
-          O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
+            l_run += p;
+            P[t][s2].v[j] = (_Float16)p;
+          }
 
-    if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
-    __syncthreads();
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++)
+            O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
+
+      if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
+      __syncthreads();
+    }
+
+    // ---- normalise this segment ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = (seg == 0 ? 1.f : w2) / l_tot;
+    if constexpr (TWO) {
+#pragma unroll
+      for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) Oacc[dt][i] += O[dt][i] * inv;
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) O[dt][i] *= inv;
+    }
   }
 
-  // ---- normalise and store: lane holds O^T[d = 32 dt + 8 i + 4 hh + 0..3][query r] in registers 4i..4i+3 ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  _Float16* op = o + ((size_t)b * Nq + q0 + r) * C + h * D;
+  // ---- store: lane holds O^T[d = 32 dt + 8 i + 4 hh + 0..3][query r] in registers 4i..4i+3 ----
 #pragma unroll
   for (int dt = 0; dt < ND; dt++)
 #pragma unroll
@@ -209,30 +242,36 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
       const int d = dt * 32 + 8 * i + 4 * hh;
       if (d < D) {
         f16x4 w;
-        w[0] = (_Float16)(O[dt][4 * i] * inv); w[1] = (_Float16)(O[dt][4 * i + 1] * inv);
-        w[2] = (_Float16)(O[dt][4 * i + 2] * inv); w[3] = (_Float16)(O[dt][4 * i + 3] * inv);
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = (_Float16)(TWO ? Oacc[dt][4 * i + j] : O[dt][4 * i + j]);
         *(f16x4*)(op + d) = w;
       }
     }
 }
 
+template <int D>
+static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
+                        float c, const void* k2, const void* v2, int Nkv2, float w2) {
+  if (k2)
+    hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f);
+}
+
 extern "C" int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
-                                     int32_t Nq, int32_t Nkv, int32_t D, float scale, void* stream) {
-  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < AT_BQ || Nq % AT_BQ || Nkv < AT_BKV || Nkv % AT_BKV) return 1;
+                                     int32_t Nq, int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2,
+                                     int32_t Nkv2, float weight2, void* stream) {
+  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < AT_BQ || Nq % AT_BQ || Nkv < 1) return 1;
+  if ((k2 != nullptr) != (v2 != nullptr) || (k2 && Nkv2 < 1)) return 1;
   const float c = scale * 1.4426950408889634f;
-  const dim3 grid(Nq / AT_BQ, B * H), block(256);
+  const dim3 grid(Nq / AT_BQ, B * H);
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 40:
-      hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, block, 0, s, (const _Float16*)q, (const _Float16*)k,
-                         (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c);
-      break;
-    case 64:
-      hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, s, (const _Float16*)q, (const _Float16*)k,
-                         (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c);
-      break;
-    default:
-      return 1;
+    case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
+    case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
+    default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -224,17 +224,23 @@ def conv1x1(x, w, bias=None):
 
 def attention_supported(q, k, heads):
     D = q.shape[-1] // heads
-    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64) and q.shape[1] % 128 == 0 and k.shape[1] % 64 == 0 and
-            q.is_contiguous() and k.is_contiguous() and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
+    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64) and q.shape[1] % 128 == 0 and
+            k.shape[1] >= 1 and q.is_contiguous() and k.is_contiguous() and
+            not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
 
 
-def attention(q, k, v, heads):
-    """softmax(q k^T / sqrt(D)) v on [B, N, heads * D] projections; returns [B, Nq, heads * D] (csrc/attention.hip)."""
+def attention(q, k, v, heads, k2=None, v2=None, weight2=1.0):
+    """softmax(q k^T / sqrt(D)) v [+ weight2 * softmax(q k2^T / sqrt(D)) v2] on [B, N, heads * D] projections; returns
+    [B, Nq, heads * D] (csrc/attention.hip).  Key counts are arbitrary (77 text tokens, 4 image tokens, 2N mutual keys)."""
     B, Nq, C = q.shape
     D = C // heads
     o = torch.empty_like(q)
+    null = ctypes.c_void_p(None)
+    two = k2 is not None
     rc = _lib.nn_lib().gip_attention_fwd_f16(_p(q), _p(k), _p(v.contiguous()), _p(o), B, heads, Nq, k.shape[1], D,
-                                             float(D) ** -0.5, ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+                                             float(D) ** -0.5, _p(k2.contiguous()) if two else null,
+                                             _p(v2.contiguous()) if two else null, k2.shape[1] if two else 0, float(weight2),
+                                             ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
     if rc != 0:
         raise RuntimeError("gip_attention_fwd_f16 failed with status %d" % rc)
     return o

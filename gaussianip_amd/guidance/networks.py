@@ -185,8 +185,11 @@ class Attention(nn.Module):
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if self.lora_rank:
             q, k, v = q + self.lora_q(x), k + self.lora_k(ctx), v + self.lora_v(ctx)
-        if ip_ctx is None and fused.attention_supported(q, k, self.heads):
-            return self._out(fused.attention(q, k, v, self.heads), residual)     # [B, N, C] in and out: no head transposes
+        if fused.attention_supported(q, k, self.heads):       # [B, N, C] in and out: no head transposes
+            if ip_ctx is None:
+                return self._out(fused.attention(q, k, v, self.heads), residual)
+            # decoupled cross-attention: text and image-prompt keys in one pass over the queries
+            return self._out(fused.attention(q, k, v, self.heads, self.to_k_ip(ip_ctx), self.to_v_ip(ip_ctx), self.ip_scale), residual)
         if self.heads == 1 and ip_ctx is None and q.is_cuda and q.dtype == torch.float16 and q.shape[-1] >= 256:
             # single wide head (the VAE's 512-channel mid attention): three dense GEMMs through hipBLASLt beat the
             # flash kernels at head dim 512 (forward and backward; measured in tools/exp_ab_vae.py)

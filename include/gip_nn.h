@@ -57,13 +57,16 @@ int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const v
 int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int32_t K,
                    int32_t Nout, int32_t geglu, void* stream);
 
-/* Self-attention forward softmax(q k^T * scale) v (csrc/attention.hip): q, o [B, Nq, H*D], k, v [B, Nkv, H*D] half —
- * the projection outputs / to_out input, heads interleaved along the last axis (no head transposes).  fp32 softmax and
- * accumulation.  No mask, no gradient (the denoiser is frozen).  D in {40, 64}; Nq % 128 == 0; Nkv % 64 == 0.
- * Replaces torch SDPA inside LoRAAttnProcessor2_0 (attention_processor_faceid.py:300-318) for the U-Net / ControlNet
- * self-attention at the 64x64 latent level, which holds ~90 % of the denoiser's attention FLOPs. */
+/* Attention forward o = softmax(q k^T * scale) v  [+ weight2 * softmax(q k2^T * scale) v2]  (csrc/attention.hip):
+ * q, o [B, Nq, H*D], k, v [B, Nkv, H*D], k2, v2 [B, Nkv2, H*D] half — the projection outputs / to_out input, heads
+ * interleaved along the last axis (no head transposes).  fp32 softmax and accumulation.  No mask, no gradient (the
+ * denoiser is frozen).  D in {40, 64}; Nq % 128 == 0; any Nkv, Nkv2 >= 1 (ragged tails are masked).  k2 = v2 = NULL:
+ * one key set — the self-attention of LoRAAttnProcessor2_0 (attention_processor_faceid.py:300-318).  With k2 / v2: the
+ * decoupled cross-attention of LoRAIPAttnProcessor2_0 (:462-500), text keys (77) and image-prompt keys (4) with their
+ * own softmax each, hidden = text + scale * ip, in ONE pass over the queries. */
 int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t Nq,
-                          int32_t Nkv, int32_t D, float scale, void* stream);
+                          int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2, int32_t Nkv2,
+                          float weight2, void* stream);
 #ifdef __cplusplus
 }
 #endif

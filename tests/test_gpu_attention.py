@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,H,Nq,Nkv,D", [(1, 1, 128, 64, 40), (2, 8, 256, 256, 40), (2, 3, 1024, 1024, 64), (12, 8, 4096, 4096, 40),
-                                          (1, 2, 384, 1152, 40)])
+                                          (1, 2, 384, 1152, 40), (2, 8, 512, 77, 40), (2, 8, 256, 81, 40), (1, 2, 128, 1, 64),
+                                          (1, 2, 128, 130, 40)])
 @pytest.mark.parametrize("spread", [1.0, 6.0])
 def test_attention_matches_fp32_reference(B, H, Nq, Nkv, D, spread):
     from gaussianip_amd.guidance import fused
@@ -60,3 +61,19 @@ def test_single_wide_head_attention_as_dense_gemms():
     (gg,) = torch.autograd.grad(got, xh, torch.ones_like(got))
     assert float((got.float() - want).abs().max()) < 1e-2 * max(1.0, float(want.abs().max()))
     assert float((gg.float() - gw).abs().max()) < 2e-2 * max(1.0, float(gw.abs().max()))
+
+
+def test_decoupled_cross_attention_two_key_sets():
+    """text keys (77) + image-prompt keys (4), separate softmaxes, hidden = text + 0.5 * ip (LoRAIPAttnProcessor2_0)."""
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, H, N, D = 3, 8, 1024, 40
+    q = torch.randn(B, N, H * D, device="cuda", generator=g).half()
+    k1, v1 = [torch.randn(B, 77, H * D, device="cuda", generator=g).half() for _ in range(2)]
+    k2, v2 = [torch.randn(B, 4, H * D, device="cuda", generator=g).half() for _ in range(2)]
+    with torch.no_grad():
+        o = fused.attention(q, k1, v1, H, k2, v2, 0.5)
+        sp = lambda t: t.float().view(B, t.shape[1], H, D).transpose(1, 2)  # noqa: E731
+        ref = F.scaled_dot_product_attention(sp(q), sp(k1), sp(v1)) + 0.5 * F.scaled_dot_product_attention(sp(q), sp(k2), sp(v2))
+        ref = ref.transpose(1, 2).reshape(B, N, H * D)
+    assert float((o.float() - ref).abs().max()) <= 3e-3 * max(1.0, float(ref.abs().max()))
