@@ -7,7 +7,7 @@ rank renders its own cameras of the replicated Gaussian state; per step the rank
                                          all_reduce(max) of the radii (GaussianIP.py:452-457, gaussian_model.py:420-422)
   * the depth normaliser               — all_reduce(max) of one float (GaussianIP.py:225 uses the batch-global max)
 xGMI is point-to-point (7 links x ~153 GB/s): at these sizes a ring all-reduce is latency-bound (~60-100 us), so the
-gradients go in ONE bucket rather than six small collectives.
+whole exchange is TWO collectives (one SUM bucket, one MAX bucket) rather than nine small ones.
 """
 from typing import Dict, Optional, Sequence
 
@@ -40,16 +40,44 @@ def allreduce_gradients(params: Sequence[torch.Tensor], group=None, average: boo
 def exchange_step(params: Sequence[torch.Tensor], viewspace_grad_norm: Optional[torch.Tensor] = None,
                   radii: Optional[torch.Tensor] = None, depth_max: Optional[torch.Tensor] = None, group=None,
                   average: bool = False) -> Dict[str, Optional[torch.Tensor]]:
-    """Everything a step exchanges.  `viewspace_grad_norm` [P] = sum over the local views of ||grad_xy||,
-    `radii` [P] = max over the local views, `depth_max` = local depth maximum (0-d tensor)."""
-    allreduce_gradients(params, group, average)
-    if _on(group):
+    """Everything a step exchanges, in TWO collectives (each small all-reduce costs tens of microseconds of latency on
+    xGMI, comparable to a raster kernel): one SUM bucket = [parameter gradients | view-space gradient norms], one MAX
+    bucket = [radii | depth maximum].  `viewspace_grad_norm` [P] = sum over the local views of ||grad_xy||,
+    `radii` [P] = max over the local views (int32: exact in float32 below 2^24), `depth_max` = local depth maximum
+    (0-d tensor).  All arguments are updated in place, like separate all_reduce calls would."""
+    if not _on(group):
+        return {"viewspace_grad_norm": viewspace_grad_norm, "radii": radii, "depth_max": depth_max}
+    grads = [p.grad for p in params if p.grad is not None]
+    world = dist.get_world_size(group)
+    sums = [g.reshape(-1) for g in grads]
+    if viewspace_grad_norm is not None:
+        sums.append(viewspace_grad_norm.reshape(-1).to(grads[0].dtype if grads else viewspace_grad_norm.dtype))
+    if sums:
+        flat = torch.cat(sums)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            if average:
+                g /= world
+            off += n
         if viewspace_grad_norm is not None:
-            dist.all_reduce(viewspace_grad_norm, op=dist.ReduceOp.SUM, group=group)
+            viewspace_grad_norm.copy_(flat[off:off + viewspace_grad_norm.numel()].view_as(viewspace_grad_norm))
+    maxes = []
+    if radii is not None:
+        maxes.append(radii.reshape(-1).to(torch.float32))
+    if depth_max is not None:
+        maxes.append(depth_max.reshape(-1).to(torch.float32))
+    if maxes:
+        flat = torch.cat(maxes)
+        dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group)
+        off = 0
         if radii is not None:
-            dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
+            radii.copy_(flat[:radii.numel()].view_as(radii).to(radii.dtype))
+            off = radii.numel()
         if depth_max is not None:
-            dist.all_reduce(depth_max, op=dist.ReduceOp.MAX, group=group)
+            depth_max.copy_(flat[off:off + depth_max.numel()].view_as(depth_max).to(depth_max.dtype))
     return {"viewspace_grad_norm": viewspace_grad_norm, "radii": radii, "depth_max": depth_max}
 
 
