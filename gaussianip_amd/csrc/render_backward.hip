@@ -70,8 +70,8 @@ struct BwdAcc { float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9; };
 __device__ __forceinline__ bool bwd_pair(BwdPix& p, BwdAcc& a, float pxf, float pyf, const float2 xy, const float4 co,
                                          const float4 cl, uint32_t i) {
   const float dx = xy.x - pxf, dy = xy.y - pyf;
-  const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-  const float G = __expf(power);
+  const float power = __builtin_fmaf(dx, __builtin_fmaf(co.x, dx, co.y * dy), (co.z * dy) * dy);   // conic pre-scaled: log2 domain
+  const float G = __builtin_amdgcn_exp2f(power);
   const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
   const bool c = i < p.lastc && power <= 0.0f && alpha >= GIP_ALPHA_MIN;
   // predicated (branch-free): a non-contributing pixel adds exact zeros and keeps its state
@@ -209,7 +209,7 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
         const float4 q0 = r0, q1 = r1, q2 = r2;
         const uint4 q3 = r3;
         s_xy[lane] = make_float2(q0.x, q0.y);
-        s_con[lane] = make_float4(q1.x, q1.y, q1.z, q0.w);
+        s_con[lane] = make_float4(q1.x * -0.72134752044448170f, q1.y * -1.4426950408889634f, q1.z * -0.72134752044448170f, q0.w);
         s_col[lane] = make_float4(q2.x, q2.y, q2.z, q0.z);
         const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
         row = rio + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);

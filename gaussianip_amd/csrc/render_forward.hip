@@ -75,7 +75,8 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     if (k < end) {
       const float4 q0 = r0, q1 = r1, q2 = r2;
       s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
-      s_con[threadIdx.x] = make_float4(q1.x, q1.y, q1.z, q0.w);
+      // conic pre-scaled into the exp2 domain: power * log2(e) = A dx^2 + B dx dy + C dy^2 (sign tests are unchanged)
+      s_con[threadIdx.x] = make_float4(q1.x * -0.72134752044448170f, q1.y * -1.4426950408889634f, q1.z * -0.72134752044448170f, q0.w);
       s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
       // extent of { power >= -ln(255 o) }  (conservative: +1% / +0.05 px)
       uint32_t mask = 0xf;
@@ -134,8 +135,8 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
             const float4 co = s_con[jj[u]];
             cc[u] = s_col[jj[u]];
             const float dx = xy.x - pxf, dy = xy.y - pyf;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            al[u] = fminf(GIP_ALPHA_MAX, co.w * __expf(power));
+            const float power = __builtin_fmaf(dx, __builtin_fmaf(co.x, dx, co.y * dy), (co.z * dy) * dy);   // log2 domain
+            al[u] = fminf(GIP_ALPHA_MAX, co.w * __builtin_amdgcn_exp2f(power));
             okk[u] = have && power <= 0.0f && al[u] >= GIP_ALPHA_MIN;
           }
           bool any_stop = false;
