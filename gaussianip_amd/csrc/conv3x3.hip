@@ -61,8 +61,8 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   const int q = total >> 3, r = total & 7, xcd = id & 7;
   const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   const int mt = t / n_tiles, nt = t - mt * n_tiles;
-  const long long M = (long long)N * H * W;
-  const long long m0 = (long long)mt * CV_BM;
+  const unsigned M = (unsigned)N * H * W;          // < 2^31 (checked on the host): 32-bit index arithmetic throughout
+  const unsigned m0 = (unsigned)mt * CV_BM;
   const int co0 = nt * (GEGLU ? BN / 2 : BN);      // first OUTPUT channel of the tile
   const int HW = H * W;
 
@@ -74,14 +74,14 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int row = i * 32 + sub_row;
-    const long long m = m0 + row;
+    const unsigned m = m0 + row;
     const int lchunk = pchunk ^ ((row >> 1) & 7);
     unsigned mask = 0;
     unsigned off = 0;
     if (m < M) {
       if constexpr (TAPS == 9) {
-        const int n = (int)(m / HW), rem = (int)(m - (long long)n * HW);
-        const int y = rem / W, xx = rem - y * W;
+        const unsigned n = m / (unsigned)HW, rem = m - n * (unsigned)HW;
+        const int y = (int)(rem / (unsigned)W), xx = (int)(rem - (unsigned)y * W);
 #pragma unroll
         for (int dy = 0; dy < 3; dy++)
 #pragma unroll
@@ -90,7 +90,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       } else {
         mask = 1u;
       }
-      off = (unsigned)(m * Cin + lchunk * 8) * 2u;
+      off = (m * (unsigned)Cin + lchunk * 8) * 2u;
     }
     a_off[i] = off;
     a_mask[i] = mask;
@@ -113,7 +113,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   // buffer resources: activations based one row + one pixel BEFORE x so that every tap displacement is >= 0
   const unsigned shift = TAPS == 9 ? (unsigned)(W + 1) * Cin * 2u : 0u;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)x - shift), 0, (int)((unsigned)(M * Cin) * 2u + 2u * shift + (unsigned)Cin * 2u), CV_RSRC_FLAGS);
+      (void*)((const char*)x - shift), 0, (int)(M * (unsigned)Cin * 2u + 2u * shift + (unsigned)Cin * 2u), CV_RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t wr =
       __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * (GEGLU ? 2u : 1u) * TAPS * Cin * 2u), CV_RSRC_FLAGS);
 
@@ -203,7 +203,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   };
 #pragma unroll
   for (int mi = 0; mi < 4; mi++) {
-    const long long m = m0 + wm * 64 + mi * 16 + (lane & 15);
+    const unsigned m = m0 + wm * 64 + mi * 16 + (lane & 15);
     if (m >= M) continue;
     if constexpr (GEGLU) {
 #pragma unroll
