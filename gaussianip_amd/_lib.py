@@ -64,7 +64,7 @@ def _missing(name):
 def raster_lib():
     global _raster
     if _raster is None:
-        path = os.path.join(LIB_DIR, "libgip_raster.so")
+        path = os.path.join(LIB_DIR, os.environ.get("GIP_RASTER_LIB", "libgip_raster.so"))
         if not os.path.exists(path):
             raise _missing("libgip_raster.so")
         lib = ctypes.CDLL(path)

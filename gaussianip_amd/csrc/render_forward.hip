@@ -23,7 +23,7 @@
 #include "gip_internal.h"
 
 #ifndef FWD_UNROLL
-#define FWD_UNROLL 4
+#define FWD_UNROLL 8
 #endif
 
 __global__ void __launch_bounds__(GIP_BLOCK)
