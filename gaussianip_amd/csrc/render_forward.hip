@@ -5,28 +5,41 @@
 // alpha [1,H,W] = sum a T, plus n_contrib for the backward replay.
 //
 // Structure (wave64-first, not a 16x16 thread block recompiled):
-//   * one workgroup = 4 waves per 16x16 tile; wave w owns the 8x8 pixel quadrant (w&1, w>>1);
+//   * one workgroup = 8 waves per 16x16 tile; wave w owns the 8x4 pixel block (w&1, w>>1) and its 64 lanes are
+//     32 pixels x 2 LIST ENTRIES: lanes 0-31 evaluate the next surviving entry of the tile's list, lanes 32-63 the
+//     one after it, for the same 32 pixels.  The two alphas are exchanged with one v_permlane32_swap and both lane
+//     halves then apply the reference's sequential rule (entry e, then entry o: T, the 1e-4 stop test, the weights)
+//     to identical values, so the result is the sequential blend while a wave retires two entries per trip through
+//     its instruction stream.  The kernel's duration is set by the longest lists walked by a lone wave (measured:
+//     ~230 cycles of issue per entry), so this halves the critical path; the finer 8x4 blocks also cull more;
 //   * workgroups are launched longest-list-first (tile_order from the scan kernel);
-//   * the tile's depth-sorted list is consumed in batches of 256: each lane fetches one key, gathers that
-//     Gaussian's 64-byte record with dwordx4 loads, stages the 40 bytes the blend needs into LDS, and
-//     computes a 4-bit QUADRANT MASK from the tight screen-space extent of the alpha >= 1/255 ellipse
-//     (|dx| <= sqrt(2 ln(255 o) cov_xx), same for y).  A pair outside that ellipse fails the reference's
-//     alpha < 1/255 test, so skipping it cannot change any output;
-//   * each wave ballots the mask bits of its quadrant and walks only the set bits with scalar
-//     find-first-one, evaluating the surviving entries with a branch-free body (LDS broadcast reads,
-//     v_exp_f32, predicated accumulation), and leaves as soon as all 64 of its pixels have terminated;
+//   * the tile's depth-sorted list is consumed in batches of 512: each lane fetches one key, gathers that
+//     Gaussian's 64-byte record with dwordx4 loads, stages the 40 bytes the blend needs into LDS (conic pre-scaled
+//     into the exp2 domain), and computes an 8-bit BLOCK MASK from the tight screen-space extent of the
+//     alpha >= 1/255 ellipse (|dx| <= sqrt(2 ln(255 o) cov_xx), same for y).  A pair outside that ellipse fails the
+//     reference's alpha < 1/255 test, so skipping it cannot change any output;
+//   * each wave ballots the mask bits of its block and walks only the set bits with scalar find-first-one, two per
+//     step, FWD_PAIRS steps per trip (independent exp / alpha chains), and leaves as soon as all its pixels terminated;
 //   * at every GIP_SEGMENT-entry boundary the per-pixel blend state (T, C, D) is checkpointed (20 B / pixel) so
 //     that the backward pass needs no sequential walk over the tile.
 // (A two-pass segment-parallel forward — local blend of every segment + per-tile combine with exact replay of the
-//  segment a pixel terminates in — was built and measured in round 1: 0.44 ms vs 0.40 ms for this kernel at 100k
-//  Gaussians, because the replays of terminating pixels cost what the flat pass saves)
+//  segment a pixel terminates in — was built and measured in round 1: 0.44 ms vs 0.40 ms for the then-current kernel
+//  at 100k Gaussians, because the replays of terminating pixels cost what the flat pass saves)
 #include "gip_internal.h"
 
-#ifndef FWD_UNROLL
-#define FWD_UNROLL 8
+#ifndef FWD_PAIRS
+#define FWD_PAIRS 4
 #endif
+#define FWD_THREADS 512
 
-__global__ void __launch_bounds__(GIP_BLOCK)
+// value held by lane ^ 32 (v_permlane32_swap: a <- [a_lo | b_lo], b <- [a_hi | b_hi]; inline asm, see render_backward.hip)
+__device__ __forceinline__ float xchg32(float x, int hh) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return hh ? a : b;
+}
+
+__global__ void __launch_bounds__(FWD_THREADS)
 gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_order,
                           const uint32_t* __restrict__ tile_start, const unsigned long long* __restrict__ keys,
                           const GipRecord* __restrict__ records, const float* __restrict__ bg,
@@ -36,12 +49,15 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   const uint32_t vt = tile_order[blockIdx.x];   // view * T + tile
   const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
   const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // wave 0..7 = 8x4 pixel block (wave & 1, wave >> 1)
+  const int hh = lane >> 5, pl = lane & 31;                        // list-entry parity, pixel inside the block
+  const int lx = ((wave & 1) << 3) | (pl & 7), ly = ((wave >> 1) << 2) | (pl >> 3);
   const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
   const bool inside = px < kp.W && py < kp.H;
   const float pxf = (float)px, pyf = (float)py;
   const float tile_x0 = (float)(tx * GIP_TILE), tile_y0 = (float)(ty * GIP_TILE);
+  // slot of this pixel in the checkpoint rows: the backward's layout (8x8 quadrant * 64 + row * 8 + column)
+  const int cpix = ((((ly >> 3) << 1) | (lx >> 3)) << 6) | ((ly & 7) << 3) | (lx & 7);
 
   const uint32_t start = tile_start[vt];
   uint32_t end = tile_start[vt + 1];
@@ -49,13 +65,13 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   if (end < start) end = start;
   const GipRecord* recs = records + (size_t)v * kp.P;
 
-  __shared__ float2 s_xy[GIP_BLOCK];
-  __shared__ float4 s_con[GIP_BLOCK];   // conic a,b,c + opacity
-  __shared__ float4 s_col[GIP_BLOCK];   // r,g,b + depth
-  __shared__ uint32_t s_mask[GIP_BLOCK];
+  __shared__ float2 s_xy[FWD_THREADS];
+  __shared__ float4 s_con[FWD_THREADS];   // conic a,b,c (exp2 domain) + opacity
+  __shared__ float4 s_col[FWD_THREADS];   // r,g,b + depth
+  __shared__ uint32_t s_mask[FWD_THREADS];
 
   bool done = !inside;
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, Dp = 0.f;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, Dp = 0.f;   // C, W, D: this lane half's share of the sums
   uint32_t last_contributor = 0;
 
   // software pipeline over the batches: the key of batch b+2 and the record of batch b+1 are in flight
@@ -63,14 +79,14 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   uint32_t g_next = 0xffffffffu, g_next2 = 0xffffffffu;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
   if (start + threadIdx.x < end) g_next = (uint32_t)keys[start + threadIdx.x];
-  if (start + GIP_BLOCK + threadIdx.x < end) g_next2 = (uint32_t)keys[start + GIP_BLOCK + threadIdx.x];
+  if (start + FWD_THREADS + threadIdx.x < end) g_next2 = (uint32_t)keys[start + FWD_THREADS + threadIdx.x];
   if (g_next != 0xffffffffu) {
     const float4* rp = reinterpret_cast<const float4*>(recs + g_next);
     r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
   }
 
-  for (uint32_t base = start; base < end; base += GIP_BLOCK) {
-    if (__syncthreads_count(done) == GIP_BLOCK) break;
+  for (uint32_t base = start; base < end; base += FWD_THREADS) {
+    if (__syncthreads_count(done) == FWD_THREADS) break;
     const uint32_t k = base + threadIdx.x;
     if (k < end) {
       const float4 q0 = r0, q1 = r1, q2 = r2;
@@ -79,7 +95,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
       s_con[threadIdx.x] = make_float4(q1.x * -0.72134752044448170f, q1.y * -1.4426950408889634f, q1.z * -0.72134752044448170f, q0.w);
       s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
       // extent of { power >= -ln(255 o) }  (conservative: +1% / +0.05 px)
-      uint32_t mask = 0xf;
+      uint32_t mask = 0xff;
       const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
       const float det = q1.x * q1.z - q1.y * q1.y;
       if (t2 <= 0.f) {
@@ -88,31 +104,35 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
         const float inv = t2 / det;
         const float hx = sqrtf(inv * q1.z) * 1.01f + 0.05f, hy = sqrtf(inv * q1.x) * 1.01f + 0.05f;
         const float rx = q0.x - tile_x0, ry = q0.y - tile_y0;   // centre relative to the tile origin
-        const bool xl = rx - hx <= 7.f, xr = rx + hx >= 8.f;     // touches columns 0..7 / 8..15
-        const bool yt = ry - hy <= 7.f, yb = ry + hy >= 8.f;
-        mask = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+        const uint32_t cols = (rx - hx <= 7.f ? 1u : 0u) | (rx + hx >= 8.f ? 2u : 0u);      // columns 0..7 / 8..15
+        const float ylo = ry - hy, yhi = ry + hy;
+        mask = 0;
+#pragma unroll
+        for (int band = 0; band < 4; band++)                                                 // rows 4 band .. 4 band + 3
+          if (ylo <= (float)(4 * band + 3) && yhi >= (float)(4 * band)) mask |= cols << (2 * band);
       }
       s_mask[threadIdx.x] = mask;
     }
     // issue the loads of the following batches (consumed one / two iterations from now)
     g_next = g_next2;
-    g_next2 = (k + 2 * GIP_BLOCK < end) ? (uint32_t)keys[k + 2 * GIP_BLOCK] : 0xffffffffu;
+    g_next2 = (k + 2 * FWD_THREADS < end) ? (uint32_t)keys[k + 2 * FWD_THREADS] : 0xffffffffu;
     if (g_next != 0xffffffffu) {
       const float4* rp = reinterpret_cast<const float4*>(recs + g_next);
       r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
     }
     __syncthreads();
-    const int cnt = min((uint32_t)GIP_BLOCK, end - base);
+    const int cnt = min((uint32_t)FWD_THREADS, end - base);
     if (!__all(done)) {
       for (int c0 = 0; c0 < cnt; c0 += 64) {
         const uint32_t rel = (base - start) + c0;
         if (rel != 0 && (rel % GIP_SEGMENT) == 0) {
           // blend state at the start of segment rel / GIP_SEGMENT (>= 1): lets the backward treat every segment of
-          // this tile as an independent work item (render_backward.hip).  Each wave stores its own 64 pixels.
+          // this tile as an independent work item (render_backward.hip).  The two lane halves hold partial sums.
+          const float s0 = C0 + xchg32(C0, hh), s1 = C1 + xchg32(C1, hh), s2 = C2 + xchg32(C2, hh), sd = Dp + xchg32(Dp, hh);
           const uint32_t slot = ckpt_start[vt] + rel / GIP_SEGMENT - 1;
-          if (slot < kp.ckpt_capacity) {
-            float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * GIP_BLOCK) + threadIdx.x;
-            cp[0] = T; cp[GIP_BLOCK] = C0; cp[2 * GIP_BLOCK] = C1; cp[3 * GIP_BLOCK] = C2; cp[4 * GIP_BLOCK] = Dp;
+          if (slot < kp.ckpt_capacity && hh == 0) {
+            float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * GIP_BLOCK) + cpix;
+            cp[0] = T; cp[GIP_BLOCK] = s0; cp[2 * GIP_BLOCK] = s1; cp[3 * GIP_BLOCK] = s2; cp[4 * GIP_BLOCK] = sd;
           }
         }
         const int e = c0 + lane;
@@ -120,38 +140,48 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
         unsigned long long m = __ballot((mk >> wave) & 1u);
         bool wave_done = false;
         while (m) {
-          // FWD_UNROLL list entries per trip: their exp / alpha chains are independent, only the short
-          // transmittance update is serial (cuts the latency-bound time per entry)
-          int jj[FWD_UNROLL];
-          bool okk[FWD_UNROLL];
-          float al[FWD_UNROLL];
-          float4 cc[FWD_UNROLL];
+          // FWD_PAIRS pairs of list entries per trip: lanes 0-31 take the first entry of a pair, lanes 32-63 the second
+          int jj[FWD_PAIRS];
+          float al[FWD_PAIRS];
+          float4 cc[FWD_PAIRS];
 #pragma unroll
-          for (int u = 0; u < FWD_UNROLL; u++) {
-            const bool have = m != 0;
-            jj[u] = have ? c0 + __builtin_ctzll(m) : jj[0];
+          for (int u = 0; u < FWD_PAIRS; u++) {
+            const int j1 = m ? __builtin_ctzll(m) : 0;
+            const bool have1 = m != 0;
             m &= m - 1;                                   // (0 & anything) stays 0
+            const int j2 = m ? __builtin_ctzll(m) : j1;
+            const bool have2 = m != 0;
+            m &= m - 1;
+            jj[u] = c0 + (hh ? j2 : j1);
+            const bool have = hh ? have2 : have1;
             const float2 xy = s_xy[jj[u]];
             const float4 co = s_con[jj[u]];
             cc[u] = s_col[jj[u]];
             const float dx = xy.x - pxf, dy = xy.y - pyf;
             const float power = __builtin_fmaf(dx, __builtin_fmaf(co.x, dx, co.y * dy), (co.z * dy) * dy);   // log2 domain
-            al[u] = fminf(GIP_ALPHA_MAX, co.w * __builtin_amdgcn_exp2f(power));
-            okk[u] = have && power <= 0.0f && al[u] >= GIP_ALPHA_MIN;
+            const float a = fminf(GIP_ALPHA_MAX, co.w * __builtin_amdgcn_exp2f(power));
+            al[u] = (have && power <= 0.0f && a >= GIP_ALPHA_MIN) ? a : 0.f;      // 0 = the reference skips this pair
           }
           bool any_stop = false;
 #pragma unroll
-          for (int u = 0; u < FWD_UNROLL; u++) {
-            const bool valid = !done && okk[u];
-            const float test_T = T * (1.f - al[u]);
-            const bool stop = valid && test_T < GIP_T_MIN;
-            const bool acc = valid && !stop;
-            done = done || stop;
-            const float w = acc ? al[u] * T : 0.f;
+          for (int u = 0; u < FWD_PAIRS; u++) {
+            const float ao = xchg32(al[u], hh);
+            const float a_e = hh ? ao : al[u], a_o = hh ? al[u] : ao;            // first / second entry of the pair
+            // the reference's per-entry rule, applied to both entries in order by both lane halves
+            const float t1 = T * (1.f - a_e);
+            const bool stop1 = !done && t1 < GIP_T_MIN;
+            const bool live1 = !done && !stop1;
+            const float T1 = live1 ? t1 : T;
+            const float t2 = T1 * (1.f - a_o);
+            const bool stop2 = live1 && t2 < GIP_T_MIN;
+            const bool live2 = live1 && !stop2;
+            const bool acc = al[u] > 0.f && (hh ? live2 : live1);
+            const float w = acc ? al[u] * (hh ? T1 : T) : 0.f;
             C0 += cc[u].x * w; C1 += cc[u].y * w; C2 += cc[u].z * w; Wt += w; Dp += cc[u].w * w;
-            T = acc ? test_T : T;
             last_contributor = acc ? (base - start) + jj[u] + 1 : last_contributor;
-            any_stop = any_stop || stop;
+            T = live2 ? t2 : T1;
+            done = done || stop1 || stop2;
+            any_stop = any_stop || stop1 || stop2;
           }
           if (__any(any_stop)) {           // wave-uniform; re-test termination only when something changed
             if (__all(done)) { wave_done = true; break; }
@@ -162,7 +192,11 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     }
   }
 
-  if (inside) {
+  // the two lane halves hold disjoint shares of the sums and the same T
+  C0 += xchg32(C0, hh); C1 += xchg32(C1, hh); C2 += xchg32(C2, hh); Wt += xchg32(Wt, hh); Dp += xchg32(Dp, hh);
+  const uint32_t lc_other = __float_as_uint(xchg32(__uint_as_float(last_contributor), hh));
+  last_contributor = max(last_contributor, lc_other);
+  if (inside && hh == 0) {
     const size_t HW = (size_t)kp.H * kp.W;
     const size_t pix = (size_t)py * kp.W + px;
     float* oc = out_color + (size_t)v * 3 * HW;
@@ -178,7 +212,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
 
 void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth,
                                float* alpha, hipStream_t s) {
-  hipLaunchKernelGGL(gip_render_forward_kernel, dim3(kp.V * kp.T), dim3(GIP_BLOCK), 0, s, kp, st.tile_order,
+  hipLaunchKernelGGL(gip_render_forward_kernel, dim3(kp.V * kp.T), dim3(FWD_THREADS), 0, s, kp, st.tile_order,
                      st.tile_start, st.keys, st.records, bg, color, depth, alpha, st.n_contrib, st.final_T, st.ckpt_start,
                      st.checkpoints);
 }
