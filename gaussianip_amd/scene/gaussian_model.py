@@ -359,6 +359,40 @@ class GaussianModel:
             rebuilt[group["name"]] = new
         return rebuilt
 
+    # ------------------------------------------------------------------ spatial order (not in the reference)
+    @staticmethod
+    def morton_order(xyz, bits=10):
+        """Permutation that sorts points along a 3-D Morton (Z-order) curve.  Rendering is invariant under a permutation
+        of the Gaussians (up to float summation order); a spatially coherent order lets the 256 Gaussians of a
+        preprocess workgroup share tile-histogram atomics and keeps a tile's records close in memory."""
+        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+        q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * (2 ** bits - 1)).long().clamp_(0, 2 ** bits - 1)
+        code = torch.zeros(xyz.shape[0], dtype=torch.long, device=xyz.device)
+        for b in range(bits):
+            for a in range(3):
+                code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        return torch.argsort(code)
+
+    def sort_spatially(self):
+        """Re-order the Gaussians (parameters, Adam moments, densification statistics) along a Morton curve.  Call after
+        create_from_pcd / densify_and_prune.  render() is unchanged up to float summation order and the order of entries
+        with identical depth bits (ties are broken by Gaussian index, as in the reference)."""
+        perm = self.morton_order(self._xyz.detach())
+        if self.optimizer is not None and self._xyz.is_cuda:
+            P = self._xyz.shape[0]
+            empty = {g["name"]: g["params"][0].detach()[:0] for g in self.optimizer.param_groups}
+            self._adopt(self._gather_all(perm.contiguous(), P, empty))
+        else:
+            for _, attr in _GROUPS:
+                setattr(self, attr, nn.Parameter(getattr(self, attr).detach()[perm].requires_grad_(True)))
+            if self.optimizer is not None:
+                raise ValueError("sort_spatially on CPU must run before training_setup")
+        for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            t = getattr(self, name)
+            if t.numel() and t.shape[0] == perm.shape[0]:
+                setattr(self, name, t[perm])
+        return perm
+
     def _densify_and_prune_fused(self, max_grad, min_opacity, extent, max_screen_size, max_world_size, N=2):
         """densify_and_clone -> densify_and_split -> prune_points x2 of the reference (gaussian_model.py:357-411) with
         the same selections, the same torch.normal draw and the same final row order, but every tensor rebuilt ONCE:

@@ -222,3 +222,36 @@ def test_fused_densify_matches_stepwise_reference_semantics():
         p = grp["params"][0]
         p.grad = torch.zeros_like(p)
     b.optimizer.step()
+
+
+def test_spatial_sort_is_invisible_to_the_renderer():
+    """GaussianModel.sort_spatially(): parameters, Adam moments and statistics are permuted consistently; render() output
+    changes only by float summation order and by the order of entries with IDENTICAL depth bits (the reference algorithm
+    breaks depth ties by Gaussian index, so a few pixels per image move by one entry's contribution)."""
+    from argparse import ArgumentParser
+    from gaussianip_amd.arguments import OptimizationParams, PipelineParams
+    from gaussianip_amd.renderer import render
+    from gaussianip_amd.scene import Camera, GaussianModel
+    from gaussianip_amd.utils import BasicPointCloud
+    rng = np.random.default_rng(3)
+    P = 30000
+    pts = scenes.human_points(P, rng).astype(np.float32)[rng.permutation(P)]
+    gm = GaussianModel(0)
+    gm.create_from_pcd(BasicPointCloud(pts, rng.uniform(0, 1, (P, 3)).astype(np.float32), None), 4.0)
+    gm.training_setup(OptimizationParams(ArgumentParser()))
+    for grp in gm.optimizer.param_groups:
+        grp["params"][0].grad = torch.randn_like(grp["params"][0]) * 1e-4
+    gm.optimizer.step()
+    cam = _camera(10.0, 30.0, 1.6, 55.0, 256, 256)
+    pipe = PipelineParams(ArgumentParser())
+    bg = torch.zeros(3, device="cuda")
+    before = render(cam, gm, pipe, bg)["render"].detach().clone()
+    xyz0 = gm.get_xyz.detach().clone()
+    m0 = gm.optimizer.state[gm.optimizer.param_groups[0]["params"][0]]["exp_avg"].clone()
+    perm = gm.sort_spatially()
+    assert torch.equal(gm.get_xyz.detach(), xyz0[perm])
+    assert torch.equal(gm.optimizer.state[gm.optimizer.param_groups[0]["params"][0]]["exp_avg"], m0[perm])
+    assert gm.optimizer.param_groups[0]["params"][0] is gm._xyz
+    after = render(cam, gm, pipe, bg)["render"].detach()
+    d = (after - before).abs()
+    assert float(d.mean()) < 2e-6 and float((d > 1e-4).float().mean()) < 2e-3 and float(d.max()) < 2e-2
