@@ -24,9 +24,9 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
                            const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                            const float* __restrict__ camposs, const GipRecord* __restrict__ records,
                            const uint32_t* __restrict__ inst_offset, const float* __restrict__ partial,
-                           GipRasterGradsOut gout) {
+                           GipRasterGradsOut gout, const GipRasterHeader* __restrict__ header) {
   const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
-  if (idx >= kp.P) return;
+  if (idx >= kp.P || header->overflow) return;      // overflowed forward: gradients are discarded by the host
   const float m0 = means3D[3 * idx], m1 = means3D[3 * idx + 1], m2 = means3D[3 * idx + 2];
 
   // 3-D covariance (recomputed rather than stored: 6 floats of state per view saved)
@@ -274,7 +274,7 @@ void gip_launch_gather_backward(const GipKernelParams& kp, const GipRasterInputs
   const dim3 grid(kp.nblk), block(GIP_BLOCK);
 #define LAUNCH(MM) hipLaunchKernelGGL((gip_gather_backward_kernel<MM>), grid, block, 0, s, kp, in.means3D, in.shs, \
     in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, st.records, \
-    st.inst_offset, partial, gout)
+    st.inst_offset, partial, gout, st.header)
   const int needed = in.shs ? (kp.D + 1) * (kp.D + 1) : 1;
   if (needed <= 1) LAUNCH(1);
   else if (needed <= 4) LAUNCH(4);

@@ -117,6 +117,9 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
   const int lx = lane & 7, ly = lane >> 3;
   const size_t HW = (size_t)kp.H * kp.W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  // an overflowed forward left truncated buckets behind: nothing downstream is meaningful (the host raises when it
+  // reads the header, see rasterizer.py) — leave without touching memory
+  if (header->overflow) return;
   uint32_t nseg = header->num_segments;
   if (nseg > kp.seg_capacity) nseg = kp.seg_capacity;
 

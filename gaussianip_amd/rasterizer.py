@@ -172,7 +172,7 @@ def _forward_with_policy(plan, need_backward):
 
 
 def _verify_pending(plan):
-    """Deferred overflow check, run when backward starts (the copy finished long ago: no stall)."""
+    """Deferred overflow check, run once the backward kernels are enqueued (see _RasterizeGaussians.backward)."""
     if getattr(plan, "pending", None) is None:
         return
     ev, host, key, cap = plan.pending
@@ -277,7 +277,6 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, g_color, g_radii, g_depth, g_alpha):
         plan = ctx.plan
         color, depth, alpha = ctx.saved_tensors
-        _verify_pending(plan)
 
         def prep(g):
             if g is None:
@@ -285,6 +284,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             return g.float().contiguous()
 
         g = _run_backward(plan, (color, depth, alpha), prep(g_color), prep(g_depth), prep(g_alpha))
+        # The deferred overflow check runs AFTER the backward kernels are enqueued: waiting for the forward's header copy
+        # then overlaps with GPU work instead of idling the device when backward follows forward immediately.  The
+        # kernels are capacity-clamped, so running them on an overflowed forward is safe; its gradients are discarded
+        # by the exception below and never reach the caller.
+        _verify_pending(plan)
         g2d = None if ctx.means2D_shape is None else g["means2D"].reshape(ctx.means2D_shape)
         return (g["means3D"], g2d, g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"],
                 g["cov3D_precomp"], None, None)

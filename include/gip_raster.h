@@ -190,7 +190,10 @@ int gip_raster_forward(const GipRasterConfig* cfg, const GipRasterInputs* in, co
 
 /* Backward: per-pixel reverse-order replay with wave/LDS segmented reduction into per-(tile,Gaussian)
  * partial rows, then a deterministic per-Gaussian gather fused with the cov2D / projection / SH /
- * cov3D backward.  No float atomics: results are bitwise reproducible. */
+ * cov3D backward.  No float atomics: results are bitwise reproducible.
+ * If the forward overflowed its capacity (GipRasterHeader.overflow != 0) the backward kernels read the flag on the
+ * device and exit without touching memory: the gradient buffers are then UNDEFINED and the caller must discard them
+ * after reading the header (this lets a caller enqueue backward before it has looked at the header). */
 int gip_raster_backward(const GipRasterConfig* cfg, const GipRasterInputs* in, const GipRasterGradsIn* gin,
                         const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
                         const GipRasterGradsOut* gout, void* stream);
