@@ -294,12 +294,56 @@ void gip_launch_scatter(const GipKernelParams& kp, GipStatePtrs st, hipStream_t 
 // the larger element to the higher index, so virtual +inf padding at indices >= n never moves and
 // comparators that touch it can simply be skipped -> correct for any n.
 // ------------------------------------------------------------------------------------------------
-template <typename PtrT>
-__device__ __forceinline__ void bitonic_any_n(PtrT a, uint32_t n) {
+// Register-blocked small strides: thread t owns the 8 consecutive keys [8t, 8t+8) (256 threads x 8 = the 2048-key LDS
+// chunk), so every comparator with both ends inside an aligned 8-block — the stages k = 2, 4, 8 and the merge strides
+// 4, 2, 1 of every later stage — runs on registers between ONE 64-byte LDS read and write, without barriers in between.
+// Keys past n are +inf in registers (a comparator against +inf never swaps: the same as skipping it).
+#define CE(x, y) { const unsigned long long lo_ = x < y ? x : y, hi_ = x < y ? y : x; x = lo_; y = hi_; }
+__device__ __forceinline__ void regs_load(const unsigned long long* a, uint32_t n, uint32_t b, unsigned long long* r) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) r[i] = b + i < n ? a[b + i] : ~0ull;
+}
+__device__ __forceinline__ void regs_store(unsigned long long* a, uint32_t n, uint32_t b, const unsigned long long* r) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) if (b + i < n) a[b + i] = r[i];
+}
+__device__ __forceinline__ void regs_merge421(unsigned long long* r) {
+  CE(r[0], r[4]) CE(r[1], r[5]) CE(r[2], r[6]) CE(r[3], r[7])
+  CE(r[0], r[2]) CE(r[1], r[3]) CE(r[4], r[6]) CE(r[5], r[7])
+  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])
+}
+__device__ __forceinline__ void regs_sort8(unsigned long long* r) {     // stages k = 2, 4, 8 of the flip network
+  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])                                   // k = 2: flip
+  CE(r[0], r[3]) CE(r[1], r[2]) CE(r[4], r[7]) CE(r[5], r[6])                                   // k = 4: flip
+  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])                                   //        stride 1
+  CE(r[0], r[7]) CE(r[1], r[6]) CE(r[2], r[5]) CE(r[3], r[4])                                   // k = 8: flip
+  CE(r[0], r[2]) CE(r[1], r[3]) CE(r[4], r[6]) CE(r[5], r[7])                                   //        stride 2
+  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])                                   //        stride 1
+}
+
+// strides j = 4, 2, 1 of one merge on registers (all threads; ends with a barrier)
+__device__ __forceinline__ void merge_low_regs(unsigned long long* a, uint32_t n) {
+  for (uint32_t b = threadIdx.x * 8; b < n; b += GIP_BLOCK * 8) {
+    unsigned long long r[8];
+    regs_load(a, n, b, r);
+    regs_merge421(r);
+    regs_store(a, n, b, r);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void bitonic_any_n(unsigned long long* a, uint32_t n) {
   uint32_t m = 1;
   while (m < n) m <<= 1;
   const uint32_t half = m >> 1;
-  for (uint32_t k = 2; k <= m; k <<= 1) {
+  for (uint32_t b = threadIdx.x * 8; b < n; b += GIP_BLOCK * 8) {             // stages k = 2, 4, 8
+    unsigned long long r[8];
+    regs_load(a, n, b, r);
+    regs_sort8(r);
+    regs_store(a, n, b, r);
+  }
+  __syncthreads();
+  for (uint32_t k = 16; k <= m; k <<= 1) {
     const uint32_t hk = k >> 1;
     for (uint32_t t = threadIdx.x; t < half; t += GIP_BLOCK) {   // flip stage
       const uint32_t blk = t / hk, off = t - blk * hk;
@@ -310,7 +354,7 @@ __device__ __forceinline__ void bitonic_any_n(PtrT a, uint32_t n) {
       }
     }
     __syncthreads();
-    for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
+    for (uint32_t j = k >> 2; j >= 8; j >>= 1) {
       for (uint32_t t = threadIdx.x; t < half; t += GIP_BLOCK) {
         const uint32_t lo = 2 * j * (t / j) + (t % j), hi = lo + j;
         if (hi < n) {
@@ -320,6 +364,7 @@ __device__ __forceinline__ void bitonic_any_n(PtrT a, uint32_t n) {
       }
       __syncthreads();
     }
+    merge_low_regs(a, n);
   }
 }
 
@@ -376,7 +421,7 @@ __device__ void sort_big_tile(unsigned long long* a, uint32_t n, unsigned long l
       const uint32_t cn = min((uint32_t)BIG_CHUNK, n - c0);
       for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) s_keys[i] = a[c0 + i];
       __syncthreads();
-      for (uint32_t j = BIG_CHUNK >> 1; j >= 1; j >>= 1) {
+      for (uint32_t j = BIG_CHUNK >> 1; j >= 8; j >>= 1) {
         for (uint32_t tt = threadIdx.x; tt < (BIG_CHUNK >> 1); tt += GIP_BLOCK) {
           const uint32_t lo = 2 * j * (tt / j) + (tt % j), hi = lo + j;
           if (hi < cn) {
@@ -386,6 +431,7 @@ __device__ void sort_big_tile(unsigned long long* a, uint32_t n, unsigned long l
         }
         __syncthreads();
       }
+      merge_low_regs(s_keys, cn);
       for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) a[c0 + i] = s_keys[i];
       __syncthreads();
     }
