@@ -46,7 +46,7 @@ template <int BN, int STAGES, int TAPS, bool GEGLU>
 __global__ void __launch_bounds__(CV_THREADS, STAGES == 2 ? 2 : 1)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
-               int m_tiles, int n_tiles) {
+               int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int A_BYTES = CV_BM * 128;          // pixel tile: 128 rows x 64 halves
   constexpr int B_BYTES = BN * 128;             // weight tile: BN rows x 64 halves
@@ -57,7 +57,9 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   const int wm = wave & 1, wn = wave >> 1;
 
   // tile of this workgroup (bijective XCD remap: ids congruent mod 8 share an XCD)
-  const int total = m_tiles * n_tiles, id = blockIdx.x;
+  // split-K (small pixel counts: too few output tiles to fill the chip): blockIdx.x = split * total + tile, every split
+  // accumulates its share of the K steps and stores an fp32 slab; conv_splitk_reduce_kernel sums the slabs
+  const int total = m_tiles * n_tiles, id = (int)(blockIdx.x % (unsigned)total), split = (int)(blockIdx.x / (unsigned)total);
   const int q = total >> 3, r = total & 7, xcd = id & 7;
   const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   const int mt = t / n_tiles, nt = t - mt * n_tiles;
@@ -118,7 +120,9 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * (GEGLU ? 2u : 1u) * TAPS * Cin * 2u), CV_RSRC_FLAGS);
 
   const int cblocks = Cin / CV_BK;
-  const int KT = TAPS * cblocks;
+  const int KT_all = TAPS * cblocks;
+  const int kt_begin = (int)((long long)split * KT_all / ksplit), kt_end = (int)((long long)(split + 1) * KT_all / ksplit);
+  const int KT = kt_end - kt_begin;
 
   auto stage = [&](int tap, int cb, int buf) {
     const int dy = tap / 3, dx = tap - dy * 3;
@@ -160,12 +164,12 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     }
   };
 
-  int tap = 0, cb = 0;                     // K step the NEXT stage() call loads
+  int tap = kt_begin / cblocks, cb = kt_begin - (kt_begin / cblocks) * cblocks;     // K step the NEXT stage() call loads
   auto advance = [&]() {
     if (++cb == cblocks) { cb = 0; ++tap; }
   };
   if constexpr (STAGES == 2) {
-    stage(0, 0, 0);
+    stage(tap, cb, 0);
     advance();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -180,7 +184,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     // three stages, one workgroup per CU: the DMA of step t+2 is issued before the math of step t, the wait at the top
     // of a step is COUNTED (the newest tile stays in flight across the barrier), one raw s_barrier per step
     constexpr int NDMA = 4 + B_ROUNDS;
-    stage(0, 0, 0);
+    stage(tap, cb, 0);
     advance();
     if (KT > 1) { stage(tap, cb, 1); advance(); }
     int buf = 0, fill = 2;
@@ -201,6 +205,22 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     const f16x4 b = *(const f16x4*)p;
     v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
   };
+  if (ksplit > 1) {
+    if constexpr (!GEGLU) {
+      float* slab = partial + (size_t)split * M * Cout;
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) {
+        const unsigned m = m0 + wm * 64 + mi * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+          const int co = co0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+          if (co < Cout) *(f32x4*)(slab + (size_t)m * Cout + co) = acc[ni][mi];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < 4; mi++) {
     const unsigned m = m0 + wm * 64 + mi * 16 + (lane & 15);
@@ -233,9 +253,33 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   }
 }
 
+// out[m][co] = sum_s slab[s][m][co] + bias[co] + residual[m][co], 4 channels per lane, fixed summation order
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce_kernel(const float* __restrict__ partial, const _Float16* __restrict__ bias, const _Float16* __restrict__ residual,
+                          _Float16* __restrict__ out, unsigned n4, int c4, int ksplit, size_t slab) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = *(const f32x4*)(partial + (size_t)i * 4);
+  for (int s = 1; s < ksplit; s++) {
+    const f32x4 p = *(const f32x4*)(partial + (size_t)s * slab + (size_t)i * 4);
+    v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+  }
+  if (bias) {
+    const f16x4 b = *(const f16x4*)(bias + (i % (unsigned)c4) * 4);
+    v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+  }
+  if (residual) {
+    const f16x4 r = *(const f16x4*)(residual + (size_t)i * 4);
+    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+  }
+  f16x4 o;
+  o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+  *(f16x4*)(out + (size_t)i * 4) = o;
+}
+
 template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
-                  int Cin, int Cout, hipStream_t s) {
+                  int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0) {
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
@@ -246,9 +290,24 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
       return 3;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds, s,
+  // split-K when the output tiles cannot fill the chip and a workspace was handed in: aim at ~2 workgroups per CU
+  int ksplit = 1;
+  const int tiles = m_tiles * n_tiles, KT = TAPS * (Cin / CV_BK);
+  if (!GEGLU && STAGES == 2 && workspace && tiles < 256) {
+    ksplit = (512 + tiles - 1) / tiles;
+    if (ksplit > KT / 8) ksplit = KT / 8;
+    if (ksplit > 16) ksplit = 16;
+    while (ksplit > 1 && (size_t)ksplit * M * Cout * sizeof(float) > workspace_bytes) ksplit--;
+    if (ksplit < 2) ksplit = 1;
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
-                     N, H, W, Cin, Cout, m_tiles, n_tiles);
+                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace);
+  if (ksplit > 1) {
+    const unsigned n4 = (unsigned)(M * Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
+                       (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, n4, Cout / 4, ksplit, (size_t)M * Cout);
+  }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -257,7 +316,8 @@ static bool fits32(long long M, int Cin, int Cout, int wrows, int taps) {
 }
 
 extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
-                                    int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+                                    int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   if (!x || !w || !out || N < 1 || H < 1 || W < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 4 || (Cout & 3)) return 1;
   if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;   // 32-bit byte offsets
   hipStream_t s = (hipStream_t)stream;
@@ -266,8 +326,8 @@ extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
   if (stages == 3)
     return wide ? launch<160, 3, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
                 : launch<128, 3, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
-  return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
-              : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
+  return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes)
+              : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes);
 }
 
 extern "C" int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,

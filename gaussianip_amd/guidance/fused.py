@@ -147,7 +147,8 @@ def geglu(x):
 # ---------------------------------------------------------------------------------------------------------------------
 # 3x3 / stride 1 / pad 1 convolution on the matrix cores (csrc/conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------------
-_MIN_CONV_TILES = 200        # below this many 128 x BN output tiles the chip is under-filled: MIOpen's split-K kernels win
+_MIN_CONV_TILES = 32         # tile counts below 256 run split-K (fp32 slabs in the shared workspace); tiny problems stay on MIOpen
+_SPLITK_WS_BYTES = 64 << 20
 _wt_cache = {}
 
 
@@ -160,8 +161,10 @@ def _conv_call(x, w, cout, bias=None, residual=None):
     N, C, H, W = x.shape
     out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     null = ctypes.c_void_p(None)
+    ws = _workspace(x.device, _SPLITK_WS_BYTES) if _conv_tiles(N, H, W, cout) < 256 else None
     rc = _lib.nn_lib().gip_conv3x3_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias),
                                             null if residual is None else _p(residual), _p(out), N, H, W, C, cout,
+                                            null if ws is None else _p(ws), 0 if ws is None else ws.numel(),
                                             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     if rc != 0:
         raise RuntimeError("gip_conv3x3_nhwc_f16 failed with status %d" % rc)

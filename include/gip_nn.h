@@ -45,9 +45,12 @@ int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
  * w [Cout,3,3,Cin] half (the channels_last memory of a torch [Cout,Cin,3,3] weight), out [N,H,W,Cout] half, fp32
  * accumulation.  Epilogue (fp32, before the single rounding to half): + bias[Cout] (NULL = none) + residual
  * [N,H,W,Cout] (NULL = none; ResnetBlock2D's shortcut).  Cin % 64 == 0, Cout % 4 == 0.
+ * `workspace` (optional, caller-owned device memory): with it, problems whose 128 x BN output tiles cannot fill the
+ * chip (the 8x8 latent level) run split-K — fp32 slabs [split][N*H*W][Cout] + a fixed-order reduce with the epilogue.
  * Replaces the MIOpen call behind diffusers' ResnetBlock2D / Upsample2D convolutions in the denoiser and the VAE. */
 int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
-                         int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
+                         int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* nn.Linear on the same MFMA machinery (TAPS = 1): out[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]) (+ residual[m][n]),
  * x [M,K], w [Nout,K] (torch Linear weight), out [M,Nout] half, fp32 accumulation, K % 64 == 0.  geglu != 0: w has

@@ -2,6 +2,7 @@
 import ctypes, sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from gaussianip_amd import _lib
+from gaussianip_amd.guidance import fused
 lib = _lib.nn_lib()
 dev = "cuda"
 def timed(fn, n=20):
@@ -14,8 +15,7 @@ def timed(fn, n=20):
     return a.elapsed_time(b) / n
 def conv(x, w, out):
     N, C, H, W = x.shape
-    rc = lib.gip_conv3x3_nhwc_f16(x.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), N, H, W, C, w.shape[0], torch.cuda.current_stream().cuda_stream)
-    assert rc == 0, rc
+    out.copy_(fused._conv_call(x, w, w.shape[0]))
     return out
 shapes = [(2, 64, 64, 9, 7), (12, 320, 320, 64, 64), (12, 640, 320, 64, 64), (12, 960, 320, 64, 64), (12, 640, 640, 32, 32), (12, 1280, 640, 32, 32), (12, 1920, 640, 32, 32),
           (12, 1280, 1280, 16, 16), (12, 2560, 1280, 16, 16), (12, 1280, 1280, 8, 8), (12, 2560, 1280, 8, 8),

@@ -1,6 +1,7 @@
 import ctypes, sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from gaussianip_amd import _lib
+from gaussianip_amd.guidance import fused
 lib = _lib.nn_lib()
 dev = "cuda"
 def timed(fn, n=20):
@@ -17,8 +18,7 @@ for N, ci, co, H, W in [(4, 512, 512, 64, 64), (8, 512, 512, 64, 64), (16, 512, 
     w = (torch.randn(co, ci, 3, 3, device=dev) * 0.01).half().contiguous(memory_format=torch.channels_last)
     out = torch.empty(N, co, H, W, device=dev, dtype=torch.half).contiguous(memory_format=torch.channels_last)
     def conv():
-        rc = lib.gip_conv3x3_nhwc_f16(x.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), N, H, W, ci, co, torch.cuda.current_stream().cuda_stream)
-        assert rc == 0
+        fused._conv_call(x, w, co)
     fl = 2.0 * N * H * W * ci * co * 9
     t = timed(conv)
     bn = 160 if (co % 160 == 0 and co % 128) else 128
