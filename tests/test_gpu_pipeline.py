@@ -255,3 +255,45 @@ def test_spatial_sort_is_invisible_to_the_renderer():
     after = render(cam, gm, pipe, bg)["render"].detach()
     d = (after - before).abs()
     assert float(d.mean()) < 2e-6 and float((d > 1e-4).float().mean()) < 2e-3 and float(d.max()) < 2e-2
+
+
+def test_stage_three_rgb_reconstruction_step_descends():
+    """system.StageThreeStep (GaussianIP.py:424-436): crop / half-size / L1 against refined images in refinement order;
+    a few Adam steps on the colours reduce the loss, the gradient reaches every parameter group."""
+    from argparse import ArgumentParser
+    from gaussianip_amd.arguments import OptimizationParams, PipelineParams
+    from gaussianip_amd.guidance.refine import VIEW_IDX_ALL
+    from gaussianip_amd.renderer import render_views
+    from gaussianip_amd.scene import GaussianModel
+    from gaussianip_amd.system import StageThreeStep
+    from gaussianip_amd.utils import BasicPointCloud
+    rng = np.random.default_rng(5)
+    P = 20000
+    pts = scenes.human_points(P, rng).astype(np.float32)
+    gm = GaussianModel(0)
+    gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
+    gm.training_setup(OptimizationParams(ArgumentParser()))
+    pipe = PipelineParams(ArgumentParser())
+    bg = torch.zeros(3, device="cuda")
+    H = W = 1024
+    cams = [_camera(5.0, -180.0 + 11.25 * i, 1.8, 70.0, H, W) for i in range(32)]      # the 32-view refine orbit
+    with torch.no_grad():
+        target = torch.cat([render_views(cams[i:i + 8], gm, pipe, bg)["render"] for i in range(0, 32, 8)])   # orbit order
+        target = (target * 0.5 + 0.25).permute(0, 2, 3, 1)                               # "refined": recoloured renders
+    refined = target[torch.as_tensor(VIEW_IDX_ALL, device="cuda")]                       # refinement order, like refine_rgb returns
+    st3 = StageThreeStep(gm, pipe, bg, cams, refined, VIEW_IDX_ALL, train_bs=4)
+    assert st3.orbit_ids == list(range(32)) and st3.gt_small.shape == (32, 3, 415, 290)
+    ids = [0, 9, 17, 30]
+    losses = []
+    for _ in range(6):
+        out = st3.training_step(id_list=ids)
+        gm.optimizer.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        if not losses:
+            for grp in gm.optimizer.param_groups:
+                gr = grp["params"][0].grad
+                assert gr is not None and torch.isfinite(gr).all(), grp["name"]
+            assert float(gm._features_dc.grad.abs().max()) > 0 and float(gm._xyz.grad.abs().max()) > 0
+        gm.optimizer.step()
+        losses.append(float(out["loss"]))
+    assert losses[-1] < losses[0], losses
