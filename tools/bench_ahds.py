@@ -40,7 +40,9 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     P, H, W, B = gaussians, 1024, 1024, 4
     gm = GaussianModel(0)
     pts = scenes.human_points(P, rng).astype(np.float32)
-    gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the model announces its size on stdout like the reference; keep stdout for the JSON line
+        gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
     gm.training_setup(OptimizationParams(ArgumentParser()))
     pipe = PipelineParams(ArgumentParser())
     bg = torch.zeros(3, device=dev)
