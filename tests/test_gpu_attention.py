@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("B,H,Nq,Nkv,D", [(1, 1, 128, 64, 40), (2, 8, 256, 256, 40), (2, 3, 1024, 1024, 64), (12, 8, 4096, 4096, 40),
                                           (1, 2, 384, 1152, 40), (2, 8, 512, 77, 40), (2, 8, 256, 81, 40), (1, 2, 128, 1, 64),
-                                          (1, 2, 128, 130, 40)])
+                                          (1, 2, 128, 130, 40), (1, 2, 2048, 16384, 40)])
 @pytest.mark.parametrize("spread", [1.0, 6.0])
 def test_attention_matches_fp32_reference(B, H, Nq, Nkv, D, spread):
     from gaussianip_amd.guidance import fused
