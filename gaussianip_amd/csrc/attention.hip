@@ -49,6 +49,10 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   constexpr int ND = (D + 31) / 32;      // 32-row tiles of O^T
   constexpr int CH = D / 8;              // 16-byte chunks per row
   constexpr int PER = (AT_BKV * CH + 255) / 256;
+  // D < 64 leaves unused rows in the last O^T tile: row D of V^T is set to ONES, so that O^T[D][q] = sum_k p[k][q] — the
+  // softmax denominator comes out of the PV matrix product and the 32 scalar adds per block disappear (VALU-bound kernel)
+  constexpr bool L_FROM_MFMA = (D % 32) != 0;
+  constexpr int L_TILE = D / 32, L_ROW = D % 32;          // position of that row in the O^T tiles
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 2 * AT_TILE];   // [stage][K | V]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.y / H, h = blockIdx.y - b * H;
@@ -70,6 +74,15 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   }
   // the padding columns of the images must be finite zeros (0 * garbage would poison S^T): clear everything once
   for (int i = tid * 16; i < 2 * 2 * AT_TILE; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
+  if constexpr (L_FROM_MFMA) {
+    __syncthreads();
+    // feature D of every V row (both stages) = 1.0; the staging only ever rewrites chunks < D / 8
+    if (tid < 2 * AT_BKV) {
+      const int stage = tid / AT_BKV, row = tid % AT_BKV, lch = D / 8;
+      unsigned char* p = smem + stage * 2 * AT_TILE + AT_TILE + row * AT_ROW + ((lch ^ (((row >> 1) & 1) << 2)) << 4);
+      *(_Float16*)p = (_Float16)1.0f;
+    }
+  }
 
   // staging descriptors: every thread moves two chunks of K and of V per block; the tail indices wrap around (a few
   // chunks are moved twice with identical data) so that no load or LDS store is predicated; rows past the end of a
@@ -185,7 +198,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
       if (__any(raise)) {
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        l_run *= alpha;
+        if constexpr (!L_FROM_MFMA) l_run *= alpha;
 #pragma unroll
         for (int dt = 0; dt < ND; dt++)
 #pragma unroll
@@ -201,7 +214,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
           for (int j = 0; j < 8; j++) {
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
-            l_run += p;
+            if constexpr (!L_FROM_MFMA) l_run += p;
             P[t][s2].v[j] = (_Float16)p;
           }
 
@@ -219,7 +232,16 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     }
 
     // ---- normalise this segment ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if constexpr (L_FROM_MFMA) {
+      // row L_ROW of tile L_TILE: register (L_ROW & 3) + 4 * (L_ROW >> 3) of the lane half (L_ROW >> 2) & 1
+      constexpr int reg = (L_ROW & 3) + 4 * (L_ROW >> 3), half = (L_ROW >> 2) & 1;
+      const float mine = O[L_TILE][reg];
+      const float other = __shfl_xor(mine, 32);
+      l_tot = (hh == half) ? mine : other;
+    } else {
+      l_tot = l_run + __shfl_xor(l_run, 32);
+    }
     const float inv = (seg == 0 ? 1.f : w2) / l_tot;
     if constexpr (TWO) {
 #pragma unroll
