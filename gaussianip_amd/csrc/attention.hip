@@ -29,8 +29,12 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 #define AT_BQ 128
 #define AT_BKV 64
-#define AT_ROW 128                       // bytes per LDS row (64 halves: D <= 64)
-#define AT_TILE (AT_BKV * AT_ROW)        // one K or V stage: 8 KB
+// LDS rows are 128 bytes (D <= 64) or 256 bytes (D <= 128); chunk swizzles per row length:
+//   K image (row reads, ds_read_b128):          chunk ^ ((row >> 1) & 7)      |  chunk ^ (row & 15)
+//   V image (transposed reads, 4-row blocks):   chunk ^ (((row >> 1) & 1) << 2) |  chunk ^ ((row & 3) << 2)
+// both make a 16-lane row read / a half-wave transposed read cover all 64 banks once.
+template <int ROWB> __device__ __forceinline__ int kswz(int row) { return ROWB == 128 ? ((row >> 1) & 7) : (row & 15); }
+template <int ROWB> __device__ __forceinline__ int vswz(int row) { return ROWB == 128 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
 #define AT_DEFER 8.0f
 
 union Frag8 {
@@ -44,7 +48,9 @@ __global__ void __launch_bounds__(256, 2)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
                 const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2) {
-  static_assert(D % 8 == 0 && D <= 64, "head dim");
+  static_assert(D % 8 == 0 && D <= 128, "head dim");
+  constexpr int AT_ROW = D <= 64 ? 128 : 256;          // bytes per LDS row
+  constexpr int AT_TILE = AT_BKV * AT_ROW;             // one K or V stage
   constexpr int NS = (D + 15) / 16;      // k-steps of the S^T product
   constexpr int ND = (D + 31) / 32;      // 32-row tiles of O^T
   constexpr int CH = D / 8;              // 16-byte chunks per row
@@ -79,7 +85,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     // feature D of every V row (both stages) = 1.0; the staging only ever rewrites chunks < D / 8
     if (tid < 2 * AT_BKV) {
       const int stage = tid / AT_BKV, row = tid % AT_BKV, lch = D / 8;
-      unsigned char* p = smem + stage * 2 * AT_TILE + AT_TILE + row * AT_ROW + ((lch ^ (((row >> 1) & 1) << 2)) << 4);
+      unsigned char* p = smem + stage * 2 * AT_TILE + AT_TILE + row * AT_ROW + ((lch ^ vswz<AT_ROW>(row)) << 4) + (D % 8) * 2;
       *(_Float16*)p = (_Float16)1.0f;
     }
   }
@@ -87,14 +93,18 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   // staging descriptors: every thread moves two chunks of K and of V per block; the tail indices wrap around (a few
   // chunks are moved twice with identical data) so that no load or LDS store is predicated; rows past the end of a
   // ragged key set are clamped to its last row (they are masked to -inf before the softmax)
-  static_assert(PER == 2, "two staging chunks per thread");
-  int idx0 = tid, idx1 = tid + 256;
+  static_assert(PER == 2 || PER == 3, "two or three staging chunks per thread");
+  int idx0 = tid, idx1 = tid + 256, idx2 = tid + 512;
   if (idx1 >= AT_BKV * CH) idx1 -= AT_BKV * CH;
-  const int row0 = idx0 / CH, ch0 = idx0 - row0 * CH, row1 = idx1 / CH, ch1 = idx1 - row1 * CH;
-  const int kl0 = row0 * AT_ROW + ((ch0 ^ ((row0 >> 1) & 7)) << 4), kl1 = row1 * AT_ROW + ((ch1 ^ ((row1 >> 1) & 7)) << 4);
-  const int vl0 = AT_TILE + row0 * AT_ROW + ((ch0 ^ (((row0 >> 1) & 1) << 2)) << 4);
-  const int vl1 = AT_TILE + row1 * AT_ROW + ((ch1 ^ (((row1 >> 1) & 1) << 2)) << 4);
-  uint4 kr0, kr1, vr0, vr1;
+  if (idx2 >= AT_BKV * CH) idx2 -= AT_BKV * CH;
+  if (idx2 >= AT_BKV * CH) idx2 -= AT_BKV * CH;
+  const int row0 = idx0 / CH, ch0 = idx0 - row0 * CH, row1 = idx1 / CH, ch1 = idx1 - row1 * CH, row2 = idx2 / CH, ch2 = idx2 - row2 * CH;
+  const int kl0 = row0 * AT_ROW + ((ch0 ^ kswz<AT_ROW>(row0)) << 4), kl1 = row1 * AT_ROW + ((ch1 ^ kswz<AT_ROW>(row1)) << 4);
+  const int kl2 = row2 * AT_ROW + ((ch2 ^ kswz<AT_ROW>(row2)) << 4);
+  const int vl0 = AT_TILE + row0 * AT_ROW + ((ch0 ^ vswz<AT_ROW>(row0)) << 4);
+  const int vl1 = AT_TILE + row1 * AT_ROW + ((ch1 ^ vswz<AT_ROW>(row1)) << 4);
+  const int vl2 = AT_TILE + row2 * AT_ROW + ((ch2 ^ vswz<AT_ROW>(row2)) << 4);
+  uint4 kr0, kr1, kr2, vr0, vr1, vr2;
 #define AT_FETCH(blk_)                                                                   \
   {                                                                                      \
     const int ra_ = min((blk_) * AT_BKV + row0, n_keys - 1), rb_ = min((blk_) * AT_BKV + row1, n_keys - 1);  \
@@ -102,6 +112,11 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     kr1 = *(const uint4*)(kp + (size_t)rb_ * C + ch1 * 8);                               \
     vr0 = *(const uint4*)(vp + (size_t)ra_ * C + ch0 * 8);                               \
     vr1 = *(const uint4*)(vp + (size_t)rb_ * C + ch1 * 8);                               \
+    if constexpr (PER == 3) {                                                            \
+      const int rc_ = min((blk_) * AT_BKV + row2, n_keys - 1);                           \
+      kr2 = *(const uint4*)(kp + (size_t)rc_ * C + ch2 * 8);                             \
+      vr2 = *(const uint4*)(vp + (size_t)rc_ * C + ch2 * 8);                             \
+    }                                                                                    \
   }
 #define AT_DEPOSIT(stage_)                                                 \
   {                                                                        \
@@ -110,10 +125,14 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     *(uint4*)(st_ + kl1) = kr1;                                            \
     *(uint4*)(st_ + vl0) = vr0;                                            \
     *(uint4*)(st_ + vl1) = vr1;                                            \
+    if constexpr (PER == 3) {                                              \
+      *(uint4*)(st_ + kl2) = kr2;                                          \
+      *(uint4*)(st_ + vl2) = vr2;                                          \
+    }                                                                      \
   }
 
   // fragment addressing
-  const int k_row_off = r * AT_ROW, k_swz = (r >> 1) & 7;
+  const int k_row_off = r * AT_ROW, k_swz = kswz<AT_ROW>(r);       // tile bases are multiples of 32: swizzle term of row = of r
   const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, half16 = (lane >> 4) & 1;
 
   f32x16 O[ND], Oacc[TWO ? ND : 1];
@@ -171,7 +190,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
           for (int s2 = 0; s2 < 2; s2++) {
             const int row = t * 32 + 16 * s2 + 4 * hh + q4;
-            const int off = row * AT_ROW + ((lch ^ (((row >> 1) & 1) << 2)) << 4) + sub;
+            const int off = row * AT_ROW + ((lch ^ vswz<AT_ROW>(row)) << 4) + sub;
             vt[dt][t][s2].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off));
             vt[dt][t][s2].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off + 8 * AT_ROW));
           }
@@ -293,6 +312,7 @@ extern "C" int gip_attention_fwd_f16(const void* q, const void* k, const void* v
   switch (D) {
     case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
     case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
+    case 80: launch_attn<80>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;

@@ -227,7 +227,7 @@ def conv1x1(x, w, bias=None):
 
 def attention_supported(q, k, heads):
     D = q.shape[-1] // heads
-    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64) and q.shape[1] % 128 == 0 and
+    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64, 80) and q.shape[1] % 128 == 0 and
             k.shape[1] >= 1 and q.is_contiguous() and k.is_contiguous() and
             not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
 

@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("B,H,Nq,Nkv,D", [(1, 1, 128, 64, 40), (2, 8, 256, 256, 40), (2, 3, 1024, 1024, 64), (12, 8, 4096, 4096, 40),
                                           (1, 2, 384, 1152, 40), (2, 8, 512, 77, 40), (2, 8, 256, 81, 40), (1, 2, 128, 1, 64),
-                                          (1, 2, 128, 130, 40), (1, 2, 2048, 16384, 40)])
+                                          (1, 2, 128, 130, 40), (1, 2, 2048, 16384, 40),
+                                          (2, 8, 1024, 1024, 80), (1, 3, 256, 77, 80), (2, 8, 4096, 8192, 80)])
 @pytest.mark.parametrize("spread", [1.0, 6.0])
 def test_attention_matches_fp32_reference(B, H, Nq, Nkv, D, spread):
     from gaussianip_amd.guidance import fused
@@ -67,7 +68,13 @@ def test_decoupled_cross_attention_two_key_sets():
     """text keys (77) + image-prompt keys (4), separate softmaxes, hidden = text + 0.5 * ip (LoRAIPAttnProcessor2_0)."""
     from gaussianip_amd.guidance import fused
     g = torch.Generator(device="cuda").manual_seed(9)
-    B, H, N, D = 3, 8, 1024, 40
+    for D in (40, 80):
+        _two_sets(g, D)
+
+
+def _two_sets(g, D):
+    from gaussianip_amd.guidance import fused
+    B, H, N = 3, 8, 1024
     q = torch.randn(B, N, H * D, device="cuda", generator=g).half()
     k1, v1 = [torch.randn(B, 77, H * D, device="cuda", generator=g).half() for _ in range(2)]
     k2, v2 = [torch.randn(B, 4, H * D, device="cuda", generator=g).half() for _ in range(2)]

@@ -10,7 +10,7 @@ def timed(fn, n=20):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
-for B, H, N, D in [(12, 8, 4096, 40), (12, 8, 1024, 40), (12, 8, 4096, 64), (4, 8, 4096, 40)]:
+for B, H, N, D in [(12, 8, 4096, 40), (12, 8, 1024, 40), (12, 8, 4096, 64), (4, 8, 4096, 40), (12, 8, 1024, 80), (2, 8, 4096, 80)]:
     q, k, v = [torch.randn(B, N, H * D, device="cuda").half() for _ in range(3)]
     sp = lambda t: t.view(B, N, H, D).transpose(1, 2)
     with torch.no_grad():
