@@ -46,7 +46,9 @@ template <int BN, int STAGES, int TAPS, bool GEGLU>
 __global__ void __launch_bounds__(CV_THREADS, STAGES == 2 ? 2 : 1)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
-               int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial) {
+               int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom) {
+  // geom = stride | pad_top << 8 | pad_left << 16; H, W are the OUTPUT dims, Hin, Win the input dims (equal at stride 1)
+  const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int A_BYTES = CV_BM * 128;          // pixel tile: 128 rows x 64 halves
   constexpr int B_BYTES = BN * 128;             // weight tile: BN rows x 64 halves
@@ -84,15 +86,17 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       if constexpr (TAPS == 9) {
         const unsigned n = m / (unsigned)HW, rem = m - n * (unsigned)HW;
         const int y = (int)(rem / (unsigned)W), xx = (int)(rem - (unsigned)y * W);
+        const int iy0 = y * cstride - pad_t, ix0 = xx * cstride - pad_l;
 #pragma unroll
         for (int dy = 0; dy < 3; dy++)
 #pragma unroll
           for (int dx = 0; dx < 3; dx++)
-            if ((unsigned)(y + dy - 1) < (unsigned)H && (unsigned)(xx + dx - 1) < (unsigned)W) mask |= 1u << (dy * 3 + dx);
+            if ((unsigned)(iy0 + dy) < (unsigned)Hin && (unsigned)(ix0 + dx) < (unsigned)Win) mask |= 1u << (dy * 3 + dx);
+        off = (((n * (unsigned)Hin + (unsigned)(y * cstride)) * (unsigned)Win + (unsigned)(xx * cstride)) * (unsigned)Cin + lchunk * 8) * 2u;
       } else {
         mask = 1u;
+        off = (m * (unsigned)Cin + lchunk * 8) * 2u;
       }
-      off = (m * (unsigned)Cin + lchunk * 8) * 2u;
     }
     a_off[i] = off;
     a_mask[i] = mask;
@@ -113,9 +117,10 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     b_off[i] = ok ? (unsigned)(wrow * TAPS * Cin + lchunk * 8) * 2u : CV_OOB;
   }
   // buffer resources: activations based one row + one pixel BEFORE x so that every tap displacement is >= 0
-  const unsigned shift = TAPS == 9 ? (unsigned)(W + 1) * Cin * 2u : 0u;
+  const unsigned shift = TAPS == 9 ? (unsigned)(pad_t * Win + pad_l) * Cin * 2u : 0u;
+  const unsigned Min = TAPS == 9 ? (unsigned)N * Hin * Win : M;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)x - shift), 0, (int)(M * (unsigned)Cin * 2u + 2u * shift + (unsigned)Cin * 2u), CV_RSRC_FLAGS);
+      (void*)((const char*)x - shift), 0, (int)(Min * (unsigned)Cin * 2u + (unsigned)(2 * Win + 2) * Cin * 2u + shift), CV_RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t wr =
       __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * (GEGLU ? 2u : 1u) * TAPS * Cin * 2u), CV_RSRC_FLAGS);
 
@@ -126,7 +131,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 
   auto stage = [&](int tap, int cb, int buf) {
     const int dy = tap / 3, dx = tap - dy * 3;
-    const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * W + dx) * Cin : 0) + cb * CV_BK) * 2u;   // relative to the shifted base
+    const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * Win + dx) * Cin : 0) + cb * CV_BK) * 2u;   // relative to the shifted base
     const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
     unsigned char* sa = smem + buf * STAGE + wave * 1024;
 #pragma unroll
@@ -279,7 +284,9 @@ conv_splitk_reduce_kernel(const float* __restrict__ partial, const _Float16* __r
 
 template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
-                  int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0) {
+                  int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0, int Hin = 0, int Win = 0,
+                  int geom = 1 | (1 << 8) | (1 << 16)) {
+  if (Hin == 0) { Hin = H; Win = W; }
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
@@ -302,7 +309,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   }
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
-                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace);
+                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom);
   if (ksplit > 1) {
     const unsigned n4 = (unsigned)(M * Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
@@ -328,6 +335,20 @@ extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
                 : launch<128, 3, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
   return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes)
               : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes);
+}
+
+extern "C" int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin,
+                                      int32_t Win, int32_t Cin, int32_t Cout, int32_t pad_top, int32_t pad_left,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !w || !out || N < 1 || Hin < 2 || Win < 2 || (Hin & 1) || (Win & 1) || Cin < CV_BK || Cin % CV_BK || Cout < 4 ||
+      (Cout & 3) || pad_top < 0 || pad_top > 1 || pad_left < 0 || pad_left > 1)
+    return 1;
+  if (!fits32((long long)N * Hin * Win, Cin, Cout, Cout, 9)) return 1;
+  const int H = Hin / 2, W = Win / 2, geom = 2 | (pad_top << 8) | (pad_left << 16);
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  return wide ? launch<160, 2, 9, false>(x, w, bias, nullptr, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes, Hin, Win, geom)
+              : launch<128, 2, 9, false>(x, w, bias, nullptr, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes, Hin, Win, geom);
 }
 
 extern "C" int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,

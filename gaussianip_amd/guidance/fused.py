@@ -277,6 +277,34 @@ def linear(x, w, bias=None, residual=None, geglu_act=False):
     return y if residual is None else y + residual
 
 
+def _conv_s2_supported(x, w):
+    return (fusable(x) and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0 and w.dtype == torch.float16 and
+            w.is_contiguous(memory_format=torch.channels_last) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and
+            _conv_tiles(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w.shape[0]) >= _MIN_CONV_TILES and x.numel() * 2 < (1 << 31))
+
+
+def _conv_s2_call(x, w, bias, pad):
+    """3x3 / stride 2 through the MFMA kernel; pad = 1 (symmetric padding=1) or 0 (F.pad(x, (0, 1, 0, 1)) form)."""
+    N, C, H, W = x.shape
+    cout = w.shape[0]
+    out = torch.empty((N, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    null = ctypes.c_void_p(None)
+    ws = _workspace(x.device, _SPLITK_WS_BYTES) if _conv_tiles(N, H // 2, W // 2, cout) < 256 else None
+    rc = _lib.nn_lib().gip_conv3x3s2_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias), _p(out), N, H, W, C, cout, pad, pad,
+                                              null if ws is None else _p(ws), 0 if ws is None else ws.numel(),
+                                              ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("gip_conv3x3s2_nhwc_f16 failed with status %d" % rc)
+    return out
+
+
+def downsample_sym(x, w, bias):
+    """diffusers Downsample2D of the U-Net / ControlNet: 3x3, stride 2, padding 1 (frozen, no gradient path needed)."""
+    if _conv_s2_supported(x, w) and not (torch.is_grad_enabled() and x.requires_grad):
+        return _conv_s2_call(x, w, bias, 1)
+    return F.conv2d(x, w, bias, stride=2, padding=1)
+
+
 class _DownsampleAsym(torch.autograd.Function):
     """VAE Downsample2D: F.pad(x, (0, 1, 0, 1)) -> 3x3 / stride 2 / pad 0 convolution.  Forward stays on MIOpen; the
     DATA GRADIENT is the stride-1 MFMA convolution of the zero-dilated upstream gradient with the flipped-transposed
@@ -288,12 +316,16 @@ class _DownsampleAsym(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(w)
         ctx.x_shape = tuple(x.shape)
+        if _conv_s2_supported(x, w):
+            return _conv_s2_call(x, w, bias, 0)
         return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
 
     @staticmethod
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
         N, C, H, W = ctx.x_shape
+        if w.shape[0] > 128:          # measured: the library's backward-data kernels are as fast at 256 / 512 channels
+            return torch.nn.grad.conv2d_input((N, C, H + 1, W + 1), w, dy, stride=2)[:, :, :H, :W], None, None
         up = torch.empty((N, w.shape[0], H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
         up[:, :, 1::2, 1::2] = dy
         return _conv_call(up, _transposed_weight(w), w.shape[1]), None, None
@@ -302,9 +334,12 @@ class _DownsampleAsym(torch.autograd.Function):
 def downsample_asym(x, w, bias):
     """Differentiable VAE downsample.  The dilated-gradient route is used where it wins (measured: the 128-channel
     level; at 256 / 512 channels the library's backward-data kernels are as fast)."""
-    if (fusable(x) and x.requires_grad and torch.is_grad_enabled() and not w.requires_grad and w.shape[0] % 64 == 0 and
-            w.shape[0] <= 128 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and w.is_contiguous(memory_format=torch.channels_last)):
-        return _DownsampleAsym.apply(x, w, bias)
+    if (fusable(x) and not w.requires_grad and w.shape[0] % 64 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and
+            w.is_contiguous(memory_format=torch.channels_last)):
+        if x.requires_grad and torch.is_grad_enabled():
+            return _DownsampleAsym.apply(x, w, bias)
+        if _conv_s2_supported(x, w):
+            return _conv_s2_call(x, w, bias, 0)
     return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
 
 

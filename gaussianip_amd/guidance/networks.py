@@ -255,7 +255,7 @@ class Downsample(nn.Module):
     def forward(self, x):
         if self.asymmetric:
             return fused.downsample_asym(x, self.conv.weight, self.conv.bias)
-        return self.conv(x)
+        return fused.downsample_sym(x, self.conv.weight, self.conv.bias)
 
 
 class Upsample(nn.Module):

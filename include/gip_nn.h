@@ -52,6 +52,13 @@ int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const v
                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The same kernel at stride 2 (diffusers Downsample2D): out [N, Hin/2, Win/2, Cout]; pad_top / pad_left = 1 with the
+ * symmetric padding of the U-Net / ControlNet (padding=1), 0 for the VAE's F.pad(x, (0, 1, 0, 1)) + padding=0 form (the
+ * missing bottom / right rows are the usual out-of-range zeros).  Hin, Win even. */
+int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin, int32_t Win,
+                           int32_t Cin, int32_t Cout, int32_t pad_top, int32_t pad_left, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* nn.Linear on the same MFMA machinery (TAPS = 1): out[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]) (+ residual[m][n]),
  * x [M,K], w [Nout,K] (torch Linear weight), out [M,Nout] half, fp32 accumulation, K % 64 == 0.  geglu != 0: w has
  * 2*Nout rows [value | gate], bias 2*Nout, out = (xWv + bv) * gelu(xWg + bg) — diffusers' GEGLU feed-forward input

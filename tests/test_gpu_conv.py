@@ -87,3 +87,30 @@ def test_conv_in_gradient_through_the_padded_mfma_convolution():
     (dx,) = torch.autograd.grad(y, x, dy)
     dxr = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), padding=1)
     assert dx.shape == x.shape and float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())
+
+
+@pytest.mark.parametrize("N,C,Co,H,W,pad", [(12, 320, 320, 64, 64, 1), (12, 1280, 1280, 16, 16, 1), (4, 128, 128, 64, 48, 0),
+                                            (2, 256, 256, 34, 18, 0), (3, 64, 72, 10, 6, 1)])
+def test_stride2_convolution(N, C, Co, H, W, pad, monkeypatch):
+    """gip_conv3x3s2_nhwc_f16: symmetric padding=1 (U-Net Downsample2D) and the VAE's pad(0,1,0,1) form."""
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setattr(fused, "_MIN_CONV_TILES", 0)
+    g = torch.Generator(device="cuda").manual_seed(C + H + pad)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(Co, C, 3, 3, device="cuda", generator=g) / (3 * C ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(Co, device="cuda", generator=g).half()
+    with torch.no_grad():
+        got = fused.downsample_sym(x, w, b) if pad else fused.downsample_asym(x, w, b)
+    xin = x.float() if pad else F.pad(x.float(), (0, 1, 0, 1))
+    ref = F.conv2d(xin, w.float(), b.float(), stride=2, padding=pad)
+    assert got.shape == ref.shape and float((got.float() - ref).abs().max()) <= 1.5e-3 * float(ref.abs().max())
+    if not pad and Co % 64 == 0:          # differentiable VAE form: forward through the kernel, gradient checked too
+        xg = x.clone().requires_grad_(True)
+        y = fused.downsample_asym(xg, w, b)
+        dy = torch.randn(y.shape, device="cuda", generator=g).half().contiguous(**cl)
+        (dx,) = torch.autograd.grad(y, xg, dy)
+        xr = x.float().requires_grad_(True)
+        (dxr,) = torch.autograd.grad(F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.float(), b.float(), stride=2), xr, dy.float())
+        assert float((y.float() - ref).abs().max()) <= 1.5e-3 * float(ref.abs().max())
+        assert float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())
