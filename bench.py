@@ -201,7 +201,13 @@ def main():
                 ro.backward(gc_h, gd_h, None)
                 tt += time.perf_counter() - c1
                 reps += 1
-            cpu = {"value": round(reps * H * W / tt / 1e6, 3), "unit": "Mpix/s", "cores": ncores, "kind": "port",
+            model = ""
+            try:
+                with open("/proc/cpuinfo") as f:
+                    model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+            except OSError:
+                pass
+            cpu = {"value": round(reps * H * W / tt / 1e6, 3), "unit": "Mpix/s", "cores": ncores, "cpu_model": model, "kind": "port",
                    "sample": "%d x (1 view fwd+bwd, P=%d, %dx%d) on the C oracle, OpenMP over tiles" % (reps, P, H, W)}
 
         out = {"metric": "raster_fwd_bwd_mpix_per_s", "value": round(mpix_s, 2), "unit": "Mpix/s", "n_gpus": world,
