@@ -62,7 +62,11 @@ class StableDiffusionGuidance:
     registry_name = "ipa-guidance"
 
     def __init__(self, cfg: Optional[GuidanceConfig] = None, device="cuda", unet=None, controlnet=None, vae=None,
-                 schedule: Optional[AHDSSchedule] = None):
+                 schedule: Optional[AHDSSchedule] = None, checkpoints: Optional[dict] = None):
+        """`checkpoints` (optional): {"unet": path, "controlnet": path, "vae": path, "ip_adapter": path} — diffusers-format
+        .safetensors / .bin files (runwayml/stable-diffusion-v1-5 unet, lllyasviel/control_v11p_sd15_openpose,
+        stabilityai/sd-vae-ft-mse, h94/IP-Adapter-FaceID ip-adapter-faceid-plusv2_sd15.bin; the names the reference loads at
+        ipa_guidance.py:127-185).  Without it the networks keep their deterministic random initialisation."""
         self.cfg = cfg or GuidanceConfig()
         self.device = torch.device(device)
         self.weights_dtype = torch.float16 if self.cfg.half_precision_weights else torch.float32
@@ -70,6 +74,8 @@ class StableDiffusionGuidance:
         self.unet = unet if unet is not None else init_for_benchmark(UNet(128, True, scale), self.cfg.seed)
         self.controlnet = controlnet if controlnet is not None else init_for_benchmark(ControlNet(), self.cfg.seed + 1)
         self.vae = vae if vae is not None else init_for_benchmark(VAEEncoder(), self.cfg.seed + 2)
+        if checkpoints:
+            self.load_checkpoints(**checkpoints)          # real weights: before the LoRA branches are folded away
         if self.cfg.fold_lora:
             self.unet.fold_lora(1.0)
         for m in (self.unet, self.controlnet, self.vae):
@@ -86,6 +92,21 @@ class StableDiffusionGuidance:
         self.ahds_chosen_t_min = self.schedule.t_min
         z = torch.zeros(1, IP_TOKENS, 768, device=self.device, dtype=self.weights_dtype)
         self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = z, z, z
+
+    def load_checkpoints(self, unet=None, controlnet=None, vae=None, ip_adapter=None):
+        from . import checkpoints as ck
+
+        def read(path):
+            return ck.load_safetensors(path) if str(path).endswith(".safetensors") else torch.load(path, map_location="cpu")
+        if unet:
+            ck.load_diffusers_state_dict(self.unet, read(unet), "unet")
+        if controlnet:
+            ck.load_diffusers_state_dict(self.controlnet, read(controlnet), "controlnet")
+        if vae:
+            ck.load_diffusers_state_dict(self.vae, read(vae), "vae_encoder")
+        if ip_adapter:
+            state = read(ip_adapter)
+            ck.load_ip_adapter_faceid(self.unet, state.get("ip_adapter", state))
 
     def set_image_embeds(self, pos, neg, null):
         """[1 or B, 4, 768] face-ID image tokens: pos = identity, null = irrelevant face, neg = zeros

@@ -12,8 +12,8 @@ this file states the same architectures directly (channel widths, block order, t
     base projections once (`fold_lora`), and the text / image-token cross-attentions of LoRAIPAttnProcessor2_0
     (:462-500) run as two SDPA calls on one projected query: `h = SDPA(q, k_text, v_text) + scale * SDPA(q, k_ip, v_ip)`.
 
-State-dict keys follow diffusers' naming closely enough that `load_diffusers_state_dict` can map real checkpoints
-(conv / linear / norm names are identical inside each block; only container names differ).
+Real checkpoints load through `checkpoints.load_diffusers_state_dict` / `load_ip_adapter_faceid` (conv / linear /
+norm names are identical inside each block; only container names differ; tensor counts equal diffusers': 686 / 340 / 248).
 
 GEMMs / convolutions go to hipBLASLt / MIOpen through PyTorch (the library path the task statement allows for plain
 GEMM-shaped work); attention is torch SDPA.

@@ -162,3 +162,64 @@ def test_refine_tables_ddim_and_attention_state_machine():
     assert "v1" not in att.refine.stored_zt or att.refine.stored_zt["v1"] == []       # non-key views store nothing
     ctl.state = "normal"
     assert torch.allclose(att(xs["front"][0]), att.to_out(plain(xs["front"][0], xs["front"][0])), atol=1e-5)
+
+
+def test_checkpoint_key_translation_tables():
+    """diffusers <-> this repo's parameter names: the tensor counts are diffusers' own (686 / 340 / 108 + 140 = 248 /
+    288 IP-Adapter-FaceID entries), every translated key is unique, well-known diffusers keys are hit, and a
+    diffusers-format dict round-trips through the loader."""
+    from gaussianip_amd.guidance import checkpoints as ck
+    from gaussianip_amd.guidance.networks import ControlNet, UNet, VAEDecoder, VAEEncoder
+    with torch.device("meta"):
+        nets = {"unet": UNet(0, False, 1.0), "controlnet": ControlNet(), "vae_encoder": VAEEncoder(), "vae_decoder": VAEDecoder()}
+        full = UNet(128, True, 0.5)
+    counts = {"unet": 686, "controlnet": 340, "vae_encoder": 108, "vae_decoder": 140}
+    known = {
+        "unet": ["time_embedding.linear_1.weight", "conv_in.bias", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.bias",
+                 "down_blocks.3.resnets.1.time_emb_proj.weight", "down_blocks.2.downsamplers.0.conv.weight",
+                 "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", "mid_block.resnets.1.conv2.bias",
+                 "up_blocks.0.upsamplers.0.conv.weight", "up_blocks.3.attentions.2.proj_out.weight",
+                 "up_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight", "up_blocks.2.resnets.2.conv_shortcut.weight",
+                 "up_blocks.3.attentions.1.transformer_blocks.0.ff.net.2.bias", "conv_norm_out.weight", "conv_out.weight"],
+        "controlnet": ["controlnet_cond_embedding.conv_in.weight", "controlnet_cond_embedding.blocks.5.bias",
+                       "controlnet_cond_embedding.conv_out.weight", "controlnet_down_blocks.11.weight", "controlnet_mid_block.bias",
+                       "down_blocks.1.attentions.1.transformer_blocks.0.norm3.weight", "mid_block.attentions.0.proj_in.weight"],
+        "vae_encoder": ["encoder.conv_in.weight", "encoder.down_blocks.1.resnets.0.conv_shortcut.weight",
+                        "encoder.down_blocks.2.downsamplers.0.conv.bias", "encoder.mid_block.attentions.0.group_norm.weight",
+                        "encoder.mid_block.attentions.0.to_out.0.weight", "encoder.conv_norm_out.bias", "quant_conv.weight"],
+        "vae_decoder": ["post_quant_conv.bias", "decoder.conv_in.weight", "decoder.up_blocks.2.resnets.0.conv_shortcut.weight",
+                        "decoder.up_blocks.0.upsamplers.0.conv.weight", "decoder.up_blocks.3.resnets.2.norm2.bias",
+                        "decoder.mid_block.attentions.0.to_q.bias", "decoder.conv_out.bias"],
+    }
+    for kind, net in nets.items():
+        keys = list(net.state_dict().keys())
+        mapped = [ck.diffusers_key(kind, k) for k in keys]
+        assert len(keys) == counts[kind] and len(set(mapped)) == len(mapped), kind
+        assert not [k for k in known[kind] if k not in set(mapped)], (kind, [k for k in known[kind] if k not in set(mapped)])
+        assert not [m for m in mapped if re_search_ours(m)], kind
+    # IP-Adapter-FaceID: 32 processors x 4 LoRA pairs + 16 x (to_k_ip, to_v_ip); cross-attention processors are the odd ones
+    table = ck.ip_adapter_key_map(full)
+    assert len(table) == 288 and len(set(table.values())) == 288
+    assert table["1.to_k_ip.weight"] == "down_attn.0.block.attn2.to_k_ip.weight"
+    assert table["0.to_q_lora.down.weight"] == "down_attn.0.block.attn1.lora_q.0.weight"
+    assert table["12.to_out_lora.up.weight"] == "up_attn.3.block.attn1.lora_out.1.weight"          # first up-block processor
+    assert table["31.to_v_ip.weight"] == "mid_attn.block.attn2.to_v_ip.weight"                    # mid block comes last
+    assert set(table.values()) == {k for k in full.state_dict() if ".lora_" in k or "_ip." in k}
+    # round trip on a small real module: VAE encoder
+    src = VAEEncoder()
+    fake = {ck.diffusers_key("vae_encoder", k): v.clone() for k, v in src.state_dict().items()}
+    old = {k.replace("attentions.0.to_q.", "attentions.0.query.").replace("attentions.0.to_out.0.", "attentions.0.proj_attn."): v
+           for k, v in fake.items()}                                                              # pre-0.18 attention names
+    for d in (fake, old):
+        dst = VAEEncoder()
+        assert ck.load_diffusers_state_dict(dst, d, "vae_encoder") == []
+        assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    with pytest.raises(KeyError):
+        ck.load_diffusers_state_dict(VAEEncoder(), {}, "vae_encoder")
+
+
+def re_search_ours(mapped_key):
+    """True if a translated key still contains one of this repo's own module names (an untranslated segment)."""
+    import re
+    return re.search(r"(down_res|down_attn|down_sample|up_res|up_attn|up_sample|mid_res|mid_attn|mid_norm|\.block\.|ff_in|ff_out|"
+                     r"time_l[12]|cond_stem|zero_convs|mid_zero|^res\.|^down\.|^up\.)", mapped_key) is not None
