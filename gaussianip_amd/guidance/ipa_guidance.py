@@ -108,6 +108,19 @@ class StableDiffusionGuidance:
             state = read(ip_adapter)
             ck.load_ip_adapter_faceid(self.unet, state.get("ip_adapter", state))
 
+    def prepare_for_sds(self, prompt=None, negative_prompt=None, null_prompt=None, image_embeds=None):
+        """Same entry point as ipa_guidance.py:236-275.  The reference runs insightface FaceAnalysis + the IP-Adapter
+        image projection here to turn the identity photo into (pos, null, neg) image-token triples; those models are the
+        caller's (not shippable, not on the per-step path), so the triple is passed in: image_embeds = (pos, neg, null),
+        each [1 or B, 4, 768].  The text prompts are accepted for signature compatibility (they are consumed by the
+        prompt processor, `prompt_utils`, exactly as in the reference)."""
+        if image_embeds is None:
+            raise ValueError("prepare_for_sds: pass image_embeds=(pos, neg, null) image-prompt tokens "
+                             "(face-ID analysis and the IP-Adapter image projection run outside this package)")
+        self.set_image_embeds(*image_embeds)
+        self.bs_embed, self.seq_len = self.pos_image_embeds.shape[0], self.pos_image_embeds.shape[1]
+        self.num_samples = self.cfg.batch_size if hasattr(self.cfg, "batch_size") else 1
+
     def set_image_embeds(self, pos, neg, null):
         """[1 or B, 4, 768] face-ID image tokens: pos = identity, null = irrelevant face, neg = zeros
         (ip_adapter_faceid.py:362-382, ipa_guidance.py:250-257)."""
