@@ -9,7 +9,7 @@ Differences: networks come from gaussianip_amd.guidance.networks (no diffusers d
 dicts are supplied); text / face-ID embeddings are inputs (`PromptEmbeddings`, `set_image_embeds`) because CLIP,
 insightface and the checkpoints are outside this path; the frozen LoRA is folded into the base weights once.
 """
-from dataclasses import dataclass
+from dataclasses import dataclass, field, fields
 from typing import Any, Optional
 
 import torch
@@ -39,6 +39,29 @@ class GuidanceConfig:
     fold_lora: bool = True
     channels_last: bool = True    # NHWC end to end: MIOpen's MFMA igemm layout + the fused GroupNorm(+SiLU) kernels
     seed: int = 0
+    extra: dict = field(default_factory=dict)     # reference keys that do not reach the per-step path (paths, prompts, ...)
+
+    # every key of the reference's Config (ipa_guidance.py:74-123) that this class does not model itself
+    _PASSIVE = ("pretrained_sd_model_name_or_path", "pretrained_realistic_model_name_or_path", "vae_path", "image_encoder_path",
+                "image_encoder_faceid_path", "ip_ckpt_path", "ip_ckpt_faceid_v1_path", "ip_ckpt_faceid_v2_path",
+                "pose_controlnet_path", "prompt", "negative_prompt", "negative_prompt_faceid", "null_prompt", "pil_image_path",
+                "pil_image_faceid_path", "irr_pil_image_path", "enable_memory_efficient_attention",
+                "enable_sequential_cpu_offload", "enable_attention_slicing", "enable_channels_last_format",
+                "ipa_faceid_s_scale", "grad_clip", "max_items_eval", "lw_depth", "original_size", "target_size")
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "GuidanceConfig":
+        """Build from the `system.guidance` section of the reference's YAML (configs/exp.yaml:78-120): the keys the
+        per-step path reads become fields, the remaining reference keys are kept in `extra`, unknown keys raise."""
+        names = {f.name for f in fields(cls)} - {"extra"}
+        own = {k: v for k, v in d.items() if k in names}
+        rest = {k: v for k, v in d.items() if k not in names}
+        unknown = [k for k in rest if k not in cls._PASSIVE]
+        if unknown:
+            raise KeyError("unknown guidance config keys: %s" % unknown)
+        if "enable_channels_last_format" in rest:
+            own.setdefault("channels_last", bool(rest["enable_channels_last_format"]) or True)
+        return cls(**own, extra=rest)
 
 
 class PromptEmbeddings:

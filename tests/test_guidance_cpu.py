@@ -223,3 +223,21 @@ def re_search_ours(mapped_key):
     import re
     return re.search(r"(down_res|down_attn|down_sample|up_res|up_attn|up_sample|mid_res|mid_attn|mid_norm|\.block\.|ff_in|ff_out|"
                      r"time_l[12]|cond_stem|zero_convs|mid_zero|^res\.|^down\.|^up\.)", mapped_key) is not None
+
+
+def test_guidance_config_accepts_the_reference_yaml_section():
+    """Every key of `system.guidance` in configs/exp.yaml:78-120 is accepted: per-step keys become fields, the rest is kept."""
+    from gaussianip_amd.guidance import GuidanceConfig
+    section = {k: None for k in (
+        "batch_size enable_memory_efficient_attention grad_clip grad_clip_pixel grad_clip_threshold guidance_rescale guidance_scale "
+        "image_encoder_faceid_path image_encoder_path ip_ckpt_faceid_v1_path ip_ckpt_faceid_v2_path ip_ckpt_path ipa_faceid_s_scale "
+        "ipa_faceid_scale ipa_scale irr_pil_image_path lw_depth negative_prompt negative_prompt_faceid null_prompt original_size "
+        "pil_image_faceid_path pose_controlnet_path pretrained_realistic_model_name_or_path pretrained_sd_model_name_or_path prompt "
+        "target_size use_anpg use_ipa_faceid use_pose_controlnet vae_path view_dependent_prompting weighting_strategy").split()}
+    section.update(batch_size=4, grad_clip_pixel=True, grad_clip_threshold=1.0, guidance_rescale=0.75, guidance_scale=7.5,
+                   ipa_faceid_scale=0.5, ipa_scale=0.6, use_anpg=True, use_ipa_faceid=True, use_pose_controlnet=True,
+                   view_dependent_prompting=True, weighting_strategy="sds")
+    cfg = GuidanceConfig.from_dict(section)
+    assert cfg.use_anpg and cfg.guidance_rescale == 0.75 and cfg.grad_clip_threshold == 1.0 and "vae_path" in cfg.extra
+    with pytest.raises(KeyError):
+        GuidanceConfig.from_dict({"not_a_reference_key": 1})
