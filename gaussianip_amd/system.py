@@ -41,6 +41,27 @@ class StageOneConfig:
     lambda_opaque: float = 0.0
     disable_hand_densification: bool = False
     hand_radius: float = 0.05
+    # refine (VCR) orbit and stage 3, configs/exp.yaml:150-160
+    refine_n_views: int = 32
+    refine_elevation: float = 17.0
+    refine_camera_distance: float = 1.5
+    refine_fovy_deg: float = 70.0
+    refine_train_bs: int = 4
+    lambda_l1: float = 10.0
+    lambda_lpips: float = 15.0
+    extra: dict = None
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "StageOneConfig":
+        """Build from the `system` section of the reference's YAML (configs/exp.yaml:122-170): scheduling / threshold keys
+        become fields, `loss.{lambda_sds, lambda_sparsity, lambda_opaque}` are lifted, everything else is kept in `extra`."""
+        from dataclasses import fields
+        names = {f.name for f in fields(cls)} - {"extra"}
+        own = {k: v for k, v in d.items() if k in names}
+        for k, v in (d.get("loss") or {}).items():
+            if k in names:
+                own[k] = v
+        return cls(**own, extra={k: v for k, v in d.items() if k not in names})
 
 
 def binary_cross_entropy(inp, target):
@@ -151,3 +172,28 @@ class StageThreeStep:
         if self.perceptual is not None and self.lambda_lpips:
             loss = loss + self.lambda_lpips * self.perceptual(small, gt).mean()
         return {"loss": loss, "render_pkg": pkg, "id_list": id_list}
+
+
+def create_refine_batch(n_views=32, elevation_deg=17.0, camera_distance=1.5, fovy_deg=70.0, height=1024, width=1024):
+    """The fixed orbit of the refine stage (GaussianIP.create_refine_batch, GaussianIP.py:232-281): azimuth
+    linspace(-180, 180, n + 1)[:n], constant elevation / distance / fovy, look-at the origin with +z up.  Returns the
+    reference's dict (c2w [n,4,4], azimuth, elevation, fovy in radians, height, width, center); mvp matrices are left to
+    the caller's projection helper, as are the Camera objects (`[Camera(c2w=b["c2w"][i], FoVy=b["fovy"][i], ...)]`)."""
+    import math
+    import torch.nn.functional as F
+    az_deg = torch.linspace(-180.0, 180.0, n_views + 1)[:n_views]
+    az = az_deg * math.pi / 180
+    el_deg = torch.full_like(az_deg, float(elevation_deg))
+    el = el_deg * math.pi / 180
+    dist = torch.full_like(az_deg, float(camera_distance))
+    pos = torch.stack([dist * torch.cos(el) * torch.cos(az), dist * torch.cos(el) * torch.sin(az), dist * torch.sin(el)], dim=-1)
+    center = torch.zeros_like(pos)
+    up = torch.as_tensor([0.0, 0.0, 1.0])[None, :].repeat(n_views, 1)
+    lookat = F.normalize(center - pos, dim=-1)
+    right = F.normalize(torch.cross(lookat, up, dim=-1), dim=-1)
+    up = F.normalize(torch.cross(right, lookat, dim=-1), dim=-1)
+    c2w3x4 = torch.cat([torch.stack([right, up, -lookat], dim=-1), pos[:, :, None]], dim=-1)
+    c2w = torch.cat([c2w3x4, torch.zeros_like(c2w3x4[:, :1])], dim=1)
+    c2w[:, 3, 3] = 1.0
+    fovy = torch.full_like(az_deg, float(fovy_deg)) * math.pi / 180
+    return {"c2w": c2w, "center": center[:, 2], "elevation": el_deg, "azimuth": az_deg, "height": height, "width": width, "fovy": fovy}

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -268,3 +269,22 @@ def test_c_abi_library_exports_every_declared_symbol():
         other = loader()
         for sym in set(re.findall(r"\b(gip_[a-z_0-9]+)\s*\(", open(os.path.join(root, "include", header)).read())):
             assert hasattr(other, sym), (header, sym)
+
+
+def test_refine_orbit_and_system_config_from_yaml_keys():
+    """create_refine_batch (GaussianIP.py:232-281) geometry and StageOneConfig.from_dict on the reference's system keys."""
+    from gaussianip_amd.system import StageOneConfig, create_refine_batch
+    b = create_refine_batch()
+    c2w = b["c2w"]
+    assert c2w.shape == (32, 4, 4) and b["azimuth"][0] == -180.0 and abs(float(b["azimuth"][1] - b["azimuth"][0]) - 11.25) < 1e-5
+    R = c2w[:, :3, :3]
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(32, 3, 3), atol=1e-5)
+    pos = c2w[:, :3, 3]
+    assert torch.allclose(pos.norm(dim=-1), torch.full((32,), 1.5), atol=1e-5)
+    assert torch.allclose(pos[:, 2], torch.full((32,), 1.5 * math.sin(math.radians(17.0))), atol=1e-5)
+    assert torch.allclose(F.normalize(-pos, dim=-1), -R[:, :, 2], atol=1e-5)            # the camera looks at the origin (-z forward)
+    assert torch.allclose(b["fovy"], torch.full((32,), math.radians(70.0)))
+    cfg = StageOneConfig.from_dict({"densify_prune_start_step": 100, "max_grad": 3e-4, "refine_n_views": 16, "pts_num": 100000,
+                                    "loss": {"lambda_sds": 2.0, "lambda_sparsity": 0.5, "lambda_opaque": 0, "scale_tau": 2}, "stage": "stage1"})
+    assert cfg.densify_prune_start_step == 100 and cfg.max_grad == 3e-4 and cfg.lambda_sds == 2.0 and cfg.lambda_sparsity == 0.5
+    assert cfg.refine_n_views == 16 and cfg.extra["pts_num"] == 100000 and "loss" in cfg.extra
