@@ -140,7 +140,7 @@ _nn = None
 def nn_lib():
     global _nn
     if _nn is None:
-        path = os.path.join(LIB_DIR, "libgip_nn.so")
+        path = os.path.join(LIB_DIR, os.environ.get("GIP_NN_LIB", "libgip_nn.so"))
         if not os.path.exists(path):
             raise _missing("libgip_nn.so")
         lib = ctypes.CDLL(path)
