@@ -215,7 +215,7 @@ static size_t reduce_lds_bytes(int C) {
 
 static int pick_splits(int N, long long HW, int C) {
   // enough workgroups to fill the chip (256 CUs x a few), at least 8 rows each
-  long long want = (2048 + N - 1) / N;
+  long long want = (1024 + N - 1) / N;
   long long by_rows = (HW + 7) / 8;
   long long s = want < by_rows ? want : by_rows;
   if (s < 1) s = 1;
@@ -330,5 +330,87 @@ extern "C" int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* 
   if (!in || !out || M < 1 || D < 8 || (D & 7)) return 1;
   hipLaunchKernelGGL(geglu_kernel, dim3(grid_for((long long)M * (D >> 3))), dim3(256), 0, (hipStream_t)stream,
                      (const half8*)in, (half8*)out, (long long)M, D >> 3);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension of [M, C] half rows (BasicTransformerBlock.norm1/2/3): y = (x - mean) * rstd * w + b.
+// HBM-bound: each row is read once into registers and written once.  A row is owned by a 16-lane group (one DPP row), so
+// a wave covers 4 rows and every load instruction fetches 256 contiguous bytes per row; ITER = ceil(C / 128) half8 chunks
+// per lane are all issued before the first is consumed (up to 10 x 16 B in flight per lane at C = 1280).  Statistics are
+// two-pass in fp32 on the register copy (exact mean first, then centred squares).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ITER>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const half8* __restrict__ x, const __half* __restrict__ w, const __half* __restrict__ b,
+                 half8* __restrict__ y, long long M, int C8, float invC, float eps) {
+  const int sub = threadIdx.x & 15;
+  const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= M) return;                       // whole 16-lane groups leave together; the shuffles below stay inside a group
+  const half8* xr = x + row * C8;
+  half8 v[ITER];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int c = i * 16 + sub;
+    if (c < C8) v[i] = xr[c];
+  }
+  float f[ITER][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int c = i * 16 + sub;
+    if (c < C8) {
+      unpack8(v[i], f[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum += f[i][k];
+    }
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+  const float mean = sum * invC;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int c = i * 16 + sub;
+    if (c < C8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { f[i][k] -= mean; sq += f[i][k] * f[i][k]; }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 16);
+  const float rstd = rsqrtf(sq * invC + eps);
+  half8* yr = y + row * C8;
+  const half8* w8 = (const half8*)w;
+  const half8* b8 = (const half8*)b;
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int c = i * 16 + sub;
+    if (c < C8) {
+      float g[8], be[8], o[8];
+      unpack8(w8[c], g);
+      unpack8(b8[c], be);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = f[i][k] * rstd * g[k] + be[k];
+      yr[c] = pack8(o);
+    }
+  }
+}
+
+extern "C" int gip_layernorm_f16(const void* x, const void* weight, const void* bias, void* y, int64_t M, int32_t C,
+                                 float eps, void* stream) {
+  if (!x || !weight || !bias || !y || M < 1 || C < 8 || (C & 7) || C > 2048 || M > (1ll << 34)) return 1;
+  const int C8 = C >> 3, iter = (C8 + 15) >> 4;
+  const dim3 grid((unsigned)((M + 15) >> 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define GIP_LN(I)                                                                                                       \
+  hipLaunchKernelGGL((layernorm_kernel<I>), grid, block, 0, s, (const half8*)x, (const __half*)weight,                  \
+                     (const __half*)bias, (half8*)y, (long long)M, C8, 1.0f / (float)C, eps)
+  if (iter <= 3) GIP_LN(3);
+  else if (iter <= 5) GIP_LN(5);
+  else if (iter <= 10) GIP_LN(10);
+  else GIP_LN(16);
+#undef GIP_LN
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -144,6 +144,25 @@ def geglu(x):
     return a * F.gelu(g)
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm over the last dimension with the same parameters and state_dict keys; frozen fp16 inference on the
+    GPU runs csrc/groupnorm.hip's one-read-one-write row kernel (BasicTransformerBlock.norm1 / norm2 / norm3)."""
+
+    def forward(self, x):
+        C = x.shape[-1]
+        if (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and self.weight is not None and
+                self.bias is not None and self.weight.dtype == torch.float16 and len(self.normalized_shape) == 1 and
+                C % 8 == 0 and C <= 2048 and x.numel() > 0 and
+                not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
+            out = torch.empty_like(x)
+            rc = _lib.nn_lib().gip_layernorm_f16(_p(x), _p(self.weight), _p(self.bias), _p(out), x.numel() // C, C,
+                                                 float(self.eps), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("gip_layernorm_f16 failed with status %d" % rc)
+            return out
+        return super().forward(x)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # 3x3 / stride 1 / pad 1 convolution on the matrix cores (csrc/conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------------

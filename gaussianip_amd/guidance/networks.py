@@ -206,11 +206,11 @@ class Attention(nn.Module):
 class TransformerBlock(nn.Module):
     def __init__(self, dim, ctx_dim, heads, lora_rank, ip, ip_scale):
         super().__init__()
-        self.norm1 = nn.LayerNorm(dim)
+        self.norm1 = fused.LayerNorm(dim)
         self.attn1 = Attention(dim, None, heads, lora_rank)
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm2 = fused.LayerNorm(dim)
         self.attn2 = Attention(dim, ctx_dim, heads, lora_rank, ip=ip, ip_scale=ip_scale)
-        self.norm3 = nn.LayerNorm(dim)
+        self.norm3 = fused.LayerNorm(dim)
         self.ff_in = nn.Linear(dim, dim * 8)     # GEGLU: value | gate
         self.ff_out = nn.Linear(dim * 4, dim)
 
@@ -239,8 +239,9 @@ class SpatialTransformer(nn.Module):
         B, C, H, W = x.shape
         if fusable(x):      # NHWC: the 1x1 projections are GEMMs on the token view, no layout change anywhere
             t = F.linear(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
-            t = F.linear(self.block(t, ctx), self.proj_out.weight.reshape(C, C), self.proj_out.bias)
-            return x + t.reshape(B, H, W, C).permute(0, 3, 1, 2)
+            t = fused.linear(self.block(t, ctx), self.proj_out.weight.reshape(C, C), self.proj_out.bias,
+                             x.permute(0, 2, 3, 1).reshape(B, H * W, C))         # the block's residual rides in the epilogue
+            return t.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.block(h, ctx).reshape(B, H, W, C).permute(0, 3, 1, 2)
         return x + self.proj_out(h)

@@ -41,6 +41,13 @@ int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const
 int gip_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t M, int32_t C, void* stream);
 int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
 
+/* LayerNorm over the last dimension: y[m, :] = (x[m, :] - mean_m) * rstd_m * weight + bias, x / y [M, C] half, weight /
+ * bias [C] half, fp32 statistics (biased variance, like torch.nn.LayerNorm).  C % 8 == 0, C <= 2048.  Replaces the
+ * BasicTransformerBlock norm1 / norm2 / norm3 calls the reference's U-Net makes through diffusers (forward only: the
+ * denoiser is frozen in ipa_guidance.py:143-172). */
+int gip_layernorm_f16(const void* x, const void* weight, const void* bias, void* y, int64_t M, int32_t C, float eps,
+                      void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution as an MFMA implicit GEMM (csrc/conv3x3.hip): x [N,H,W,Cin] half (NHWC),
  * w [Cout,3,3,Cin] half (the channels_last memory of a torch [Cout,Cin,3,3] weight), out [N,H,W,Cout] half, fp32
  * accumulation.  Epilogue (fp32, before the single rounding to half): + bias[Cout] (NULL = none) + residual

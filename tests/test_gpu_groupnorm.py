@@ -137,3 +137,29 @@ def test_mfma_linear_residual_and_geglu_epilogues():
             ref = v * F.gelu(gate)
             got = fused.linear(x, w, b, None, True)
             assert got.shape == (M, D) and float((got.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(4096 * 3, 320), (1024 * 2 + 5, 640), (777, 1280), (64, 512), (33, 2048), (19, 8), (1, 136)])
+def test_layernorm_rows_match_torch_fp32(rows, C):
+    """csrc/groupnorm.hip layernorm_kernel (BasicTransformerBlock.norm1/2/3) against F.layer_norm in fp32 on the same
+    half inputs; tolerance = one half-precision rounding of the output."""
+    import torch.nn.functional as F
+    from gaussianip_amd.guidance import fused
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(rows + C)
+    x = (torch.randn(rows, C, device=dev, generator=g) * 2.0 + 0.7).half()
+    ln = fused.LayerNorm(C).to(dev).half().requires_grad_(False)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, device=dev, generator=g) * 0.5 + 1.0)
+        ln.bias.copy_(torch.randn(C, device=dev, generator=g) * 0.3)
+        y = ln(x.view(1, rows, C)).view(rows, C)
+        with fused.disabled():
+            assert ln(x).dtype == torch.float16                           # the library path still works
+    ref = F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps)
+    err = (y.float() - ref).abs()
+    assert float(err.max()) <= 1e-3 * float(ref.abs().max()) + 1e-3, float(err.max())
+    # training-mode inputs take the autograd path
+    xg = x.clone().requires_grad_(True)
+    ln(xg).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
