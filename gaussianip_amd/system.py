@@ -139,8 +139,10 @@ class StageOneStep:
 class StageThreeStep:
     """Stage 3 (GaussianIP.py:424-436): RGB-only reconstruction of the refined orbit images.  Renders a random subset of
     the refine cameras, crops [60:890, 220:800], halves the resolution (bilinear) and takes
-    lambda_l1 * L1 + lambda_lpips * perceptual against the equally prepared refined images.  LPIPS needs pretrained
-    VGG weights that are not shippable: `perceptual` is a callable (default None = term omitted, stated in DESIGN.md)."""
+    lambda_l1 * L1 + lambda_lpips * perceptual against the equally prepared refined images.  `perceptual` is either
+    a `guidance.perceptual.LPIPSVGG` (the reference's `lpips.LPIPS(net='vgg')`; the target images' features are then
+    computed once and kept on the device) or any callable (a, b) -> distances; None omits the term.  The pretrained
+    VGG / LPIPS weights are not shippable, so benchmarks use `LPIPSVGG().init_for_benchmark()`."""
 
     CROP = (slice(60, 890), slice(220, 800))
 
@@ -155,6 +157,9 @@ class StageThreeStep:
         gt = gt[:, :, self.CROP[0], self.CROP[1]] if gt.shape[2] >= 890 and gt.shape[3] >= 800 else gt
         self.gt_small = F.interpolate(gt, scale_factor=0.5, mode="bilinear", align_corners=False)
         self.orbit_ids = torch.as_tensor(view_idx_all)[order].tolist()
+        self.gt_feats = None
+        if perceptual is not None and lambda_lpips and hasattr(perceptual, "target_features"):
+            self.gt_feats = perceptual.target_features(self.gt_small, normalize=True)
 
     def training_step(self, id_list=None, generator=None):
         import random
@@ -170,7 +175,14 @@ class StageThreeStep:
         gt = self.gt_small[torch.as_tensor(id_list, device=self.gt_small.device)]
         loss = self.lambda_l1 * (small - gt).abs().mean()
         if self.perceptual is not None and self.lambda_lpips:
-            loss = loss + self.lambda_lpips * self.perceptual(small, gt).mean()
+            if self.gt_feats is not None:
+                sel = torch.as_tensor(id_list, device=self.gt_small.device)
+                d = self.perceptual.distance_to_features(small, [f[sel] for f in self.gt_feats], normalize=True)
+            elif hasattr(self.perceptual, "target_features"):
+                d = self.perceptual(small, gt, normalize=True)
+            else:
+                d = self.perceptual(small, gt)
+            loss = loss + self.lambda_lpips * d.mean()
         return {"loss": loss, "render_pkg": pkg, "id_list": id_list}
 
 

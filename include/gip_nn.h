@@ -48,6 +48,23 @@ int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
 int gip_layernorm_f16(const void* x, const void* weight, const void* bias, void* y, int64_t M, int32_t C, float eps,
                       void* stream);
 
+/* One LPIPS layer term against cached target features (csrc/lpips.hip); replaces, per VGG tap, the
+ * normalize_tensor -> (a - b)^2 -> lin -> spatial_average chain of `lpips.LPIPS.forward` that the reference calls at
+ * threestudio/systems/GaussianIP.py:435 (third-party `lpips` package; published LPIPS v0.1 algorithm).
+ *   feat         [N, HW, C] half  raw VGG features of the rendered images (NHWC)
+ *   target_unit  [N, HW, C] half  channel-normalised features of the fixed refined images
+ *   lin          [C] float        the layer's 1x1 weights
+ * forward : partial[n * blocks + b] = this block's share of sum_hw sum_c lin[c] (feat/(|feat|+1e-10) - target)^2 ; the
+ *           caller sums over b (fixed order: deterministic) and divides by HW.  blocks = gip_lpips_layer_blocks(N, HW).
+ * backward: grad_feat [N, HW, C] half = d(sum_hw ...)/dfeat * coef[n], saturated to the fp16 range (coef carries
+ *           gout / HW and the caller's power-of-two loss scale).
+ * C % 8 == 0, C <= 512. */
+int32_t gip_lpips_layer_blocks(int32_t N, int64_t HW);
+int gip_lpips_layer_forward(const void* feat, const void* target_unit, const float* lin, float* partial, int32_t N,
+                            int64_t HW, int32_t C, int32_t blocks, void* stream);
+int gip_lpips_layer_backward(const void* feat, const void* target_unit, const float* lin, const float* coef,
+                             void* grad_feat, int32_t N, int64_t HW, int32_t C, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution as an MFMA implicit GEMM (csrc/conv3x3.hip): x [N,H,W,Cin] half (NHWC),
  * w [Cout,3,3,Cin] half (the channels_last memory of a torch [Cout,Cin,3,3] weight), out [N,H,W,Cout] half, fp32
  * accumulation.  Epilogue (fp32, before the single rounding to half): + bias[Cout] (NULL = none) + residual

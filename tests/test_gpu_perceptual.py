@@ -1,0 +1,88 @@
+"""LPIPS-VGG (guidance/perceptual.py; GaussianIP.py:121,433-436) on the GPU: the fp16 path, whose 3x3 convolutions and
+data gradients run on the MFMA kernel, against the same weights in fp32 through plain PyTorch ops."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(seed, n=2, h=415, w=290):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    base = torch.rand(n, 3, h // 8, w // 8, device="cuda", generator=g)
+    a = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear") + 0.05 * torch.rand(n, 3, h, w, device="cuda", generator=g)
+    b = a + 0.1 * torch.randn(n, 3, h, w, device="cuda", generator=g)
+    return a.clamp(0, 1), b.clamp(0, 1)
+
+
+def test_fp16_mfma_path_matches_fp32_distance_and_gradient():
+    from gaussianip_amd.guidance import fused
+    from gaussianip_amd.guidance.perceptual import LPIPSVGG
+    ref = LPIPSVGG().init_for_benchmark(11).cuda()
+    fast = copy.deepcopy(ref).prepare_inference("cuda")
+    a, b = _pair(0)
+    a32 = a.clone().requires_grad_(True)
+    with fused.disabled():
+        d32 = ref(a32, b, normalize=True)
+        d32.sum().backward()
+    calls = {"n": 0}
+    orig = fused._conv_call
+    def counting(*args, **kw):
+        calls["n"] += 1
+        return orig(*args, **kw)
+    fused._conv_call = counting
+    try:
+        a16 = a.clone().requires_grad_(True)
+        tf = fast.target_features(b, normalize=True)
+        d16 = fast.distance_to_features(a16, tf, normalize=True)
+        d16.sum().backward()
+    finally:
+        fused._conv_call = orig
+    assert calls["n"] >= 12 + 12 + 11, "the MFMA convolution did not run (forward x2, data gradients): %d calls" % calls["n"]
+    assert d16.shape == (2, 1, 1, 1)
+    rel = float(((d16 - d32).abs() / d32.abs()).max())
+    assert rel < 2e-2, rel                                     # fp16 features, fp32 distance
+    ga, gr = a16.grad.float(), a32.grad.float()
+    cos = float((ga * gr).sum() / (ga.norm() * gr.norm()))
+    assert cos > 0.995 and abs(float(ga.norm() / gr.norm()) - 1.0) < 3e-2, (cos, float(ga.norm() / gr.norm()))
+
+
+@pytest.mark.parametrize("N,H,W,C", [(4, 415, 290, 64), (2, 103, 72, 256), (3, 25, 18, 512), (1, 7, 5, 128), (2, 33, 1, 8)])
+def test_layer_kernels_match_fp32_autograd(N, H, W, C):
+    """gip_lpips_layer_forward / _backward (csrc/lpips.hip) against the elementwise fp32 formula and its autograd
+    gradient on the same fp16 tensors, including pixels whose features are all zero (ReLU output)."""
+    import ctypes
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance.fused import _p
+    lib = _lib.nn_lib()
+    g = torch.Generator(device="cuda").manual_seed(N * 1000 + C)
+    f = torch.relu(torch.randn(N, C, H, W, device="cuda", generator=g)).half().contiguous(memory_format=torch.channels_last)
+    f[:, :, 0, 0] = 0                                                       # an all-zero pixel per sample
+    t = torch.relu(torch.randn(N, C, H, W, device="cuda", generator=g))
+    t = (t / (t.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)).half().contiguous(memory_format=torch.channels_last)
+    lin = (torch.rand(C, device="cuda", generator=g) * (2.0 / C)).contiguous()
+    HW = H * W
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    blocks = lib.gip_lpips_layer_blocks(N, HW)
+    partial = torch.empty(N, blocks, device="cuda")
+    assert lib.gip_lpips_layer_forward(_p(f), _p(t), _p(lin), _p(partial), N, HW, C, blocks, stream) == 0
+    got = partial.sum(1) / HW
+    f32 = f.float().requires_grad_(True)
+    u = f32 / (f32.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    want = ((u - t.float()) ** 2 * lin.view(1, C, 1, 1)).sum(1).mean((1, 2))
+    assert torch.allclose(got, want, rtol=2e-5, atol=1e-9), (got, want)
+    gout = torch.rand(N, device="cuda", generator=g) + 0.5
+    scale = 2.0 ** 16
+    (want * gout).sum().backward()
+    coef = (gout * scale / HW).contiguous()
+    gf = torch.empty_like(f)
+    assert lib.gip_lpips_layer_backward(_p(f), _p(t), _p(lin), _p(coef), _p(gf), N, HW, C, stream) == 0
+    ref = f32.grad * scale
+    nz = f.float().pow(2).sum(1, keepdim=True) > 0                           # |f| = 0 pixels: 1/eps branch, saturated here
+    zero = torch.zeros_like(ref)                                             # (autograd's sqrt'(0) makes the reference NaN there)
+    err = torch.where(nz, gf.float() - ref, zero).abs().max()
+    top = torch.where(nz, ref, zero).abs().max()
+    assert float(err) <= 2e-3 * float(top) + 1e-6, (float(err), float(top))
+    assert torch.isfinite(gf.float()).all()
+    assert gf.is_contiguous(memory_format=torch.channels_last)

@@ -297,3 +297,36 @@ def test_stage_three_rgb_reconstruction_step_descends():
         gm.optimizer.step()
         losses.append(float(out["loss"]))
     assert losses[-1] < losses[0], losses
+
+
+def test_stage_three_step_with_lpips_term():
+    """StageThreeStep with lambda_l1 = 10, lambda_lpips = 15 (configs/exp.yaml:125-126) and the LPIPS-VGG restatement
+    (guidance/perceptual.py): target features cached once in fp16, the loss exceeds the L1-only loss, its gradient
+    reaches the Gaussians through the MFMA convolution's data-gradient path."""
+    from argparse import ArgumentParser
+    from gaussianip_amd.arguments import OptimizationParams, PipelineParams
+    from gaussianip_amd.guidance.perceptual import LPIPSVGG
+    from gaussianip_amd.scene import GaussianModel
+    from gaussianip_amd.system import StageThreeStep
+    from gaussianip_amd.utils import BasicPointCloud
+    rng = np.random.default_rng(6)
+    P = 20000
+    pts = scenes.human_points(P, rng).astype(np.float32)
+    gm = GaussianModel(0)
+    gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
+    gm.training_setup(OptimizationParams(ArgumentParser()))
+    pipe = PipelineParams(ArgumentParser())
+    bg = torch.ones(3, device="cuda")
+    cams = [_camera(17.0, -180.0 + 90.0 * i, 1.5, 70.0, 1024, 1024) for i in range(4)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    refined = torch.rand(4, 1024, 1024, 3, device="cuda", generator=g)
+    lp = LPIPSVGG().init_for_benchmark(2).prepare_inference("cuda")
+    order = [2, 0, 3, 1]
+    st3 = StageThreeStep(gm, pipe, bg, cams, refined, order, lambda_l1=10.0, lambda_lpips=15.0, perceptual=lp, train_bs=2)
+    assert st3.gt_feats is not None and st3.gt_feats[0].shape == (4, 64, 415, 290) and st3.gt_feats[0].dtype == torch.float16
+    out = st3.training_step(id_list=[1, 3])
+    plain = StageThreeStep(gm, pipe, bg, cams, refined, order, lambda_l1=10.0, lambda_lpips=0.0, train_bs=2).training_step(id_list=[1, 3])
+    assert float(out["loss"]) > float(plain["loss"]) > 0
+    gm.optimizer.zero_grad(set_to_none=True)
+    out["loss"].backward()
+    assert float(gm._features_dc.grad.abs().max()) > 0 and torch.isfinite(gm._xyz.grad).all()

@@ -241,3 +241,44 @@ def test_guidance_config_accepts_the_reference_yaml_section():
     assert cfg.use_anpg and cfg.guidance_rescale == 0.75 and cfg.grad_clip_threshold == 1.0 and "vae_path" in cfg.extra
     with pytest.raises(KeyError):
         GuidanceConfig.from_dict({"not_a_reference_key": 1})
+
+
+def test_lpips_vgg_restatement_properties_and_state_dict_names():
+    """guidance/perceptual.py (GaussianIP.py:121,433-436): LPIPS-VGG algebra against a second, loop-written statement
+    of the published algorithm on the same weights; identity / symmetry; the lpips package's parameter names."""
+    import torch.nn.functional as F
+    from gaussianip_amd.guidance.perceptual import LPIPSVGG
+    m = LPIPSVGG().init_for_benchmark(3)
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.rand(2, 3, 40, 28, generator=g), torch.rand(2, 3, 40, 28, generator=g)
+    d = m(a, b, normalize=True)
+    assert d.shape == (2, 1, 1, 1) and float(d.min()) > 0
+    assert float(m(a, a, normalize=True).abs().max()) == 0.0
+    assert torch.allclose(m(b, a, normalize=True), d)
+    # direct restatement: torchvision layer order 0..28 with ReLU after each conv and pools before conv 5, 10, 17, 24
+    sd = m.state_dict()
+    def feats(x):
+        x = ((2 * x - 1) - sd["scaling_layer.shift"]) / sd["scaling_layer.scale"]
+        out = []
+        for k, ids in enumerate(((0, 2), (5, 7), (10, 12, 14), (17, 19, 21), (24, 26, 28))):
+            if k:
+                x = F.max_pool2d(x, 2, 2)
+            for i in ids:
+                x = F.relu(F.conv2d(x, sd["net.slice%d.%d.weight" % (k + 1, i)], sd["net.slice%d.%d.bias" % (k + 1, i)], padding=1))
+            out.append(x)
+        return out
+    want = 0
+    for k, (fa, fb) in enumerate(zip(feats(a), feats(b))):
+        na = fa / (fa.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+        nb = fb / (fb.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+        want = want + F.conv2d((na - nb) ** 2, sd["lin%d.model.1.weight" % k]).mean((2, 3), keepdim=True)
+    assert torch.allclose(d, want, rtol=1e-5, atol=1e-7)
+    names = set(sd)
+    assert len(names) == 2 + 26 + 5 and {"net.slice3.14.bias", "net.slice5.28.weight", "lin4.model.1.weight"} <= names
+    # cached target features give the same distance, and the gradient reaches the first argument only
+    a.requires_grad_(True)
+    tf = m.target_features(b, True, torch.float32)
+    d2 = m.distance_to_features(a, tf, True)
+    assert torch.allclose(d2, d, rtol=1e-6, atol=1e-8)
+    d2.sum().backward()
+    assert float(a.grad.abs().max()) > 0 and all(not p.requires_grad for p in m.parameters())
