@@ -111,12 +111,14 @@ def main():
         m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
         color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], sts, shs=t["shs"],
                                                      scales=t["scales"], rotations=t["rotations"])
+        if world > 1:       # the MAX bucket holds forward outputs: its all-reduce overlaps the backward
+            pending = parallel.exchange_forward_stats(radii, depth)
         grads = torch.autograd.grad([color, depth], plist + [m2d], [gC, gD])
         if world > 1:
             for p_, g_ in zip(plist, grads[:-1]):
                 p_.grad = g_
-            parallel.exchange_step(plist, grads[-1][..., :2].norm(dim=-1).sum(0), radii.max(dim=0).values,
-                                   depth.max())
+            parallel.exchange_sum(plist, torch.linalg.vector_norm(grads[-1][..., :2], dim=-1).sum(0))
+            pending.wait()
         return color
 
     for _ in range(args.warmup):

@@ -38,6 +38,20 @@ def _worker(rank, world, port, out):
     assert torch.allclose(res["viewspace_grad_norm"], sum(gathered[r]["vs"] for r in range(world)))
     assert torch.equal(res["radii"], torch.stack([gathered[r]["radii"] for r in range(world)]).max(0).values)
     assert float(res["depth_max"]) == float(world)
+    # the MAX bucket started early (forward outputs) and waited on later, like bench.py does around the backward
+    r2, d2 = radii.clone(), torch.tensor(0.25 * (1 + rank))
+    h = parallel.exchange_max(r2, d2, async_op=True)
+    h.wait()
+    assert torch.equal(r2, res["radii"]) and float(d2) == 0.25 * world
+    per_view = torch.stack([radii, radii // 2])
+    rm, dm = parallel.exchange_forward_stats(per_view, torch.full((2, 1, 4, 4), 0.5 + rank)).wait()
+    assert torch.equal(rm, res["radii"]) and float(dm) == 0.5 + (world - 1)
+    v2 = vs.clone()
+    parallel.exchange_sum(params, v2, average=True)          # gradients (already summed) averaged, norms summed
+    assert torch.allclose(v2, res["viewspace_grad_norm"])
+    for i, p in enumerate(params):
+        ref = sum(gathered[r]["local"][i] for r in range(world))
+        assert torch.allclose(p.grad, ref, atol=1e-5)        # sum over ranks of the same reduced value / world
     # broadcast of a model-like object
     class M:
         pass
