@@ -151,7 +151,17 @@ class StableDiffusionGuidance:
         self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = cast(pos), cast(neg), cast(null)
 
     # ------------------------------------------------------------------ networks
-    def forward_unet(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet=True, **_unused):
+    def embed_control(self, control_img):
+        """The ControlNet's hint embedding of `control_img` [n, 3, H, W] (timestep-independent): pass it to forward_unet as
+        `control_embedding` when the same pose map is denoised more than once."""
+        cond = control_img.to(self.weights_dtype)
+        if self.cfg.channels_last:
+            cond = cond.contiguous(memory_format=torch.channels_last)
+        with torch.autocast("cuda", enabled=False):
+            return self.controlnet.embed_condition(cond)
+
+    def forward_unet(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet=True,
+                     control_embedding=None, **_unused):
         dt = self.weights_dtype
         x = noisy_latents.to(dt)
         ctx = encoder_hidden_states.to(dt)
@@ -160,10 +170,9 @@ class StableDiffusionGuidance:
         with torch.autocast("cuda", enabled=False):
             if not use_pose_controlnet:
                 return self.unet(x, t, ctx).to(noisy_latents.dtype)
-            cond = control_img.to(dt)
-            if self.cfg.channels_last:
-                cond = cond.contiguous(memory_format=torch.channels_last)
-            down, mid = self.controlnet(x, t, ctx, cond, 1.0)
+            if control_embedding is None:
+                control_embedding = self.embed_control(control_img)
+            down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=control_embedding)
             return self.unet(x, t, ctx, down, mid).to(noisy_latents.dtype)
 
     def encode_images(self, imgs, generator=None):

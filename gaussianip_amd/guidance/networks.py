@@ -392,15 +392,22 @@ class ControlNet(_Encoder):
         self.zero_convs = nn.ModuleList([nn.Conv2d(c, c, 1) for c in (320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280)])
         self.mid_zero = nn.Conv2d(1280, 1280, 1)
 
-    def forward(self, x, t, ctx, cond, conditioning_scale=1.0) -> Tuple[List[torch.Tensor], torch.Tensor]:
-        """`cond` may hold fewer samples than x (B / k): the hint stem then runs once per distinct hint and its output
-        is tiled k times — the three guidance branches of compute_grad_anpg share their pose maps (ipa_guidance.py:397-399)."""
-        temb = self.temb(t, x.dtype)
+    def embed_condition(self, cond):
+        """controlnet_cond_embedding: the 8-convolution hint stem (image -> 320 channels at 1/8 resolution).  It depends on
+        the pose map only — not on the latents or the timestep — so a caller that denoises the same view repeatedly (the 8
+        DDIM steps of the refine pass) computes it once and hands it to forward() as `cond_embedding`."""
         c = cond
         for i, conv in enumerate(self.cond_stem):
             c = conv(c)
             if i < len(self.cond_stem) - 1:
                 c = F.silu(c)
+        return c
+
+    def forward(self, x, t, ctx, cond, conditioning_scale=1.0, cond_embedding=None) -> Tuple[List[torch.Tensor], torch.Tensor]:
+        """`cond` may hold fewer samples than x (B / k): the hint stem then runs once per distinct hint and its output
+        is tiled k times — the three guidance branches of compute_grad_anpg share their pose maps (ipa_guidance.py:397-399)."""
+        temb = self.temb(t, x.dtype)
+        c = self.embed_condition(cond) if cond_embedding is None else cond_embedding
         if c.shape[0] != x.shape[0]:
             c = c.repeat(x.shape[0] // c.shape[0], 1, 1, 1)
         h, skips = self.encode(self.conv_in(x) + c, temb, ctx)

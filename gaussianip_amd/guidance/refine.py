@@ -91,9 +91,10 @@ class ViewConsistentRefiner:
     def refine_latents(self, latents_noisy, embeds, control_img, timesteps):
         """8-step DDIM with classifier-free guidance; embeds = cat[uncond, cond] [2, 81, 768]; control_img [1,3,H,W]."""
         lat = latents_noisy
+        hint = self.g.embed_control(control_img)      # timestep-independent: once per view, not once per DDIM step
         for t in timesteps:
             tt = t.reshape(1).expand(2)
-            noise_pred = self.g.forward_unet(torch.cat([lat] * 2), control_img, tt, embeds, True)
+            noise_pred = self.g.forward_unet(torch.cat([lat] * 2), None, tt, embeds, True, control_embedding=hint)
             uncond, text = noise_pred.float().chunk(2)
             noise_pred = uncond + self.guidance_scale * (text - uncond)
             lat = ddim_step(lat, noise_pred, t, self.g.alphas)
