@@ -10,8 +10,9 @@
 //                                   per-workgroup tiles_touched sums -> instance offsets; header
 //   3. gip_scatter_kernel           every (Gaussian, tile) instance takes a slot in its tile's bucket
 //                                   (one returning integer atomic) and stores key = depth_bits<<32 | index
-//   4. gip_tile_sort_kernel         one workgroup per tile sorts its bucket in LDS (bitonic network on
-//                                   u64, all-ascending "flip" form so any length works without padding)
+//   4. gip_tile_sort_kernel /       per-tile sort of the bucket (bitonic network on u64, all-ascending "flip" form so any
+//      gip_tile_sort_long_kernel    length works without padding): a wave sorts lists < 512 entirely in registers with
+//                                   DPP / ds_bpermute lane exchanges; longer lists combine those wave blocks through LDS
 //
 // Keys are unique, so the sorted order — and therefore every downstream buffer — is independent of
 // the order in which the atomics resolved: the tile / index buffers are deterministic and equal to
@@ -85,9 +86,10 @@ __device__ void heavy_first_order(const uint32_t* lds_counts, const uint32_t* ca
       const uint32_t k = s_bucket[c];
       s_bucket[c] = run;
       run += k;
-      if (c == 0) class_end[0] = class_end[1] = run;   // sort role A: >= 2048
-      if (c == 1) class_end[2] = run;                  // sort role B: 1024..2047
-      if (c == 4) class_end[3] = run;                  // sort role C: 1..1023 ; beyond: empty tiles
+      if (c == 0) class_end[1] = run;                  // long-list kernel: >= 2048
+      if (c == 1) class_end[2] = run;                  // (1024..2047)
+      if (c == 2) class_end[0] = run;                  // workgroup-per-tile role: 512..2047 = [class_end[1], class_end[0])
+      if (c == 4) class_end[3] = run;                  // wave-per-tile role: 1..511 ; beyond: empty tiles
     }
   }
   __syncthreads();
@@ -294,91 +296,221 @@ void gip_launch_scatter(const GipKernelParams& kp, GipStatePtrs st, hipStream_t 
 // the larger element to the higher index, so virtual +inf padding at indices >= n never moves and
 // comparators that touch it can simply be skipped -> correct for any n.
 // ------------------------------------------------------------------------------------------------
-// Register-blocked small strides: thread t owns the 8 consecutive keys [8t, 8t+8) (256 threads x 8 = the 2048-key LDS
-// chunk), so every comparator with both ends inside an aligned 8-block — the stages k = 2, 4, 8 and the merge strides
-// 4, 2, 1 of every later stage — runs on registers between ONE 64-byte LDS read and write, without barriers in between.
-// Keys past n are +inf in registers (a comparator against +inf never swaps: the same as skipping it).
-#define CE(x, y) { const unsigned long long lo_ = x < y ? x : y, hi_ = x < y ? y : x; x = lo_; y = hi_; }
-__device__ __forceinline__ void regs_load(const unsigned long long* a, uint32_t n, uint32_t b, unsigned long long* r) {
-#pragma unroll
-  for (int i = 0; i < 8; i++) r[i] = b + i < n ? a[b + i] : ~0ull;
+// ------------------------------------------------------------------------------------------------
+// Wave-level part of the network.  A wave holds a 64*R-key block as R registers per lane (key i of the block = row
+// i / 64, lane i % 64).  Every comparator of the all-ascending network pairs index x with x ^ mask (flip: mask = k - 1,
+// stride: mask = j), so inside such a block
+//   * masks < 64 are lane exchanges (__shfl_xor) — no LDS traffic, no barrier;
+//   * strides >= 64 pair two rows of the same lane — plain register compare-exchange;
+//   * flips with k >= 128 pair row r with row r ^ (k/64 - 1) of the mirrored lane (lane ^ 63).
+// A wave therefore runs ALL stages k <= 64*R of its block (wave_sort) or all strides < 64*R of a later stage
+// (wave_tail) between one load and one store of the block.  Keys past n are +inf and never move.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long u64min(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned long long u64max(unsigned long long a, unsigned long long b) { return a < b ? b : a; }
+
+// value of `x` held by lane ^ MASK.  VALU-only forms where the hardware has them (no LDS round trip, no wait):
+//   1, 2, 3 -> DPP quad_perm;  4 -> row_shl:4 / row_shr:4 on alternate banks;  7 -> row_half_mirror;  8 -> row_ror:8
+//   (== xor 8 inside a 16-lane row);  15 -> row_mirror;  16, 31, 32, 63 -> ds_bpermute through __shfl_xor (measured: v_permlane16/32_swap
+//   forms are slower — the network is VALU-bound and the LDS crossbar is otherwise idle).
+template <int MASK>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t x) {
+  if constexpr (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+  else if constexpr (MASK == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+  else if constexpr (MASK == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x1B, 0xF, 0xF, false);
+  else if constexpr (MASK == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);
+  else if constexpr (MASK == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);
+  else if constexpr (MASK == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);
+  else if constexpr (MASK == 4) {       // lanes with bit 2 clear take lane + 4 (row_shl:4, banks 0 and 2), the others lane - 4
+    const int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);
+  } else return (uint32_t)__shfl_xor((int)x, MASK, 64);
 }
-__device__ __forceinline__ void regs_store(unsigned long long* a, uint32_t n, uint32_t b, const unsigned long long* r) {
-#pragma unroll
-  for (int i = 0; i < 8; i++) if (b + i < n) a[b + i] = r[i];
-}
-__device__ __forceinline__ void regs_merge421(unsigned long long* r) {
-  CE(r[0], r[4]) CE(r[1], r[5]) CE(r[2], r[6]) CE(r[3], r[7])
-  CE(r[0], r[2]) CE(r[1], r[3]) CE(r[4], r[6]) CE(r[5], r[7])
-  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])
-}
-__device__ __forceinline__ void regs_sort8(unsigned long long* r) {     // stages k = 2, 4, 8 of the flip network
-  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])                                   // k = 2: flip
-  CE(r[0], r[3]) CE(r[1], r[2]) CE(r[4], r[7]) CE(r[5], r[6])                                   // k = 4: flip
-  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])                                   //        stride 1
-  CE(r[0], r[7]) CE(r[1], r[6]) CE(r[2], r[5]) CE(r[3], r[4])                                   // k = 8: flip
-  CE(r[0], r[2]) CE(r[1], r[3]) CE(r[4], r[6]) CE(r[5], r[7])                                   //        stride 2
-  CE(r[0], r[1]) CE(r[2], r[3]) CE(r[4], r[5]) CE(r[6], r[7])                                   //        stride 1
+template <int MASK>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long x) {
+  const uint32_t lo = lane_xor32<MASK>((uint32_t)x), hi = lane_xor32<MASK>((uint32_t)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
 }
 
-// strides j = 4, 2, 1 of one merge on registers (all threads; ends with a barrier)
-__device__ __forceinline__ void merge_low_regs(unsigned long long* a, uint32_t n) {
-  for (uint32_t b = threadIdx.x * 8; b < n; b += GIP_BLOCK * 8) {
-    unsigned long long r[8];
-    regs_load(a, n, b, r);
-    regs_merge421(r);
-    regs_store(a, n, b, r);
+// one comparator layer x <-> x ^ MASK inside the rows: a lane keeps the minimum if it is the lower index of its pair.
+// (keys are unique, so "keep v unless the partner wins" is one 64-bit compare and two selects)
+template <int R, int MASK>
+__device__ __forceinline__ void wave_xor_step(unsigned long long (&v)[R], bool keep_min) {
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const unsigned long long p = lane_xor64<MASK>(v[r]);
+    v[r] = ((v[r] < p) == keep_min) ? v[r] : p;
   }
-  __syncthreads();
+}
+template <int R, int FROM>
+__device__ __forceinline__ void wave_lane_strides(unsigned long long (&v)[R], int lane) {     // strides FROM .. 1
+  if constexpr (FROM >= 32) wave_xor_step<R, 32>(v, !(lane & 32));
+  if constexpr (FROM >= 16) wave_xor_step<R, 16>(v, !(lane & 16));
+  if constexpr (FROM >= 8) wave_xor_step<R, 8>(v, !(lane & 8));
+  if constexpr (FROM >= 4) wave_xor_step<R, 4>(v, !(lane & 4));
+  if constexpr (FROM >= 2) wave_xor_step<R, 2>(v, !(lane & 2));
+  if constexpr (FROM >= 1) wave_xor_step<R, 1>(v, !(lane & 1));
+}
+template <int R>
+__device__ __forceinline__ void wave_row_strides(unsigned long long (&v)[R], int from) {
+#pragma unroll
+  for (int jr = R >> 1; jr >= 1; jr >>= 1) {
+    if (jr > from) continue;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (!(r & jr)) { const unsigned long long lo = u64min(v[r], v[r + jr]), hi = u64max(v[r], v[r + jr]); v[r] = lo; v[r + jr] = hi; }
+  }
+}
+template <int R, int ROWS>
+__device__ __forceinline__ void wave_row_stage(unsigned long long (&v)[R], int lane) {         // stage k = 64 * ROWS
+  if constexpr (ROWS <= R) {
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (!(r & (ROWS >> 1))) {
+        const int q = r ^ (ROWS - 1);
+        const unsigned long long a = v[r], b = v[q];
+        const unsigned long long br = lane_xor64<63>(b), ar = lane_xor64<63>(a);
+        v[r] = a < br ? a : br;
+        v[q] = b < ar ? ar : b;
+      }
+    wave_row_strides<R>(v, ROWS >> 2);
+    wave_lane_strides<R, 32>(v, lane);
+  }
+}
+template <int R>
+__device__ __forceinline__ void wave_sort(unsigned long long (&v)[R], int lane) {       // stages k = 2 .. 64*R
+  wave_xor_step<R, 1>(v, !(lane & 1));                                                  // k = 2
+  wave_xor_step<R, 3>(v, !(lane & 2));  wave_lane_strides<R, 1>(v, lane);               // k = 4
+  wave_xor_step<R, 7>(v, !(lane & 4));  wave_lane_strides<R, 2>(v, lane);               // k = 8
+  wave_xor_step<R, 15>(v, !(lane & 8)); wave_lane_strides<R, 4>(v, lane);               // k = 16
+  wave_xor_step<R, 31>(v, !(lane & 16)); wave_lane_strides<R, 8>(v, lane);              // k = 32
+  wave_xor_step<R, 63>(v, !(lane & 32)); wave_lane_strides<R, 16>(v, lane);             // k = 64
+  wave_row_stage<R, 2>(v, lane);
+  wave_row_stage<R, 4>(v, lane);
+  wave_row_stage<R, 8>(v, lane);
+}
+template <int R>
+__device__ __forceinline__ void wave_tail(unsigned long long (&v)[R], int lane) {       // strides 32*R .. 1
+  wave_row_strides<R>(v, R >> 1);
+  wave_lane_strides<R, 32>(v, lane);
+}
+template <int R>
+__device__ __forceinline__ void wave_load(const unsigned long long* a, uint32_t n, uint32_t base, int lane, unsigned long long (&v)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) { const uint32_t i = base + r * 64 + lane; v[r] = i < n ? a[i] : ~0ull; }
+}
+template <int R>
+__device__ __forceinline__ void wave_store(unsigned long long* a, uint32_t n, uint32_t base, int lane, const unsigned long long (&v)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) { const uint32_t i = base + r * 64 + lane; if (i < n) a[i] = v[r]; }
+}
+// one tile of n <= 64*R keys, one wave, registers only
+template <int R>
+__device__ __forceinline__ void wave_sort_tile(unsigned long long* a, uint32_t n, int lane) {
+  unsigned long long v[R];
+  wave_load<R>(a, n, 0, lane, v);
+  wave_sort<R>(v, lane);
+  wave_store<R>(a, n, 0, lane, v);
 }
 
-__device__ __forceinline__ void bitonic_any_n(unsigned long long* a, uint32_t n) {
-  uint32_t m = 1;
+// n keys (n <= the LDS chunk s) from global `src` to global `dst`, sorted, by the NT threads of the workgroup:
+//   pass 0     every wave sorts 512-key blocks straight from global memory in registers and parks them in LDS;
+//   stage k    (1024 .. m) flip and the strides >= 512 as LDS passes, then every wave finishes its blocks' strides
+//              256 .. 1 in registers (wave_tail); the last stage writes to `dst` instead of LDS.
+// LDS round trips for 8192 keys: 1 + 2 + 3 + 4 + 5 = 15 (the one-stride-per-pass form needed 65).
+template <int NT>
+__device__ void lds_sort(unsigned long long* s, uint32_t n, const unsigned long long* src, unsigned long long* dst) {
+  constexpr int WAVES = NT / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t m = 512;
   while (m < n) m <<= 1;
-  const uint32_t half = m >> 1;
-  for (uint32_t b = threadIdx.x * 8; b < n; b += GIP_BLOCK * 8) {             // stages k = 2, 4, 8
-    unsigned long long r[8];
-    regs_load(a, n, b, r);
-    regs_sort8(r);
-    regs_store(a, n, b, r);
+  __syncthreads();                                   // the previous tile's readers are done with s
+  for (uint32_t base = wave * 512; base < n; base += WAVES * 512) {
+    unsigned long long v[8];
+    wave_load<8>(src, n, base, lane, v);
+    wave_sort<8>(v, lane);
+    wave_store<8>(m == 512 ? dst : s, n, base, lane, v);
   }
+  if (m == 512) return;
   __syncthreads();
-  for (uint32_t k = 16; k <= m; k <<= 1) {
+  const uint32_t half = m >> 1;
+  for (uint32_t k = 1024; k <= m; k <<= 1) {
     const uint32_t hk = k >> 1;
-    for (uint32_t t = threadIdx.x; t < half; t += GIP_BLOCK) {   // flip stage
-      const uint32_t blk = t / hk, off = t - blk * hk;
-      const uint32_t lo = blk * k + off, hi = blk * k + k - 1 - off;
+    for (uint32_t t = threadIdx.x; t < half; t += NT) {   // flip stage
+      const uint32_t base = (t & ~(hk - 1)) << 1, off = t & (hk - 1);
+      const uint32_t lo = base + off, hi = base + k - 1 - off;
       if (hi < n) {
-        unsigned long long x = a[lo], y = a[hi];
-        if (x > y) { a[lo] = y; a[hi] = x; }
+        const unsigned long long x = s[lo], y = s[hi];
+        if (x > y) { s[lo] = y; s[hi] = x; }
       }
     }
     __syncthreads();
-    for (uint32_t j = k >> 2; j >= 8; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < half; t += GIP_BLOCK) {
-        const uint32_t lo = 2 * j * (t / j) + (t % j), hi = lo + j;
+    for (uint32_t j = k >> 2; j >= 512; j >>= 1) {
+      for (uint32_t t = threadIdx.x; t < half; t += NT) {
+        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo + j;
         if (hi < n) {
-          unsigned long long x = a[lo], y = a[hi];
-          if (x > y) { a[lo] = y; a[hi] = x; }
+          const unsigned long long x = s[lo], y = s[hi];
+          if (x > y) { s[lo] = y; s[hi] = x; }
         }
       }
       __syncthreads();
     }
-    merge_low_regs(a, n);
+    for (uint32_t base = wave * 512; base < n; base += WAVES * 512) {
+      unsigned long long v[8];
+      wave_load<8>(s, n, base, lane, v);
+      wave_tail<8>(v, lane);
+      wave_store<8>(k == m ? dst : s, n, base, lane, v);
+    }
+    __syncthreads();
   }
 }
 
-// Per-tile sort, ONE launch.  The size classes are contiguous ranges of tile_order (written by the scan kernel
-// into header->class_end); workgroups take a role by blockIdx so that the few long lists (many bitonic stages,
-// latency-bound) sort concurrently with the many short ones instead of in separate back-to-back launches:
-//   role A  [0, SORT_WG_BIG)              tiles with >= 2048 entries: all-ascending network, strides < 2048 in LDS
-//                                          one 2048-key chunk at a time, longer strides in place in global memory
-//   role B  [SORT_WG_BIG, +SORT_WG_MID)   1024..2047 entries, fully in LDS
-//   role C  the rest                       1..1023 entries, fully in LDS
-#define BIG_CHUNK 2048
-#define SORT_WG_BIG 256
+// the strides hi_stride .. 1 (hi_stride < chunk) of one merge stage on an n-key chunk: global -> LDS, strides >= 512 as LDS
+// passes, strides 256 .. 1 in the waves' registers, -> global
+template <int NT>
+__device__ void lds_merge(unsigned long long* s, uint32_t n, const unsigned long long* src, unsigned long long* dst,
+                          uint32_t hi_stride, uint32_t half) {
+  constexpr int WAVES = NT / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += NT) s[i] = src[i];
+  __syncthreads();
+  for (uint32_t j = hi_stride; j >= 512; j >>= 1) {
+    for (uint32_t t = threadIdx.x; t < half; t += NT) {
+      const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo + j;
+      if (hi < n) {
+        const unsigned long long x = s[lo], y = s[hi];
+        if (x > y) { s[lo] = y; s[hi] = x; }
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t base = wave * 512; base < n; base += WAVES * 512) {
+    unsigned long long v[8];
+    wave_load<8>(s, n, base, lane, v);
+    wave_tail<8>(v, lane);
+    wave_store<8>(dst, n, base, lane, v);
+  }
+}
+
+// Per-tile sort in two launches by list length (the scan kernel wrote the size classes as contiguous ranges of
+// tile_order into header->class_end):
+//   gip_tile_sort_long_kernel  tiles with >= 2048 entries.  1024 threads and a 16384-key (128 KB) LDS chunk per
+//                              workgroup, one workgroup per CU looping over the class: lists up to 16384 entries are
+//                              read once, sorted entirely on chip (lds_sort) and written once; longer lists sort their
+//                              16384-key chunks that way and run only the merge strides >= 16384 in place in global
+//                              memory.  (1M-Gaussian orbit views put ~6000 entries, up to 22k, in every occupied tile:
+//                              this class IS the sort there.)
+//   gip_tile_sort_kernel       256 threads.  Workgroup-per-tile role: 512..2047 entries (lds_sort in a 2048-key chunk).
+//                              Wave-per-tile role: 1..511 entries — a wave sorts its tile in registers (wave_sort_tile,
+//                              64 / 128 / 256 / 512-key networks by length), no LDS and no barrier at all; the four
+//                              waves of a workgroup work on four different tiles.
+#define LONG_CHUNK 16384
+#define LONG_THREADS 1024
+#define LONG_WGS 256
+#define MID_CHUNK 2048
 #define SORT_WG_MID 512
-#define SORT_WG_SMALL 2048
+#define SORT_WG_SMALL 1024
 __device__ __forceinline__ void ce_global(unsigned long long* a, uint32_t lo, uint32_t hi, uint32_t n) {
   if (hi < n) {
     const unsigned long long x = a[lo], y = a[hi];
@@ -386,57 +518,81 @@ __device__ __forceinline__ void ce_global(unsigned long long* a, uint32_t lo, ui
   }
 }
 
-__device__ void sort_big_tile(unsigned long long* a, uint32_t n, unsigned long long* s_keys) {
+// n > LONG_CHUNK: chunks in LDS, strides >= LONG_CHUNK in place in global memory
+__device__ void sort_beyond_lds(unsigned long long* a, uint32_t n, unsigned long long* s_keys) {
+  constexpr int NT = LONG_THREADS;
   uint32_t m = 1;
   while (m < n) m <<= 1;
-  // phase 1: sort every BIG_CHUNK-aligned chunk completely in LDS
-  for (uint32_t c0 = 0; c0 < n; c0 += BIG_CHUNK) {
-    const uint32_t cn = min((uint32_t)BIG_CHUNK, n - c0);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) s_keys[i] = a[c0 + i];
-    __syncthreads();
-    bitonic_any_n(s_keys, cn);
-    for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) a[c0 + i] = s_keys[i];
+  // phase 1: sort every LONG_CHUNK-aligned chunk completely in LDS
+  for (uint32_t c0 = 0; c0 < n; c0 += LONG_CHUNK) {
+    const uint32_t cn = min((uint32_t)LONG_CHUNK, n - c0);
+    lds_sort<NT>(s_keys, cn, a + c0, a + c0);
   }
   __threadfence_block();
   __syncthreads();
-  // phase 2: merges of size k > BIG_CHUNK
-  for (uint32_t k = 2 * BIG_CHUNK; k <= m; k <<= 1) {
+  // phase 2: merges of size k > LONG_CHUNK
+  for (uint32_t k = 2 * LONG_CHUNK; k <= m; k <<= 1) {
     const uint32_t hk = k >> 1;
-    for (uint32_t tt = threadIdx.x; tt < (m >> 1); tt += GIP_BLOCK) {       // flip stage, global
-      const uint32_t blk = tt / hk, off = tt - blk * hk;
-      ce_global(a, blk * k + off, blk * k + k - 1 - off, n);
+    for (uint32_t tt = threadIdx.x; tt < (m >> 1); tt += NT) {       // flip stage, global
+      const uint32_t base = (tt & ~(hk - 1)) << 1, off = tt & (hk - 1);
+      ce_global(a, base + off, base + k - 1 - off, n);
     }
     __threadfence_block();
     __syncthreads();
-    for (uint32_t j = k >> 2; j >= BIG_CHUNK; j >>= 1) {                    // long strides, global
-      for (uint32_t tt = threadIdx.x; tt < (m >> 1); tt += GIP_BLOCK) {
-        const uint32_t lo = 2 * j * (tt / j) + (tt % j);
+    for (uint32_t j = k >> 2; j >= LONG_CHUNK; j >>= 1) {                    // long strides, global
+      for (uint32_t tt = threadIdx.x; tt < (m >> 1); tt += NT) {
+        const uint32_t lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
         ce_global(a, lo, lo + j, n);
       }
       __threadfence_block();
       __syncthreads();
     }
-    for (uint32_t c0 = 0; c0 < n; c0 += BIG_CHUNK) {                        // strides < BIG_CHUNK, in LDS
-      const uint32_t cn = min((uint32_t)BIG_CHUNK, n - c0);
-      for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) s_keys[i] = a[c0 + i];
-      __syncthreads();
-      for (uint32_t j = BIG_CHUNK >> 1; j >= 8; j >>= 1) {
-        for (uint32_t tt = threadIdx.x; tt < (BIG_CHUNK >> 1); tt += GIP_BLOCK) {
-          const uint32_t lo = 2 * j * (tt / j) + (tt % j), hi = lo + j;
-          if (hi < cn) {
-            const unsigned long long x = s_keys[lo], y = s_keys[hi];
-            if (x > y) { s_keys[lo] = y; s_keys[hi] = x; }
-          }
-        }
-        __syncthreads();
-      }
-      merge_low_regs(s_keys, cn);
-      for (uint32_t i = threadIdx.x; i < cn; i += GIP_BLOCK) a[c0 + i] = s_keys[i];
-      __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += LONG_CHUNK) {                        // strides < LONG_CHUNK, on chip
+      const uint32_t cn = min((uint32_t)LONG_CHUNK, n - c0);
+      lds_merge<NT>(s_keys, cn, a + c0, a + c0, LONG_CHUNK >> 1, LONG_CHUNK >> 1);
     }
     __threadfence_block();
     __syncthreads();
+  }
+}
+
+// segment -> tile map of one tile's segments (work list of the backward kernel)
+template <int NT>
+__device__ __forceinline__ void write_seg_tiles(const GipKernelParams& kp, const uint32_t* __restrict__ seg_start,
+                                                uint32_t* __restrict__ seg_tile, uint32_t t, uint32_t n) {
+  const uint32_t s0 = seg_start[t], ns = (n + GIP_SEGMENT - 1) / GIP_SEGMENT;
+  for (uint32_t b = threadIdx.x; b < ns; b += NT)
+    if (s0 + b < kp.seg_capacity) seg_tile[s0 + b] = t;
+}
+
+__global__ void __launch_bounds__(LONG_THREADS)
+gip_tile_sort_long_kernel(GipKernelParams kp, GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
+                          const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ seg_start,
+                          uint32_t* __restrict__ seg_tile, unsigned long long* __restrict__ keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_long[];
+  __shared__ uint32_t s_pos;
+  const uint32_t pos_hi = header->class_end[1];
+  // lists of 2048 .. 20000+ entries: tiles are handed out one at a time (header->sort_cursor, zeroed with the header)
+  // instead of round-robin, so a workgroup that drew long lists simply draws fewer
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_pos = atomicAdd(&header->sort_cursor, 1u);
+    __syncthreads();
+    const uint32_t pos = s_pos;
+    if (pos >= pos_hi) break;
+    const uint32_t t = tile_order[pos];
+    const uint32_t start = tile_start[t];
+    uint32_t end = tile_start[t + 1];
+    if (end > kp.capacity) end = kp.capacity;
+    if (end <= start) continue;
+    const uint32_t n = end - start;
+    write_seg_tiles<LONG_THREADS>(kp, seg_start, seg_tile, t, n);
+    if (n <= 1) continue;
+    if (n <= LONG_CHUNK) {
+      lds_sort<LONG_THREADS>(s_long, n, keys + start, keys + start);
+    } else {
+      sort_beyond_lds(keys + start, n, s_long);
+    }
   }
 }
 
@@ -444,44 +600,56 @@ __global__ void __launch_bounds__(GIP_BLOCK)
 gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
                      const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ seg_start,
                      uint32_t* __restrict__ seg_tile, unsigned long long* __restrict__ keys) {
-  __shared__ unsigned long long s_keys[BIG_CHUNK];
-  uint32_t pos_lo, pos_hi, first, stride;
-  bool big = false;
-  if (blockIdx.x < SORT_WG_BIG) {
-    pos_lo = 0; pos_hi = header->class_end[1]; first = blockIdx.x; stride = SORT_WG_BIG; big = true;
-  } else if (blockIdx.x < SORT_WG_BIG + SORT_WG_MID) {
-    pos_lo = header->class_end[1]; pos_hi = header->class_end[2]; first = blockIdx.x - SORT_WG_BIG; stride = SORT_WG_MID;
-  } else {
-    pos_lo = header->class_end[2]; pos_hi = header->class_end[3];
-    first = blockIdx.x - SORT_WG_BIG - SORT_WG_MID; stride = SORT_WG_SMALL;
+  __shared__ unsigned long long s_keys[MID_CHUNK];
+  if (blockIdx.x < SORT_WG_MID) {                                     // workgroup per tile: 512..2047 entries
+    const uint32_t pos_hi = header->class_end[0];
+    for (uint32_t pos = header->class_end[1] + blockIdx.x; pos < pos_hi; pos += SORT_WG_MID) {
+      const uint32_t t = tile_order[pos];
+      const uint32_t start = tile_start[t];
+      uint32_t end = tile_start[t + 1];
+      if (end > kp.capacity) end = kp.capacity;
+      if (end <= start) continue;
+      const uint32_t n = end - start;
+      write_seg_tiles<GIP_BLOCK>(kp, seg_start, seg_tile, t, n);
+      if (n > 1) lds_sort<GIP_BLOCK>(s_keys, n, keys + start, keys + start);
+    }
+    return;
   }
-  for (uint32_t pos = pos_lo + first; pos < pos_hi; pos += stride) {
+  // wave per tile: 1..511 entries (no workgroup barriers below: the four waves run independent trip counts)
+  const int lane = threadIdx.x & 63;
+  const uint32_t pos_hi = header->class_end[3];
+  const uint32_t wave_id = (blockIdx.x - SORT_WG_MID) * (GIP_BLOCK / 64) + (threadIdx.x >> 6);
+  for (uint32_t pos = header->class_end[0] + wave_id; pos < pos_hi; pos += SORT_WG_SMALL * (GIP_BLOCK / 64)) {
     const uint32_t t = tile_order[pos];
     const uint32_t start = tile_start[t];
     uint32_t end = tile_start[t + 1];
     if (end > kp.capacity) end = kp.capacity;
     if (end <= start) continue;
     const uint32_t n = end - start;
-    // segment -> tile map of this tile's segments (work list of the backward kernel)
     {
       const uint32_t s0 = seg_start[t], ns = (n + GIP_SEGMENT - 1) / GIP_SEGMENT;
-      for (uint32_t b = threadIdx.x; b < ns; b += GIP_BLOCK)
+      for (uint32_t b = lane; b < ns; b += 64)
         if (s0 + b < kp.seg_capacity) seg_tile[s0 + b] = t;
     }
+    unsigned long long* a = keys + start;
     if (n <= 1) continue;
-    if (big) {
-      sort_big_tile(keys + start, n, s_keys);
-    } else {
-      __syncthreads();
-      for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) s_keys[i] = keys[start + i];
-      __syncthreads();
-      bitonic_any_n(s_keys, n);
-      for (uint32_t i = threadIdx.x; i < n; i += GIP_BLOCK) keys[start + i] = s_keys[i];
-    }
+    if (n <= 64) wave_sort_tile<1>(a, n, lane);
+    else if (n <= 128) wave_sort_tile<2>(a, n, lane);
+    else if (n <= 256) wave_sort_tile<4>(a, n, lane);
+    else wave_sort_tile<8>(a, n, lane);
   }
 }
 
 void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  hipLaunchKernelGGL(gip_tile_sort_kernel, dim3(SORT_WG_BIG + SORT_WG_MID + SORT_WG_SMALL), dim3(GIP_BLOCK), 0, s, kp,
+  // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process)
+  static bool long_ready = false;
+  constexpr size_t long_lds = (size_t)LONG_CHUNK * sizeof(unsigned long long);
+  if (!long_ready) {
+    (void)hipFuncSetAttribute((const void*)gip_tile_sort_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)long_lds);
+    long_ready = true;
+  }
+  hipLaunchKernelGGL(gip_tile_sort_long_kernel, dim3(LONG_WGS), dim3(LONG_THREADS), long_lds, s, kp, st.header, st.tile_order,
+                     st.tile_start, st.seg_start, st.seg_tile, st.keys);
+  hipLaunchKernelGGL(gip_tile_sort_kernel, dim3(SORT_WG_MID + SORT_WG_SMALL), dim3(GIP_BLOCK), 0, s, kp,
                      st.header, st.tile_order, st.tile_start, st.seg_start, st.seg_tile, st.keys);
 }

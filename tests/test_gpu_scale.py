@@ -111,10 +111,12 @@ def test_capacity_overflow_protocol():
         R._MIN_CAPACITY, R._CAPACITY_MARGIN = old_min, old_margin
 
 
-def test_very_long_tile_lists_use_the_global_sort_path(oracle):
-    """A camera inside a dense cloud of large splats: > 8192 entries in one tile (strides >= 2048 sorted in global memory)."""
+@pytest.mark.parametrize("P,longest", [(40000, 8192), (90000, 16384), (180000, 32768)])
+def test_very_long_tile_lists_use_the_global_sort_path(oracle, P, longest):
+    """A camera inside a dense cloud of large splats: > 8192 entries in one tile (the 1024-thread kernel's on-chip path),
+    > 16384 (its chunks + one global merge level) and > 32768 (two levels, strides >= 16384 in global memory)."""
     from gaussianip_amd import rasterizer as R
-    P, H, W = 40000, 64, 64
+    H, W = 64, 64
     rng = np.random.default_rng(5)
     sc = scenes.make_scene("ball", P, seed=5)
     sc["scales"] = (sc["scales"] * 6.0).astype(np.float32)
@@ -125,7 +127,7 @@ def test_very_long_tile_lists_use_the_global_sort_path(oracle):
     (color, radii, depth, alpha), plan = R.forward_with_state(t["means3D"], t["opacities"], [st], shs=t["shs"],
                                                               scales=t["scales"], rotations=t["rotations"])
     sv = R.state_views(plan)
-    assert int(sv["header"][3]) > 8192, "scene does not exercise the long-list path (max list %d)" % int(sv["header"][3])
+    assert int(sv["header"][3]) > longest, "scene does not exercise the long-list path (max list %d)" % int(sv["header"][3])
     oracle.set_threads(8)
     ro = oracle.RasterOracle()
     o_color, o_radii, o_depth, o_alpha = ro.forward(
