@@ -86,10 +86,10 @@ __device__ void heavy_first_order(const uint32_t* lds_counts, const uint32_t* ca
       const uint32_t k = s_bucket[c];
       s_bucket[c] = run;
       run += k;
-      if (c == 0) class_end[1] = run;                  // long-list kernel: >= 2048
-      if (c == 1) class_end[2] = run;                  // (1024..2047)
-      if (c == 2) class_end[0] = run;                  // workgroup-per-tile role: 512..2047 = [class_end[1], class_end[0])
-      if (c == 4) class_end[3] = run;                  // wave-per-tile role: 1..511 ; beyond: empty tiles
+      if (c == 0) class_end[1] = run;                  // sort phase A: lists >= 2048 = [0, class_end[1])
+      if (c == 1) class_end[2] = run;                  // (>= 1024)
+      if (c == 2) class_end[0] = run;                  // sort phase M: 512..2047 = [class_end[1], class_end[0])
+      if (c == 4) class_end[3] = run;                  // sort phase B: 1..511 = [class_end[0], class_end[3]) ; beyond: empty tiles
     }
   }
   __syncthreads();
@@ -493,24 +493,23 @@ __device__ void lds_merge(unsigned long long* s, uint32_t n, const unsigned long
   }
 }
 
-// Per-tile sort in two launches by list length (the scan kernel wrote the size classes as contiguous ranges of
-// tile_order into header->class_end):
-//   gip_tile_sort_long_kernel  tiles with >= 2048 entries.  1024 threads and a 16384-key (128 KB) LDS chunk per
-//                              workgroup, one workgroup per CU looping over the class: lists up to 16384 entries are
-//                              read once, sorted entirely on chip (lds_sort) and written once; longer lists sort their
-//                              16384-key chunks that way and run only the merge strides >= 16384 in place in global
-//                              memory.  (1M-Gaussian orbit views put ~6000 entries, up to 22k, in every occupied tile:
-//                              this class IS the sort there.)
-//   gip_tile_sort_kernel       256 threads.  Workgroup-per-tile role: 512..2047 entries (lds_sort in a 2048-key chunk).
-//                              Wave-per-tile role: 1..511 entries — a wave sorts its tile in registers (wave_sort_tile,
-//                              64 / 128 / 256 / 512-key networks by length), no LDS and no barrier at all; the four
-//                              waves of a workgroup work on four different tiles.
+// Per-tile sort, ONE launch of one 1024-thread workgroup per CU with a 16384-key (128 KB) LDS chunk.  The scan kernel
+// wrote tile_order longest class first and the class boundaries into header->class_end; every workgroup runs three
+// phases; A and M draw their work from atomic cursors in the header, so a workgroup held up in A simply draws less in M
+// (as separate launches the few long lists of a training view cost 25 serial microseconds):
+//   A  lists >= 2048 entries, one tile per workgroup: up to 16384 entries are read once, sorted entirely on chip
+//      (lds_sort) and written once; longer lists sort their 16384-key chunks that way and run only the merge strides
+//      >= 16384 in place in global memory.  (1M-Gaussian orbit views put ~6000 entries, up to 22k, in every occupied
+//      tile: phase A IS the sort there.)
+//   M  lists of 512..2047 entries, FOUR tiles per workgroup at a time: each 256-thread quarter sorts its tile in its own
+//      2048-key slice of the chunk (one 512-key register block per wave, then the stages 1024 and 2048).  All quarters
+//      run the same fixed stage sequence so that the workgroup barriers line up; comparators beyond a list's length are
+//      skipped, a stage a short list does not need leaves it unchanged.
+//   B  lists of 1..511 entries, one tile per WAVE, entirely in registers (wave_sort_tile: 64 / 128 / 256 / 512-key
+//      networks by length), no LDS and no barrier; static round-robin over the grid's waves (a 1024^2 view has at most
+//      4096 tiles: about one per wave).
 #define LONG_CHUNK 16384
 #define LONG_THREADS 1024
-#define LONG_WGS 256
-#define MID_CHUNK 2048
-#define SORT_WG_MID 512
-#define SORT_WG_SMALL 1024
 __device__ __forceinline__ void ce_global(unsigned long long* a, uint32_t lo, uint32_t hi, uint32_t n) {
   if (hi < n) {
     const unsigned long long x = a[lo], y = a[hi];
@@ -565,61 +564,111 @@ __device__ __forceinline__ void write_seg_tiles(const GipKernelParams& kp, const
     if (s0 + b < kp.seg_capacity) seg_tile[s0 + b] = t;
 }
 
-__global__ void __launch_bounds__(LONG_THREADS)
-gip_tile_sort_long_kernel(GipKernelParams kp, GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
-                          const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ seg_start,
-                          uint32_t* __restrict__ seg_tile, unsigned long long* __restrict__ keys) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_long[];
-  __shared__ uint32_t s_pos;
-  const uint32_t pos_hi = header->class_end[1];
-  // lists of 2048 .. 20000+ entries: tiles are handed out one at a time (header->sort_cursor, zeroed with the header)
-  // instead of round-robin, so a workgroup that drew long lists simply draws fewer
-  for (;;) {
+// phase M worker: the calling 256-thread quarter sorts a[0, n) (n < 2048; n == 0: no tile, barriers only) in its LDS slice
+__device__ void quarter_sort(unsigned long long* s, uint32_t n, unsigned long long* a) {
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3, ltid = threadIdx.x & 255;
+  const uint32_t base = w * 512;
+  const bool multi = n > 512;
+  if (base < n) {
+    unsigned long long v[8];
+    wave_load<8>(a, n, base, lane, v);
+    wave_sort<8>(v, lane);
+    wave_store<8>(multi ? s : a, n, base, lane, v);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t k = 1024; k <= 2048; k <<= 1) {
+    const uint32_t hk = k >> 1;
+    if (multi)
+      for (uint32_t t = ltid; t < 1024; t += 256) {               // flip stage
+        const uint32_t b0 = (t & ~(hk - 1)) << 1, off = t & (hk - 1);
+        const uint32_t lo = b0 + off, hi = b0 + k - 1 - off;
+        if (hi < n) {
+          const unsigned long long x = s[lo], y = s[hi];
+          if (x > y) { s[lo] = y; s[hi] = x; }
+        }
+      }
     __syncthreads();
-    if (threadIdx.x == 0) s_pos = atomicAdd(&header->sort_cursor, 1u);
-    __syncthreads();
-    const uint32_t pos = s_pos;
-    if (pos >= pos_hi) break;
-    const uint32_t t = tile_order[pos];
-    const uint32_t start = tile_start[t];
-    uint32_t end = tile_start[t + 1];
-    if (end > kp.capacity) end = kp.capacity;
-    if (end <= start) continue;
-    const uint32_t n = end - start;
-    write_seg_tiles<LONG_THREADS>(kp, seg_start, seg_tile, t, n);
-    if (n <= 1) continue;
-    if (n <= LONG_CHUNK) {
-      lds_sort<LONG_THREADS>(s_long, n, keys + start, keys + start);
-    } else {
-      sort_beyond_lds(keys + start, n, s_long);
+    if (k == 2048) {
+      if (multi)
+        for (uint32_t t = ltid; t < 1024; t += 256) {             // stride 512
+          const uint32_t lo = ((t & ~511u) << 1) | (t & 511u), hi = lo + 512;
+          if (hi < n) {
+            const unsigned long long x = s[lo], y = s[hi];
+            if (x > y) { s[lo] = y; s[hi] = x; }
+          }
+        }
+      __syncthreads();
     }
+    if (multi && base < n) {
+      unsigned long long v[8];
+      wave_load<8>(s, n, base, lane, v);
+      wave_tail<8>(v, lane);
+      wave_store<8>(k == 2048 ? a : s, n, base, lane, v);
+    }
+    __syncthreads();
   }
 }
 
-__global__ void __launch_bounds__(GIP_BLOCK)
-gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
+__global__ void __launch_bounds__(LONG_THREADS)
+gip_tile_sort_kernel(GipKernelParams kp, GipRasterHeader* __restrict__ header, const uint32_t* __restrict__ tile_order,
                      const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ seg_start,
                      uint32_t* __restrict__ seg_tile, unsigned long long* __restrict__ keys) {
-  __shared__ unsigned long long s_keys[MID_CHUNK];
-  if (blockIdx.x < SORT_WG_MID) {                                     // workgroup per tile: 512..2047 entries
-    const uint32_t pos_hi = header->class_end[0];
-    for (uint32_t pos = header->class_end[1] + blockIdx.x; pos < pos_hi; pos += SORT_WG_MID) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_long[];
+  __shared__ uint32_t s_pos;
+  const uint32_t end_a = header->class_end[1], end_m = header->class_end[0], end_b = header->class_end[3];
+  // ---- phase A: workgroup per tile ----
+  if (end_a > 0) {
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_pos = atomicAdd(&header->sort_cursor, 1u);
+      __syncthreads();
+      const uint32_t pos = s_pos;
+      if (pos >= end_a) break;
       const uint32_t t = tile_order[pos];
       const uint32_t start = tile_start[t];
       uint32_t end = tile_start[t + 1];
       if (end > kp.capacity) end = kp.capacity;
       if (end <= start) continue;
       const uint32_t n = end - start;
-      write_seg_tiles<GIP_BLOCK>(kp, seg_start, seg_tile, t, n);
-      if (n > 1) lds_sort<GIP_BLOCK>(s_keys, n, keys + start, keys + start);
+      write_seg_tiles<LONG_THREADS>(kp, seg_start, seg_tile, t, n);
+      if (n <= 1) continue;
+      if (n <= LONG_CHUNK) lds_sort<LONG_THREADS>(s_long, n, keys + start, keys + start);
+      else sort_beyond_lds(keys + start, n, s_long);
     }
-    return;
   }
-  // wave per tile: 1..511 entries (no workgroup barriers below: the four waves run independent trip counts)
+  // ---- phase M: quarter (256 threads) per tile, four tiles per draw ----
+  if (end_m > end_a) {
+    const uint32_t q = threadIdx.x >> 8;
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_pos = atomicAdd(&header->sort_cursor_m, 4u);
+      __syncthreads();
+      const uint32_t pos = end_a + s_pos + q;
+      if (end_a + s_pos >= end_m) break;
+      uint32_t n = 0;
+      unsigned long long* a = keys;
+      if (pos < end_m) {
+        const uint32_t t = tile_order[pos];
+        const uint32_t start = tile_start[t];
+        uint32_t end = tile_start[t + 1];
+        if (end > kp.capacity) end = kp.capacity;
+        if (end > start) {
+          n = end - start;
+          a = keys + start;
+          const uint32_t s0 = seg_start[t], ns = (n + GIP_SEGMENT - 1) / GIP_SEGMENT;
+          for (uint32_t b = threadIdx.x & 255; b < ns; b += 256)
+            if (s0 + b < kp.seg_capacity) seg_tile[s0 + b] = t;
+        }
+      }
+      quarter_sort(s_long + q * 2048, n > 1 ? n : 0, a);
+    }
+  }
+  // ---- phase B: wave per tile, static round-robin over all waves of the grid (no barrier from here on) ----
   const int lane = threadIdx.x & 63;
-  const uint32_t pos_hi = header->class_end[3];
-  const uint32_t wave_id = (blockIdx.x - SORT_WG_MID) * (GIP_BLOCK / 64) + (threadIdx.x >> 6);
-  for (uint32_t pos = header->class_end[0] + wave_id; pos < pos_hi; pos += SORT_WG_SMALL * (GIP_BLOCK / 64)) {
+  const uint32_t waves_per_wg = LONG_THREADS / 64;
+  // consecutive positions (similar lengths: the order is by size class) go to different CUs, not to the waves of one
+  for (uint32_t pos = end_m + (threadIdx.x >> 6) * gridDim.x + blockIdx.x; pos < end_b; pos += gridDim.x * waves_per_wg) {
     const uint32_t t = tile_order[pos];
     const uint32_t start = tile_start[t];
     uint32_t end = tile_start[t + 1];
@@ -641,15 +690,17 @@ gip_tile_sort_kernel(GipKernelParams kp, const GipRasterHeader* __restrict__ hea
 }
 
 void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process)
-  static bool long_ready = false;
-  constexpr size_t long_lds = (size_t)LONG_CHUNK * sizeof(unsigned long long);
-  if (!long_ready) {
-    (void)hipFuncSetAttribute((const void*)gip_tile_sort_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)long_lds);
-    long_ready = true;
+  // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process); one workgroup per CU
+  static int wgs = 0;
+  constexpr size_t lds = (size_t)LONG_CHUNK * sizeof(unsigned long long);
+  if (!wgs) {
+    (void)hipFuncSetAttribute((const void*)gip_tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
+    wgs = cus;
   }
-  hipLaunchKernelGGL(gip_tile_sort_long_kernel, dim3(LONG_WGS), dim3(LONG_THREADS), long_lds, s, kp, st.header, st.tile_order,
+  hipLaunchKernelGGL(gip_tile_sort_kernel, dim3(wgs), dim3(LONG_THREADS), lds, s, kp, st.header, st.tile_order,
                      st.tile_start, st.seg_start, st.seg_tile, st.keys);
-  hipLaunchKernelGGL(gip_tile_sort_kernel, dim3(SORT_WG_MID + SORT_WG_SMALL), dim3(GIP_BLOCK), 0, s, kp,
-                     st.header, st.tile_order, st.tile_start, st.seg_start, st.seg_tile, st.keys);
 }
+

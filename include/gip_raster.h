@@ -133,8 +133,9 @@ typedef struct GipRasterHeader {
   uint32_t num_segments;   /* sum over tiles of ceil(count / GIP_SEGMENT): work items of the backward replay */
   uint32_t num_checkpoints;/* sum over tiles of max(segments - 1, 0) */
   uint32_t class_end[4];   /* positions in tile_order where the per-tile-sort size classes end: [1] lists >= 2048, [2] >= 1024, [0] >= 512, [3] >= 1 */
-  uint32_t sort_cursor;    /* scratch: work counter of the long-list sort kernel */
-  uint32_t reserved[4];
+  uint32_t sort_cursor;    /* scratch: work counters of the per-tile sort kernel (lists >= 2048 entries, ... */
+  uint32_t sort_cursor_m;  /* ... lists of 512..2047 entries) */
+  uint32_t reserved[3];
 } GipRasterHeader;
 
 /* Byte offsets of the sub-buffers inside `state` (for tests, debugging and parity checks of the
