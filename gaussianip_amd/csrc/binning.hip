@@ -27,7 +27,9 @@
 #endif
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define SCAN_LDS_TILES 32768   // tile counts staged in LDS when V*T fits (128 KB of the 160 KB)
+#define SCAN_LDS_TILES 32768   // tile counts staged in LDS when V*T fits (padded 17/16: 136 KB of the 160 KB)
+#define SCAN_LDS_TILES2 36864  // ... and the prefixes too when 2 * V*T fits (153 KB)
+#define SCAN_LDS_WORDS(n) ((n) + ((n) >> 4) + 2)
 
 struct U3 { uint32_t a, b, c; };
 
@@ -61,50 +63,62 @@ __device__ __forceinline__ int bucket_of(uint32_t c) { return c ? 32 - __clz(c) 
 __device__ __forceinline__ int class_of(uint32_t c) {
   return c >= 2048 ? 0 : c >= 1024 ? 1 : c >= 512 ? 2 : c >= 128 ? 3 : c >= 1 ? 4 : 5;
 }
+// LDS image of the tile counts: one pad word per 16, so that a thread walking its own 16-word chunk (stride 17 across
+// lanes) and a wave reading 64 consecutive counts are both bank-conflict free (unpadded, the chunk walk is 16-way
+// conflicted: it made the prefix role 32 us long)
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+
 __device__ void heavy_first_order(const uint32_t* lds_counts, const uint32_t* ca, const uint32_t* cb,
-                                  uint32_t* __restrict__ order, int n, uint32_t* s_bucket /*[33]*/,
+                                  uint32_t* __restrict__ order, int n, uint32_t* s_wcnt /*[ORDER_CLASSES * SCAN_WAVES + ORDER_CLASSES]*/,
                                   uint32_t* class_end /*[4] out, thread 0*/) {
-  auto count_of = [&](int i) -> uint32_t { return lds_counts ? lds_counts[i] : ca[i] + cb[i]; };
-  const int lane = threadIdx.x & 63;
+  // counting sort by class without atomics: every wave owns a contiguous slice of the tiles, counts its classes with
+  // ballots (pass 1), the 6 x 16 counts become write cursors (class-major, wave-minor: longest class first, index order
+  // inside a class), and pass 2 places each tile at cursor + rank inside the ballot.
+  auto count_of = [&](int i) -> uint32_t { return lds_counts ? lds_counts[pad16(i)] : ca[i] + cb[i]; };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int i = threadIdx.x; i < 33; i += SCAN_THREADS) s_bucket[i] = 0;
-  __syncthreads();
-  const int rounds = (n + SCAN_THREADS - 1) / SCAN_THREADS;
-  for (int r = 0; r < rounds; r++) {
-    const int i = r * SCAN_THREADS + threadIdx.x;
-    const int cls = i < n ? class_of(count_of(i)) : -1;
+  const int per_wave = ((n + SCAN_WAVES - 1) / SCAN_WAVES + 63) & ~63;
+  const int lo = wave * per_wave, hi = min(n, lo + per_wave);
+  uint32_t cnt[ORDER_CLASSES];
 #pragma unroll
-    for (int c = 0; c < ORDER_CLASSES; c++) {
-      const unsigned long long m = __ballot(cls == c);
-      if (m && lane == 0) atomicAdd(&s_bucket[c], (uint32_t)__popcll(m));
-    }
+  for (int c = 0; c < ORDER_CLASSES; c++) cnt[c] = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const int cls = i < hi ? class_of(count_of(i)) : -1;
+#pragma unroll
+    for (int c = 0; c < ORDER_CLASSES; c++) cnt[c] += (uint32_t)__popcll(__ballot(cls == c));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < ORDER_CLASSES; c++) s_wcnt[c * SCAN_WAVES + wave] = cnt[c];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  uint32_t cur[ORDER_CLASSES];
+  {
     uint32_t run = 0;
+#pragma unroll
     for (int c = 0; c < ORDER_CLASSES; c++) {
-      const uint32_t k = s_bucket[c];
-      s_bucket[c] = run;
-      run += k;
-      if (c == 0) class_end[1] = run;                  // sort phase A: lists >= 2048 = [0, class_end[1])
-      if (c == 1) class_end[2] = run;                  // (>= 1024)
-      if (c == 2) class_end[0] = run;                  // sort phase M: 512..2047 = [class_end[1], class_end[0])
-      if (c == 4) class_end[3] = run;                  // sort phase B: 1..511 = [class_end[0], class_end[3]) ; beyond: empty tiles
+      for (int w = 0; w < SCAN_WAVES; w++) {
+        const uint32_t k = s_wcnt[c * SCAN_WAVES + w];
+        if (w == wave) cur[c] = run;
+        run += k;
+      }
+      if (threadIdx.x == 0) {
+        if (c == 0) class_end[1] = run;                  // sort phase A: lists >= 2048 = [0, class_end[1])
+        if (c == 1) class_end[2] = run;                  // (>= 1024)
+        if (c == 2) class_end[0] = run;                  // sort phase M: 512..2047 = [class_end[1], class_end[0])
+        if (c == 4) class_end[3] = run;                  // sort phase B: 1..511 = [class_end[0], class_end[3]) ; beyond: empty tiles
+      }
     }
   }
-  __syncthreads();
-  for (int r = 0; r < rounds; r++) {
-    const int i = r * SCAN_THREADS + threadIdx.x;
-    const int cls = i < n ? class_of(count_of(i)) : -1;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const int cls = i < hi ? class_of(count_of(i)) : -1;
 #pragma unroll
     for (int c = 0; c < ORDER_CLASSES; c++) {
       const unsigned long long m = __ballot(cls == c);
-      if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_bucket[c], (uint32_t)__popcll(m));
-        base = __shfl(base, 0, 64);
-        if (cls == c) order[base + __popcll(m & lt)] = (uint32_t)i;
-      }
+      if (cls == c) order[cur[c] + __popcll(m & lt)] = (uint32_t)i;
+      cur[c] += (uint32_t)__popcll(m);
     }
   }
 }
@@ -116,7 +130,7 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offset,
                 uint32_t* __restrict__ tile_order, GipRasterHeader* __restrict__ header) {
   __shared__ uint32_t s_wave[3][SCAN_WAVES];
-  __shared__ uint32_t s_bucket[33];
+  __shared__ uint32_t s_bucket[ORDER_CLASSES * SCAN_WAVES];
   __shared__ uint32_t s_class[4];
   // ---- tiles: instance ranges, segment ranges, checkpoint slots (one pass, three running sums) ----
   // counts are first staged in LDS with coalesced loads (each thread then walks its contiguous chunk
@@ -150,13 +164,13 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int i = i0 + u * SCAN_THREADS;
-        if (i < n) s_cnt[i] = va[u] + vb[u];
+        if (i < n) s_cnt[pad16(i)] = va[u] + vb[u];
       }
     }
     __syncthreads();
   }
   // (beyond SCAN_LDS_TILES tiles the two partial counts are summed on the fly from global memory)
-  auto cnt_at = [&](int i) -> uint32_t { return in_lds ? s_cnt[i] : tile_count[i] + tile_count_b[i]; };
+  auto cnt_at = [&](int i) -> uint32_t { return in_lds ? s_cnt[pad16(i)] : tile_count[i] + tile_count_b[i]; };
   // Three independent jobs, one workgroup each (blockIdx.x = role), so that their latency chains overlap:
   //   role 0: tile prefixes (ranges / segments / checkpoint slots) + totals in the header
   //   role 1: longest-first launch order + class boundaries in the header
@@ -183,20 +197,20 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
   }
   U3 total;
   const U3 run0 = block_excl_scan3(sum, s_wave, &total);
-  if (in_lds && 2 * n <= SCAN_LDS_TILES) {
+  if (in_lds && 2 * n <= SCAN_LDS_TILES2) {
     // prefixes go through a second LDS array so that the global stores are coalesced (a thread's own chunk is
     // 16 consecutive words: written directly it costs 64 separate cache lines per wave store)
-    uint32_t* s_out = s_cnt + n;
+    uint32_t* s_out = s_cnt + pad16(n) + 1;
     for (int which = 0; which < 3; which++) {
       uint32_t r = which == 0 ? run0.a : which == 1 ? run0.b : run0.c;
       for (int i = lo; i < hi; i++) {
-        const uint32_t c = s_cnt[i], a = nseg_of(c);
-        s_out[i] = r;
+        const uint32_t c = s_cnt[pad16(i)], a = nseg_of(c);
+        s_out[pad16(i)] = r;
         r += which == 0 ? c : which == 1 ? a : (a ? a - 1 : 0);
       }
       __syncthreads();
       uint32_t* dst = which == 0 ? tile_start : which == 1 ? seg_start : ckpt_start;
-      for (int i = threadIdx.x; i < n; i += SCAN_THREADS) dst[i] = s_out[i];
+      for (int i = threadIdx.x; i < n; i += SCAN_THREADS) dst[i] = s_out[pad16(i)];
       __syncthreads();
     }
   } else {
@@ -225,10 +239,10 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   const int n = kp.V * kp.T;
-  const size_t lds = n <= SCAN_LDS_TILES ? (size_t)(2 * n <= SCAN_LDS_TILES ? 2 * n : n) * 4 : 0;
+  const size_t lds = n <= SCAN_LDS_TILES ? (size_t)(2 * n <= SCAN_LDS_TILES2 ? 2 * SCAN_LDS_WORDS(n) : SCAN_LDS_WORDS(n)) * 4 : 0;
   // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process)
   static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(gip_scan_kernel),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_TILES * 4);
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SCAN_LDS_WORDS(SCAN_LDS_TILES2 / 2) * 4);
   (void)attr_once;
   hipLaunchKernelGGL(gip_scan_kernel, dim3(3), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
                      st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header);
