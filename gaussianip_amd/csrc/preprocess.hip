@@ -45,7 +45,11 @@ __device__ __forceinline__ float sh_channel(int deg, const float* __restrict__ s
   return res;
 }
 
-__global__ void __launch_bounds__(GIP_BLOCK)
+// Workgroup = PRE_THREADS lanes = PRE_THREADS / GIP_BLOCK of the 256-Gaussian blocks the scan / scatter kernels index by
+// (block_sums stays per 256).  The wider workgroup exists for the tile histogram below: four times the Gaussians share
+// one LDS table, so neighbouring Gaussians' instances of a tile collapse into one global atomic four times as often.
+#define PRE_THREADS 1024
+__global__ void __launch_bounds__(PRE_THREADS)
 gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -56,7 +60,7 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
                       uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ block_sums,
                       GipRasterHeader* __restrict__ header) {
   const int v = blockIdx.y;
-  const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
+  const int idx = blockIdx.x * PRE_THREADS + threadIdx.x;
   const float* view = viewmatrix + 16 * v;   // wave-uniform -> scalar loads
   const float* proj = projmatrix + 16 * v;
   const float* campos = camposs + 3 * v;
@@ -171,16 +175,17 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
 
   // ---- per-tile histogram, aggregated per workgroup ----
   // The first GIP_SLOTS instances of a Gaussian remember their bucket slot, so the scatter pass places them without a
-  // second atomic; the (rare) rest only count (tile_count_b).  Global returning atomics run at ~10 G/s chip-wide and
-  // were this kernel's bound (one per instance), so the 256 Gaussians of a workgroup first count their instances per
-  // tile in an LDS hash table (open addressing, <= 2048 insertions into 4096 slots), then ONE global atomic per distinct
-  // tile reserves that tile's range for the whole workgroup, and slot = range base + rank inside the workgroup.
-  // Neighbouring Gaussians share tiles, so this is a 5-15x cut in global atomics when the Gaussian order is spatially
-  // coherent (limb-ordered synthetic scenes; Morton-ordered models) and costs a few LDS operations per instance otherwise.
+  // second atomic; the (rare) rest only count (tile_count_b).  Global returning atomics run at ~10 G/s chip-wide and are
+  // this kernel's bound (measured with wall_clock64 stamps: a workgroup's own latency is half the kernel time, the rest
+  // is atomic throughput), so the 1024 Gaussians of a workgroup first count their instances per tile in an LDS hash
+  // table (open addressing, <= 8192 insertions into 8192 slots), then ONE global atomic per distinct tile reserves that
+  // tile's range for the whole workgroup, and slot = range base + rank inside the workgroup.  Neighbouring Gaussians
+  // share tiles: 256 per table cut the atomics 3x on the limb-ordered bench scene, 1024 per table 8x (5-15x more when the
+  // model is Morton-ordered); it costs a few LDS operations per instance otherwise.
   {
-    constexpr int HT = 4096;
+    constexpr int HT = 8192;
     __shared__ uint32_t s_key[HT], s_cnt[HT];
-    for (int i = threadIdx.x; i < HT; i += GIP_BLOCK) { s_key[i] = 0u; s_cnt[i] = 0u; }
+    for (int i = threadIdx.x; i < HT; i += PRE_THREADS) { s_key[i] = 0u; s_cnt[i] = 0u; }
     __syncthreads();
     const int gx = kp.tiles_x;
     const int rminx = (int)(rec.rmin & 0xffffu), rminy = (int)(rec.rmin >> 16);
@@ -197,13 +202,13 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
         for (int tx = rminx; tx < rmaxx; tx++, k++) {
           const uint32_t tile = (uint32_t)(ty * gx + tx);
           if (k < GIP_SLOTS) {
-            uint32_t h = (tile * 2654435761u) >> 20;                 // 12 bits
+            uint32_t h = (tile * 2654435761u) >> 19;                 // 13 bits
             for (;;) {
               const uint32_t prev = atomicCAS(&s_key[h], 0u, tile + 1u);
               if (prev == 0u || prev == tile + 1u) break;
               h = (h + 1u) & (HT - 1);
             }
-            const uint32_t packed = (h << 16) | atomicAdd(&s_cnt[h], 1u);   // rank < 2048
+            const uint32_t packed = (h << 16) | atomicAdd(&s_cnt[h], 1u);   // rank < 8192
 #pragma unroll
             for (int kk = 0; kk < GIP_SLOTS; kk++) if (kk == k) slots[kk] = packed;
           } else {
@@ -212,9 +217,21 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HT; i += GIP_BLOCK) {
-      const uint32_t key = s_key[i];
-      if (key) s_cnt[i] = atomicAdd(&tc[key - 1u], s_cnt[i]);        // count -> base of this workgroup's range
+    {
+      // count -> base of this workgroup's range; all of a thread's returning atomics are issued before the first result
+      // is consumed
+      uint32_t keyv[HT / PRE_THREADS], val[HT / PRE_THREADS];
+#pragma unroll
+      for (int k = 0; k < HT / PRE_THREADS; k++) {
+        keyv[k] = s_key[threadIdx.x + k * PRE_THREADS];
+        val[k] = s_cnt[threadIdx.x + k * PRE_THREADS];
+      }
+#pragma unroll
+      for (int k = 0; k < HT / PRE_THREADS; k++)
+        if (keyv[k]) val[k] = atomicAdd(&tc[keyv[k] - 1u], val[k]);
+#pragma unroll
+      for (int k = 0; k < HT / PRE_THREADS; k++)
+        if (keyv[k]) s_cnt[threadIdx.x + k * PRE_THREADS] = val[k];
     }
     __syncthreads();
     if (ntiles > 0) {
@@ -227,23 +244,30 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
     }
   }
 
-  // workgroup sum of tiles_touched (feeds the instance-offset scan) + visible count
-  __shared__ uint32_t s_sum[4], s_vis[4];
+  // per-256-Gaussian-block sums of tiles_touched (feed the instance-offset scan) + visible count
+  constexpr int PRE_WAVES = PRE_THREADS / 64, PRE_SUB = PRE_THREADS / GIP_BLOCK;
+  __shared__ uint32_t s_sum[PRE_WAVES], s_vis[PRE_WAVES];
   uint32_t t = rec.tiles, vis = rec.radius > 0 ? 1u : 0u;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { t += __shfl_xor(t, d, 64); vis += __shfl_xor(vis, d, 64); }
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { s_sum[wave] = t; s_vis[wave] = vis; }
   __syncthreads();
+  if (threadIdx.x < PRE_SUB) {
+    const int blk = blockIdx.x * PRE_SUB + threadIdx.x;              // the 256-Gaussian block the scan / scatter kernels index by
+    const int w0 = threadIdx.x * (GIP_BLOCK / 64);
+    if (blk < kp.nblk) block_sums[(size_t)v * kp.nblk + blk] = s_sum[w0] + s_sum[w0 + 1] + s_sum[w0 + 2] + s_sum[w0 + 3];
+  }
   if (threadIdx.x == 0) {
-    block_sums[(size_t)v * kp.nblk + blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-    const uint32_t nv = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+    uint32_t nv = 0;
+#pragma unroll
+    for (int w = 0; w < PRE_WAVES; w++) nv += s_vis[w];
     if (nv) atomicAdd(&header->num_visible, nv);
   }
 }
 
 void gip_launch_preprocess(const GipKernelParams& kp, const GipRasterInputs& in, int32_t* radii, GipStatePtrs st, hipStream_t s) {
-  dim3 grid(kp.nblk, kp.V), block(GIP_BLOCK);
+  dim3 grid((kp.nblk + PRE_THREADS / GIP_BLOCK - 1) / (PRE_THREADS / GIP_BLOCK), kp.V), block(PRE_THREADS);
   hipLaunchKernelGGL(gip_preprocess_kernel, grid, block, 0, s, kp, in.means3D, in.shs, in.colors_precomp, in.opacities,
                      in.scales, in.rotations, in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, radii,
                      st.records, st.tile_count, st.tile_count_b, st.inst_slot, st.block_sums, st.header);

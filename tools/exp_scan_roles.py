@@ -14,4 +14,4 @@ for _ in range(5):
     (outs, plan) = R.forward_with_state(t["means3D"], t["opacities"], sts, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
     torch.cuda.synchronize()
     h = R.state_views(plan)["header"].cpu().numpy()
-    print("header words", h[:16], "role ticks (10 ns): role0 %d role1 %d role2 %d" % (h[13], h[14], h[15]))
+    print("header words", h[:16], "ticks (10 ns): %d %d %d" % (h[13], h[14], h[15]))
