@@ -27,8 +27,7 @@
 #endif
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define SCAN_LDS_TILES 32768   // tile counts staged in LDS when V*T fits (padded 17/16: 136 KB of the 160 KB)
-#define SCAN_LDS_TILES2 36864  // ... and the prefixes too when 2 * V*T fits (153 KB)
+#define SCAN_CHUNK 16384        // tiles per round: counts + prefixes in LDS, padded 17/16 (2 x 68 KB of the 160 KB)
 #define SCAN_LDS_WORDS(n) ((n) + ((n) >> 4) + 2)
 
 struct U3 { uint32_t a, b, c; };
@@ -150,32 +149,32 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
     if (threadIdx.x == 0) block_offset[nb] = t2.a;
     return;
   }
-  const bool in_lds = n <= SCAN_LDS_TILES;
-  if (in_lds) {
-    // 8 independent load pairs in flight per thread (a plain loop would wait for each pair in turn)
-    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * SCAN_THREADS) {
-      uint32_t va[8], vb[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * SCAN_THREADS;
-        va[u] = i < n ? tile_count[i] : 0u;
-        vb[u] = i < n ? tile_count_b[i] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * SCAN_THREADS;
-        if (i < n) s_cnt[pad16(i)] = va[u] + vb[u];
-      }
-    }
-    __syncthreads();
-  }
-  // (beyond SCAN_LDS_TILES tiles the two partial counts are summed on the fly from global memory)
-  auto cnt_at = [&](int i) -> uint32_t { return in_lds ? s_cnt[pad16(i)] : tile_count[i] + tile_count_b[i]; };
   // Three independent jobs, one workgroup each (blockIdx.x = role), so that their latency chains overlap:
   //   role 0: tile prefixes (ranges / segments / checkpoint slots) + totals in the header
   //   role 1: longest-first launch order + class boundaries in the header
   //   role 2: per-workgroup tiles_touched sums -> instance offsets
+  // Counts are staged in LDS with coalesced loads, 8 independent load pairs in flight per thread (a plain loop would
+  // wait for each pair in turn), SCAN_CHUNK tiles at a time.
+  auto stage_counts = [&](int c0, int cn) {
+    for (int i0 = threadIdx.x; i0 < cn; i0 += 8 * SCAN_THREADS) {
+      uint32_t va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * SCAN_THREADS;
+        va[u] = i < cn ? tile_count[c0 + i] : 0u;
+        vb[u] = i < cn ? tile_count_b[c0 + i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * SCAN_THREADS;
+        if (i < cn) s_cnt[pad16(i)] = va[u] + vb[u];
+      }
+    }
+    __syncthreads();
+  };
   if (role == 1) {
+    const bool in_lds = SCAN_LDS_WORDS(n) <= 2 * SCAN_LDS_WORDS(SCAN_CHUNK);   // V*T <= 32768; beyond, the two passes read global memory
+    if (in_lds) stage_counts(0, n);
 #if !(SCAN_SKIP & 1)
     heavy_first_order(in_lds ? s_cnt : nullptr, tile_count, tile_count_b, tile_order, n, s_bucket, s_class);
 #endif
@@ -186,41 +185,41 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
     }
     return;
   }
-  const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
-  const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
-  U3 sum = {0, 0, 0};
+  // role 0, SCAN_CHUNK tiles per round with the running totals carried over: every thread owns 16 consecutive tiles of
+  // the round; the prefixes go through a second LDS array so that the global stores are coalesced (a thread's own
+  // chunk written directly costs 64 separate cache lines per wave store)
+  U3 carry = {0, 0, 0};
   uint32_t mx = 0;
-  for (int i = lo; i < hi; i++) {
-    const uint32_t c = cnt_at(i), a = nseg_of(c);
-    sum.a += c; sum.b += a; sum.c += a ? a - 1 : 0;
-    mx = c > mx ? c : mx;
-  }
-  U3 total;
-  const U3 run0 = block_excl_scan3(sum, s_wave, &total);
-  if (in_lds && 2 * n <= SCAN_LDS_TILES2) {
-    // prefixes go through a second LDS array so that the global stores are coalesced (a thread's own chunk is
-    // 16 consecutive words: written directly it costs 64 separate cache lines per wave store)
-    uint32_t* s_out = s_cnt + pad16(n) + 1;
+  uint32_t* s_out = s_cnt + pad16(SCAN_CHUNK) + 1;
+  for (int c0 = 0; c0 < n; c0 += SCAN_CHUNK) {
+    const int cn = min(SCAN_CHUNK, n - c0);
+    __syncthreads();
+    stage_counts(c0, cn);
+    const int per = (cn + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = threadIdx.x * per, hi = min(cn, lo + per);
+    U3 sum = {0, 0, 0};
+    for (int i = lo; i < hi; i++) {
+      const uint32_t c = s_cnt[pad16(i)], a = nseg_of(c);
+      sum.a += c; sum.b += a; sum.c += a ? a - 1 : 0;
+      mx = c > mx ? c : mx;
+    }
+    U3 total;
+    const U3 run0 = block_excl_scan3(sum, s_wave, &total);
     for (int which = 0; which < 3; which++) {
-      uint32_t r = which == 0 ? run0.a : which == 1 ? run0.b : run0.c;
+      uint32_t r = which == 0 ? carry.a + run0.a : which == 1 ? carry.b + run0.b : carry.c + run0.c;
       for (int i = lo; i < hi; i++) {
         const uint32_t c = s_cnt[pad16(i)], a = nseg_of(c);
         s_out[pad16(i)] = r;
         r += which == 0 ? c : which == 1 ? a : (a ? a - 1 : 0);
       }
       __syncthreads();
-      uint32_t* dst = which == 0 ? tile_start : which == 1 ? seg_start : ckpt_start;
-      for (int i = threadIdx.x; i < n; i += SCAN_THREADS) dst[i] = s_out[pad16(i)];
+      uint32_t* dst = (which == 0 ? tile_start : which == 1 ? seg_start : ckpt_start) + c0;
+      for (int i = threadIdx.x; i < cn; i += SCAN_THREADS) dst[i] = s_out[pad16(i)];
       __syncthreads();
     }
-  } else {
-    U3 run = run0;
-    for (int i = lo; i < hi; i++) {
-      const uint32_t c = cnt_at(i), a = nseg_of(c);
-      tile_start[i] = run.a; seg_start[i] = run.b; ckpt_start[i] = run.c;
-      run.a += c; run.b += a; run.c += a ? a - 1 : 0;
-    }
+    carry.a += total.a; carry.b += total.b; carry.c += total.c;
   }
+  const U3 total = carry;
   if (threadIdx.x == 0) { tile_start[n] = total.a; seg_start[n] = total.b; ckpt_start[n] = total.c; }
   mx = gip_wave_max_u32(mx);
   if ((threadIdx.x & 63) == 0) s_wave[0][threadIdx.x >> 6] = mx;
@@ -238,11 +237,10 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
 }
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  const int n = kp.V * kp.T;
-  const size_t lds = n <= SCAN_LDS_TILES ? (size_t)(2 * n <= SCAN_LDS_TILES2 ? 2 * SCAN_LDS_WORDS(n) : SCAN_LDS_WORDS(n)) * 4 : 0;
   // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process)
+  constexpr size_t lds = 2 * SCAN_LDS_WORDS(SCAN_CHUNK) * 4;
   static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(gip_scan_kernel),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SCAN_LDS_WORDS(SCAN_LDS_TILES2 / 2) * 4);
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr_once;
   hipLaunchKernelGGL(gip_scan_kernel, dim3(3), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
                      st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header);
