@@ -425,56 +425,81 @@ __device__ __forceinline__ void wave_sort_tile(unsigned long long* a, uint32_t n
   wave_store<R>(a, n, 0, lane, v);
 }
 
-// n keys (n <= the LDS chunk s) from global `src` to global `dst`, sorted, by the NT threads of the workgroup:
-//   pass 0     every wave sorts 512-key blocks straight from global memory in registers and parks them in LDS;
-//   stage k    (1024 .. m) flip and the strides >= 512 as LDS passes, then every wave finishes its blocks' strides
-//              256 .. 1 in registers (wave_tail); the last stage writes to `dst` instead of LDS.
-// LDS round trips for 8192 keys: 1 + 2 + 3 + 4 + 5 = 15 (the one-stride-per-pass form needed 65).
+// LDS image of a key chunk: one pad slot per 16 keys, so that a thread writing its own 8 / 16 consecutive keys (stride
+// 8.5 / 17 slots across lanes) and a wave writing 64 consecutive keys are both (nearly) bank-conflict free
+__device__ __forceinline__ uint32_t padk(uint32_t i) { return i + (i >> 4); }
+#define PADK_SLOTS(n) ((n) + ((n) >> 4) + 1)
+
+// One merge level on the chunk: sorted runs of length L -> sorted runs of 2L (the last run of a list may be short or
+// missing).  Merge path: group thread `tid` produces the E consecutive outputs [tid * E, tid * E + E): a binary search
+// along its diagonal finds how many of the preceding outputs come from each run, then it merges sequentially into
+// registers; after a barrier the registers go back in place.  ~20 instructions per key and level, where the bitonic
+// merge of the same two runs costs log2(2L) comparator layers of ~6 instructions each.
+// Call with the same L by every thread of the workgroup (two barriers inside); n == 0 only runs the barriers.
+template <int E>
+__device__ __forceinline__ void merge_level(unsigned long long* s, uint32_t n, uint32_t L, uint32_t tid) {
+  unsigned long long out[E];
+  const uint32_t o0 = tid * E;
+  uint32_t cnt = 0;
+  if (o0 < n) {
+    const uint32_t a0 = o0 & ~(2u * L - 1u);
+    const uint32_t b0 = min(a0 + L, n), b1 = min(a0 + 2u * L, n);
+    const uint32_t lenA = b0 - a0, lenB = b1 - b0, d = o0 - a0;
+    uint32_t lo = d > lenB ? d - lenB : 0u, hi = min(d, lenA);
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s[padk(a0 + mid)] < s[padk(b0 + d - 1u - mid)]) lo = mid + 1u; else hi = mid;
+    }
+    uint32_t i = lo, j = d - lo;
+    cnt = min((uint32_t)E, b1 - o0);
+    unsigned long long va = i < lenA ? s[padk(a0 + i)] : ~0ull, vb = j < lenB ? s[padk(b0 + j)] : ~0ull;
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+      const bool take_a = va < vb;                      // an exhausted run reads as +inf; real keys are unique and smaller
+      out[k] = take_a ? va : vb;
+      if (take_a) { ++i; va = i < lenA ? s[padk(a0 + i)] : ~0ull; }
+      else { ++j; vb = j < lenB ? s[padk(b0 + j)] : ~0ull; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < E; k++)
+    if ((uint32_t)k < cnt) s[padk(o0 + k)] = out[k];
+  __syncthreads();
+}
+
+// n keys (512 < n <= NT * 16) from global `src` to global `dst`, sorted, by the NT threads of the workgroup:
+//   pass 0   every wave sorts 512-key blocks straight from global memory in registers (wave_sort) and parks them in LDS;
+//   levels   L = 512, 1024, ... : merge_level (8 outputs per thread while the list fits NT * 8 keys, else 16);
+//   copy     LDS -> dst, coalesced.
 template <int NT>
 __device__ void lds_sort(unsigned long long* s, uint32_t n, const unsigned long long* src, unsigned long long* dst) {
   constexpr int WAVES = NT / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t m = 512;
-  while (m < n) m <<= 1;
   __syncthreads();                                   // the previous tile's readers are done with s
+  if (n <= 512) {                                    // one block: registers only
+    if (wave == 0) {
+      unsigned long long v[8];
+      wave_load<8>(src, n, 0, lane, v);
+      wave_sort<8>(v, lane);
+      wave_store<8>(dst, n, 0, lane, v);
+    }
+    return;
+  }
   for (uint32_t base = wave * 512; base < n; base += WAVES * 512) {
     unsigned long long v[8];
     wave_load<8>(src, n, base, lane, v);
     wave_sort<8>(v, lane);
-    wave_store<8>(m == 512 ? dst : s, n, base, lane, v);
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const uint32_t i = base + r * 64 + lane; if (i < n) s[padk(i)] = v[r]; }
   }
-  if (m == 512) return;
   __syncthreads();
-  const uint32_t half = m >> 1;
-  for (uint32_t k = 1024; k <= m; k <<= 1) {
-    const uint32_t hk = k >> 1;
-    for (uint32_t t = threadIdx.x; t < half; t += NT) {   // flip stage
-      const uint32_t base = (t & ~(hk - 1)) << 1, off = t & (hk - 1);
-      const uint32_t lo = base + off, hi = base + k - 1 - off;
-      if (hi < n) {
-        const unsigned long long x = s[lo], y = s[hi];
-        if (x > y) { s[lo] = y; s[hi] = x; }
-      }
-    }
-    __syncthreads();
-    for (uint32_t j = k >> 2; j >= 512; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < half; t += NT) {
-        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo + j;
-        if (hi < n) {
-          const unsigned long long x = s[lo], y = s[hi];
-          if (x > y) { s[lo] = y; s[hi] = x; }
-        }
-      }
-      __syncthreads();
-    }
-    for (uint32_t base = wave * 512; base < n; base += WAVES * 512) {
-      unsigned long long v[8];
-      wave_load<8>(s, n, base, lane, v);
-      wave_tail<8>(v, lane);
-      wave_store<8>(k == m ? dst : s, n, base, lane, v);
-    }
-    __syncthreads();
+  if (n <= (uint32_t)NT * 8u) {
+    for (uint32_t L = 512; L < n; L <<= 1) merge_level<8>(s, n, L, threadIdx.x);
+  } else {
+    for (uint32_t L = 512; L < n; L <<= 1) merge_level<16>(s, n, L, threadIdx.x);
   }
+  for (uint32_t i = threadIdx.x; i < n; i += NT) dst[i] = s[padk(i)];
 }
 
 // the strides hi_stride .. 1 (hi_stride < chunk) of one merge stage on an n-key chunk: global -> LDS, strides >= 512 as LDS
@@ -576,50 +601,29 @@ __device__ __forceinline__ void write_seg_tiles(const GipKernelParams& kp, const
     if (s0 + b < kp.seg_capacity) seg_tile[s0 + b] = t;
 }
 
-// phase M worker: the calling 256-thread quarter sorts a[0, n) (n < 2048; n == 0: no tile, barriers only) in its LDS slice
+// phase M worker: the calling 256-thread quarter sorts a[0, n) (n < 2048; n == 0: no tile, barriers only) in its LDS slice:
+// one 512-key register block per wave, then the two merge levels 512 -> 1024 -> 2048, then the coalesced copy out.
+// Fixed sequence for every quarter, so the workgroup barriers inside merge_level line up.
 __device__ void quarter_sort(unsigned long long* s, uint32_t n, unsigned long long* a) {
-  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3, ltid = threadIdx.x & 255;
-  const uint32_t base = w * 512;
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
+  const uint32_t ltid = threadIdx.x & 255, base = w * 512;
   const bool multi = n > 512;
   if (base < n) {
     unsigned long long v[8];
     wave_load<8>(a, n, base, lane, v);
     wave_sort<8>(v, lane);
-    wave_store<8>(multi ? s : a, n, base, lane, v);
+    if (multi) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) { const uint32_t i = base + r * 64 + lane; if (i < n) s[padk(i)] = v[r]; }
+    } else {
+      wave_store<8>(a, n, base, lane, v);
+    }
   }
   __syncthreads();
-#pragma unroll 1
-  for (uint32_t k = 1024; k <= 2048; k <<= 1) {
-    const uint32_t hk = k >> 1;
-    if (multi)
-      for (uint32_t t = ltid; t < 1024; t += 256) {               // flip stage
-        const uint32_t b0 = (t & ~(hk - 1)) << 1, off = t & (hk - 1);
-        const uint32_t lo = b0 + off, hi = b0 + k - 1 - off;
-        if (hi < n) {
-          const unsigned long long x = s[lo], y = s[hi];
-          if (x > y) { s[lo] = y; s[hi] = x; }
-        }
-      }
-    __syncthreads();
-    if (k == 2048) {
-      if (multi)
-        for (uint32_t t = ltid; t < 1024; t += 256) {             // stride 512
-          const uint32_t lo = ((t & ~511u) << 1) | (t & 511u), hi = lo + 512;
-          if (hi < n) {
-            const unsigned long long x = s[lo], y = s[hi];
-            if (x > y) { s[lo] = y; s[hi] = x; }
-          }
-        }
-      __syncthreads();
-    }
-    if (multi && base < n) {
-      unsigned long long v[8];
-      wave_load<8>(s, n, base, lane, v);
-      wave_tail<8>(v, lane);
-      wave_store<8>(k == 2048 ? a : s, n, base, lane, v);
-    }
-    __syncthreads();
-  }
+  const uint32_t nm = multi ? n : 0u;
+  merge_level<8>(s, nm, 512, ltid);
+  merge_level<8>(s, nm, 1024, ltid);
+  for (uint32_t i = ltid; i < nm; i += 256) a[i] = s[padk(i)];
 }
 
 __global__ void __launch_bounds__(LONG_THREADS)
@@ -673,7 +677,7 @@ gip_tile_sort_kernel(GipKernelParams kp, GipRasterHeader* __restrict__ header, c
             if (s0 + b < kp.seg_capacity) seg_tile[s0 + b] = t;
         }
       }
-      quarter_sort(s_long + q * 2048, n > 1 ? n : 0, a);
+      quarter_sort(s_long + q * PADK_SLOTS(2048), n > 1 ? n : 0, a);
     }
   }
   // ---- phase B: wave per tile, static round-robin over all waves of the grid (no barrier from here on) ----
@@ -704,7 +708,7 @@ gip_tile_sort_kernel(GipKernelParams kp, GipRasterHeader* __restrict__ header, c
 void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process); one workgroup per CU
   static int wgs = 0;
-  constexpr size_t lds = (size_t)LONG_CHUNK * sizeof(unsigned long long);
+  constexpr size_t lds = (size_t)PADK_SLOTS(LONG_CHUNK) * sizeof(unsigned long long);
   if (!wgs) {
     (void)hipFuncSetAttribute((const void*)gip_tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int dev = 0, cus = 0;
