@@ -101,7 +101,10 @@ class _ForwardStats:
     def wait(self):
         """Joins the side stream; returns (radii_max [P] int32, depth_max 0-d float32), global over all ranks."""
         if self._side is not None:
-            torch.cuda.current_stream(self.radii.device).wait_stream(self._side)
+            cur = torch.cuda.current_stream(self.radii.device)
+            cur.wait_stream(self._side)
+            self.radii.record_stream(cur)          # allocated on the side stream, consumed on the caller's
+            self.depth_max.record_stream(cur)
             self._side = None
         return self.radii, self.depth_max
 
