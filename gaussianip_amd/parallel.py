@@ -119,6 +119,8 @@ def exchange_forward_stats(radii_per_view: torch.Tensor, depth: torch.Tensor, gr
         if side is None:
             side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        radii_per_view.record_stream(side)
+        depth.record_stream(side)
         with torch.cuda.stream(side):
             rmax, dmax = radii_per_view.amax(dim=0), depth.detach().amax()
             exchange_max(rmax, dmax, group)
