@@ -117,7 +117,7 @@ def main():
         if world > 1:
             for p_, g_ in zip(plist, grads[:-1]):
                 p_.grad = g_
-            parallel.exchange_sum(plist, torch.linalg.vector_norm(grads[-1][..., :2], dim=-1).sum(0))
+            parallel.exchange_sum(plist, viewspace_grads=grads[-1])
             pending.wait()
         return color
 

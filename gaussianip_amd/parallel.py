@@ -27,14 +27,57 @@ def _copy_back(dsts, srcs):
             d.copy_(s_)
 
 
+def _bucket_fast_path(dsts, extra):
+    ts = list(dsts) + ([extra] if extra is not None else [])
+    return bool(ts) and len(dsts) <= 12 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+
+
 def exchange_sum(params: Sequence[torch.Tensor], viewspace_grad_norm: Optional[torch.Tensor] = None, group=None,
-                 average: bool = False) -> Optional[torch.Tensor]:
-    """all_reduce(sum) of `p.grad` for all params and of `viewspace_grad_norm` [P] through ONE flat bucket, in place
-    (pack = one cat kernel, unpack = one multi-tensor copy).  `average` divides the gradients (not the norms) by the
-    world size."""
+                 average: bool = False, viewspace_grads: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """all_reduce(sum) of `p.grad` for all params and of the per-Gaussian view-space gradient norms through ONE flat
+    bucket.  The norms come either ready-made (`viewspace_grad_norm` [P], updated in place) or as the raw means2D
+    gradients of the local views (`viewspace_grads` [V, P, 3]): then sum_v |grad_xy| is computed by the packing kernel
+    and the reduced [P] tensor is returned.  `average` divides the gradients (not the norms) by the world size.
+    On the GPU the bucket is packed and unpacked by one launch each (gip_pack_bucket / gip_unpack_bucket)."""
     if not _on(group):
+        if viewspace_grads is not None:
+            return torch.linalg.vector_norm(viewspace_grads[..., :2], dim=-1).sum(0)
         return viewspace_grad_norm
     grads = [p.grad for p in params if p.grad is not None]
+    world = dist.get_world_size(group)
+    if _bucket_fast_path(grads + ([viewspace_grad_norm] if viewspace_grad_norm is not None else []), viewspace_grads):
+        import ctypes
+        from . import _lib
+        lib = _lib.model_lib()
+        dsts = grads + ([viewspace_grad_norm] if viewspace_grad_norm is not None else [])
+        n_scaled = len(grads)
+        counts = [d.numel() for d in dsts]
+        P = int(viewspace_grads.shape[1]) if viewspace_grads is not None else 0
+        V = int(viewspace_grads.shape[0]) if viewspace_grads is not None else 0
+        dev = (dsts[0] if dsts else viewspace_grads).device
+        flat = torch.empty(sum(counts) + P, device=dev, dtype=torch.float32)
+        seg = (ctypes.c_void_p * max(len(dsts), 1))(*[d.data_ptr() for d in dsts])
+        cnt = (ctypes.c_int64 * max(len(dsts), 1))(*counts)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        g2d = ctypes.c_void_p(viewspace_grads.data_ptr()) if viewspace_grads is not None else ctypes.c_void_p(None)
+        rc = lib.gip_pack_bucket(seg, cnt, len(dsts), g2d, V, P, ctypes.c_void_p(flat.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError("gip_pack_bucket failed with status %d" % rc)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        # gradients (scaled when averaged) and a ready-made norm tensor (never scaled) go back in place
+        if average and n_scaled < len(dsts):
+            rc = lib.gip_unpack_bucket(seg, cnt, n_scaled, ctypes.c_void_p(dsts[-1].data_ptr()), counts[-1],
+                                       ctypes.c_void_p(flat.data_ptr()), 1.0 / world, stream)
+        else:
+            rc = lib.gip_unpack_bucket(seg, cnt, len(dsts), ctypes.c_void_p(None), 0, ctypes.c_void_p(flat.data_ptr()),
+                                       1.0 / world if average else 1.0, stream)
+        if rc != 0:
+            raise RuntimeError("gip_unpack_bucket failed with status %d" % rc)
+        if viewspace_grads is not None:
+            return flat[sum(counts):]
+        return viewspace_grad_norm
+    if viewspace_grads is not None:
+        viewspace_grad_norm = torch.linalg.vector_norm(viewspace_grads[..., :2], dim=-1).sum(0)
     dsts = list(grads)
     if viewspace_grad_norm is not None:
         dsts.append(viewspace_grad_norm)
@@ -45,7 +88,7 @@ def exchange_sum(params: Sequence[torch.Tensor], viewspace_grad_norm: Optional[t
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average and grads:
         n_grad = sum(g.numel() for g in grads)
-        flat[:n_grad].mul_(1.0 / dist.get_world_size(group))
+        flat[:n_grad].mul_(1.0 / world)
     _copy_back(dsts, [c.view_as(d) for d, c in zip(dsts, flat.split([d.numel() for d in dsts]))])
     return viewspace_grad_norm
 
@@ -91,40 +134,36 @@ def exchange_max(radii: Optional[torch.Tensor] = None, depth_max: Optional[torch
     return h
 
 
-_side_streams = {}
-
-
 class _ForwardStats:
-    def __init__(self, radii, depth_max, side):
-        self.radii, self.depth_max, self._side = radii, depth_max, side
+    def __init__(self, radii, depth_max, work):
+        self.radii, self.depth_max, self._work = radii, depth_max, work
 
     def wait(self):
-        """Joins the side stream; returns (radii_max [P] int32, depth_max 0-d float32), global over all ranks."""
-        if self._side is not None:
-            cur = torch.cuda.current_stream(self.radii.device)
-            cur.wait_stream(self._side)
-            self.radii.record_stream(cur)          # allocated on the side stream, consumed on the caller's
-            self.depth_max.record_stream(cur)
-            self._side = None
+        """Returns (radii_max [P] int32, depth_max 0-d float32), global over all ranks."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
         return self.radii, self.depth_max
 
 
 def exchange_forward_stats(radii_per_view: torch.Tensor, depth: torch.Tensor, group=None) -> _ForwardStats:
-    """The MAX bucket straight from the forward outputs — radii [V, P] int32 and the depth images — reduced over the
-    local views / pixels AND exchanged on a side HIP stream, so that the small reduction / packing kernels and the
-    collective's latency all hide under the raster backward that the caller enqueues next.  .wait() before use."""
-    if radii_per_view.is_cuda:
-        dev = radii_per_view.device
-        side = _side_streams.get(dev.index)
-        if side is None:
-            side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        radii_per_view.record_stream(side)
-        depth.record_stream(side)
-        with torch.cuda.stream(side):
-            rmax, dmax = radii_per_view.amax(dim=0), depth.detach().amax()
-            exchange_max(rmax, dmax, group)
-        return _ForwardStats(rmax, dmax, side)
+    """The MAX bucket straight from the forward outputs — radii [V, P] int32 and the depth images (>= 0).  On the GPU one
+    kernel (gip_max_bucket) reduces both into an int32 bucket [P + 1] and the all-reduce is started asynchronously, so its
+    latency hides under the raster backward that the caller enqueues next; the results are views of the bucket (no
+    unpacking).  .wait() before use."""
+    if radii_per_view.is_cuda and radii_per_view.dtype == torch.int32 and radii_per_view.is_contiguous() and \
+            depth.dtype == torch.float32 and depth.is_contiguous():
+        import ctypes
+        from . import _lib
+        V, P = int(radii_per_view.shape[0]), int(radii_per_view.shape[1])
+        bucket = torch.empty(P + 1, device=radii_per_view.device, dtype=torch.int32)
+        rc = _lib.model_lib().gip_max_bucket(ctypes.c_void_p(radii_per_view.data_ptr()), V, P, ctypes.c_void_p(depth.data_ptr()),
+                                             depth.numel(), ctypes.c_void_p(bucket.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream(bucket.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_max_bucket failed with status %d" % rc)
+        work = dist.all_reduce(bucket, op=dist.ReduceOp.MAX, group=group, async_op=True) if _on(group) else None
+        return _ForwardStats(bucket[:P], bucket[P:].view(torch.float32).reshape(()), work)
     rmax, dmax = radii_per_view.amax(dim=0), depth.detach().amax()
     exchange_max(rmax, dmax, group)
     return _ForwardStats(rmax, dmax, None)

@@ -52,6 +52,11 @@ def _worker(rank, world, port, out):
     for i, p in enumerate(params):
         ref = sum(gathered[r]["local"][i] for r in range(world))
         assert torch.allclose(p.grad, ref, atol=1e-5)        # sum over ranks of the same reduced value / world
+    g2 = torch.rand(3, P, 3, generator=g)                    # raw means2D gradients of three local views
+    red = parallel.exchange_sum([], viewspace_grads=g2.clone())
+    all_g2 = [None] * world
+    dist.all_gather_object(all_g2, g2)
+    assert torch.allclose(red, sum(torch.linalg.vector_norm(x[..., :2], dim=-1).sum(0) for x in all_g2), atol=1e-5)
     # broadcast of a model-like object
     class M:
         pass

@@ -330,3 +330,48 @@ def test_stage_three_step_with_lpips_term():
     gm.optimizer.zero_grad(set_to_none=True)
     out["loss"].backward()
     assert float(gm._features_dc.grad.abs().max()) > 0 and torch.isfinite(gm._xyz.grad).all()
+
+
+def test_exchange_bucket_pack_and_unpack_kernels():
+    """gip_pack_bucket / gip_unpack_bucket (include/gip_model.h; the per-step multi-GPU exchange of parallel.py) against
+    torch.cat / vector_norm / split on odd sizes and unaligned segment starts."""
+    import ctypes
+    from gaussianip_amd import _lib
+    lib = _lib.model_lib()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    P, V = 1237, 3
+    shapes = [(P, 3), (P, 1, 3), (P, 1), (P, 3), (P, 4), (5,)]
+    segs = [torch.randn(sh, device="cuda", generator=g) for sh in shapes]
+    g2d = torch.randn(V, P, 3, device="cuda", generator=g)
+    counts = [t.numel() for t in segs]
+    flat = torch.full((sum(counts) + P,), float("nan"), device="cuda")
+    ptrs = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for t in segs])
+    cnt = (ctypes.c_int64 * len(segs))(*counts)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.gip_pack_bucket(ptrs, cnt, len(segs), ctypes.c_void_p(g2d.data_ptr()), V, P, ctypes.c_void_p(flat.data_ptr()), stream) == 0
+    want = torch.cat([t.reshape(-1) for t in segs] + [torch.linalg.vector_norm(g2d[..., :2], dim=-1).sum(0)])
+    assert torch.equal(flat[:sum(counts)], want[:sum(counts)])
+    assert torch.allclose(flat[sum(counts):], want[sum(counts):], rtol=1e-6, atol=1e-7)
+    # unpack: the first five segments scaled by 1/4, the sixth (a ready-made statistic) and nothing else unscaled
+    outs = [torch.zeros_like(t) for t in segs]
+    optr = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+    assert lib.gip_unpack_bucket(optr, cnt, 5, ctypes.c_void_p(outs[5].data_ptr()), counts[5], ctypes.c_void_p(flat.data_ptr()), 0.25, stream) == 0
+    for i in range(5):
+        assert torch.equal(outs[i], segs[i] * 0.25)
+    assert torch.equal(outs[5], segs[5])
+    # no tail, no scaling
+    outs2 = [torch.zeros_like(t) for t in segs]
+    optr2 = (ctypes.c_void_p * len(outs2))(*[t.data_ptr() for t in outs2])
+    assert lib.gip_unpack_bucket(optr2, cnt, len(segs), ctypes.c_void_p(None), 0, ctypes.c_void_p(flat.data_ptr()), 1.0, stream) == 0
+    assert all(torch.equal(a, b) for a, b in zip(outs2, segs))
+    # MAX bucket: radii maximum over the views + depth maximum as its bit pattern
+    radii = torch.randint(0, 300, (V, P), device="cuda", generator=g, dtype=torch.int32)
+    depth = torch.rand(V, 1, 37, 53, device="cuda", generator=g) * 7.0
+    mb = torch.full((P + 1,), -5, device="cuda", dtype=torch.int32)
+    assert lib.gip_max_bucket(ctypes.c_void_p(radii.data_ptr()), V, P, ctypes.c_void_p(depth.data_ptr()), depth.numel(),
+                              ctypes.c_void_p(mb.data_ptr()), stream) == 0
+    assert torch.equal(mb[:P], radii.amax(0)) and float(mb[P:].view(torch.float32)) == float(depth.max())
+    from gaussianip_amd import parallel
+    r2, d2 = parallel.exchange_forward_stats(radii, depth).wait()            # single process: the same numbers, no collective
+    assert torch.equal(r2, radii.amax(0)) and float(d2) == float(depth.max())
+

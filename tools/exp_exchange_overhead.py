@@ -18,16 +18,17 @@ gC = torch.randn((V, 3, H, W), device=dev) * 1e-3; gD = torch.randn((V, 1, H, W)
 plist = [t[n] for n in ["means3D", "shs", "opacities", "scales", "rotations"]]
 class W_:
     def wait(self): pass
+MODE = os.environ.get("MODE", "both")
 def step(multi):
     m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
     color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], sts, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
-    if multi:
+    if multi and MODE in ("both", "max"):
         pending = parallel.exchange_forward_stats(radii, depth)
     grads = torch.autograd.grad([color, depth], plist + [m2d], [gC, gD])
     if multi:
         for p_, g_ in zip(plist, grads[:-1]): p_.grad = g_
-        parallel.exchange_sum(plist, torch.linalg.vector_norm(grads[-1][..., :2], dim=-1).sum(0))
-        pending.wait()
+        if MODE in ("both", "sum"): parallel.exchange_sum(plist, viewspace_grads=grads[-1])
+        if MODE in ("both", "max"): pending.wait()
 def timeit(multi, n=200):
     for _ in range(20): step(multi)
     torch.cuda.synchronize(); t0 = time.perf_counter()
