@@ -116,6 +116,21 @@ class RasterOracle:
         self.lib.oracle_copy_binning(self.ctx, _p(keys), _p(vals), _p(ranges), _p(tt), _p(nc))
         return keys, vals, ranges, tt, nc
 
+    def pixel_margins(self, pix_ids):
+        """Knife-edge margin (see oracle_pixel_margins in raster_oracle.c) of the given flat pixel ids y * W + x."""
+        ids = np.ascontiguousarray(np.asarray(pix_ids, dtype=np.int32))
+        out = np.zeros(ids.shape[0], np.float32)
+        if ids.shape[0]:
+            self.lib.oracle_pixel_margins(self.ctx, _p(ids), ctypes.c_int(ids.shape[0]), _p(out))
+        return out
+
+    def knife_edge_gaussians(self, thresh=2e-5):
+        """(bool [P] mask of the Gaussians that are the subject of a knife-edge threshold test, number of such pixels)."""
+        flags = np.zeros(self.P, np.uint8)
+        self.lib.oracle_knife_edge_gaussians.restype = ctypes.c_int
+        n = self.lib.oracle_knife_edge_gaussians(self.ctx, ctypes.c_float(thresh), _p(flags))
+        return flags.astype(bool), int(n)
+
     def geom(self):
         P = self.P
         out = dict(means2D=np.zeros((P, 2), np.float32), depths=np.zeros((P,), np.float32),
@@ -125,7 +140,12 @@ class RasterOracle:
                                   _p(out["conic_opacity"]), _p(out["clamped"]))
         return out
 
-    def backward(self, dL_dcolor=None, dL_ddepth=None, dL_dalpha=None):
+    def backward(self, dL_dcolor=None, dL_ddepth=None, dL_dalpha=None, alpha_out=None):
+        """`alpha_out` [1,H,W]: the forward's alpha image the backward derives T_final = 1 - alpha from (the fork passes
+        its own forward output).  Default: this oracle's forward output.  Passing the alpha image of the implementation
+        under test isolates the backward: where a pixel is nearly opaque, T_final is the difference of two nearly equal
+        numbers and a 1e-7 difference between two forwards' alpha becomes a percent-level difference in every T_j of
+        that pixel — a property of the reference's formulation, not of either implementation."""
         a = self.args
         P, M = self.P, self.M
         g = dict(means3D=np.zeros((P, 3), np.float32), means2D=np.zeros((P, 3), np.float32),
@@ -140,7 +160,8 @@ class RasterOracle:
         rc = self.lib.oracle_raster_backward(
             self.ctx, _p(a["means3D"]), _p(a["shs"]), _p(a["colors_precomp"]), _p(a["scales"]), _p(a["rotations"]),
             _p(a["cov3D_precomp"]), ctypes.c_float(self.scale_modifier), _p(a["viewmatrix"]), _p(a["projmatrix"]),
-            _p(a["campos"]), _p(a["bg"]), ctypes.c_float(self.tanfovx), ctypes.c_float(self.tanfovy), _p(self.alpha),
+            _p(a["campos"]), _p(a["bg"]), ctypes.c_float(self.tanfovx), ctypes.c_float(self.tanfovy),
+            _p(self.alpha if alpha_out is None else _f32(alpha_out).reshape(self.alpha.shape)),
             _p(gc), _p(gd), _p(ga), _p(g["means3D"]), _p(g["means2D"]), _p(g["shs"]), _p(g["colors_precomp"]),
             _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["cov3D_precomp"]), _p(acc))
         if rc != 0:

@@ -404,6 +404,72 @@ void oracle_copy_geom(const oracle_ctx* c, float* means2D, float* depths, float*
   if (clamped) memcpy(clamped, c->clamped, P * 3);
 }
 
+/* Knife-edge margin of a pixel: the smallest relative distance of any of the forward walk's three threshold tests
+ * from flipping, min over the entries the walk visits of |alpha - 1/255| / (1/255), |T (1 - alpha) - 1e-4| / 1e-4 and
+ * |power| (the power > 0 rejection).  Two correct implementations whose exp differs in the last ulp (libm expf here,
+ * v_exp_f32 on the GPU, __expf / expf in CUDA) can only disagree by more than rounding at pixels where this margin is
+ * of the order of 1e-6; the parity tests use it to PROVE that an out-of-tolerance pixel is such a pixel instead of
+ * allowing a blanket fraction of mismatches. */
+void oracle_pixel_margins(const oracle_ctx* c, const int32_t* pix_ids, int n, float* margins) {
+  for (int q = 0; q < n; q++) {
+    const int pix_id = pix_ids[q], px = pix_id % c->W, py = pix_id / c->W;
+    const int tile = (py / TILE) * c->tiles_x + px / TILE;
+    const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
+    float T = 1.0f, m = 1e30f;
+    for (uint32_t k = r0; k < r1; k++) {
+      const uint32_t g = c->values[k];
+      const float dx = c->means2D[2 * g] - (float)px, dy = c->means2D[2 * g + 1] - (float)py;
+      const float* co = c->conic_opacity + 4 * g;
+      const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+      m = fminf(m, fabsf(power));
+      if (power > 0.0f) continue;
+      const float alpha = fminf(0.99f, co[3] * expf(power));
+      m = fminf(m, fabsf(alpha - 1.0f / 255.0f) * 255.0f);
+      if (alpha < 1.0f / 255.0f) continue;
+      const float test_T = T * (1 - alpha);
+      m = fminf(m, fabsf(test_T - 0.0001f) * 10000.0f);
+      if (test_T < 0.0001f) break;
+      T = test_T;
+    }
+    margins[q] = m;
+  }
+}
+
+/* flags[g] = 1 for every Gaussian g that is the SUBJECT of a knife-edge threshold test at some pixel (its alpha within
+ * `thresh` (relative) of 1/255, its power within `thresh` of 0, or the transmittance test T (1 - alpha) < 1e-4 decided
+ * within `thresh` at its entry): the set of gradient rows that a legitimately different decision changes by one whole
+ * pixel contribution.  Entries behind a flipped one see T change by at most 0.4 % at that single pixel (alpha flips)
+ * or contribute with T < 1e-4 (termination flips) and are not flagged.  Returns the number of knife-edge pixels. */
+int oracle_knife_edge_gaussians(const oracle_ctx* c, float thresh, uint8_t* flags) {
+  const int H = c->H, W = c->W;
+  int count = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : count)
+  for (int pix_id = 0; pix_id < H * W; pix_id++) {
+    const int px = pix_id % W, py = pix_id / W;
+    const int tile = (py / TILE) * c->tiles_x + px / TILE;
+    const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
+    float T = 1.0f;
+    int hit = 0;
+    for (uint32_t k = r0; k < r1; k++) {
+      const uint32_t g = c->values[k];
+      const float dx = c->means2D[2 * g] - (float)px, dy = c->means2D[2 * g + 1] - (float)py;
+      const float* co = c->conic_opacity + 4 * g;
+      const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+      if (fabsf(power) < thresh) { flags[g] = 1; hit = 1; } /* benign race: every writer stores 1 */
+      if (power > 0.0f) continue;
+      const float alpha = fminf(0.99f, co[3] * expf(power));
+      if (fabsf(alpha - 1.0f / 255.0f) * 255.0f < thresh) { flags[g] = 1; hit = 1; }
+      if (alpha < 1.0f / 255.0f) continue;
+      const float test_T = T * (1 - alpha);
+      if (fabsf(test_T - 0.0001f) * 10000.0f < thresh) { flags[g] = 1; hit = 1; }
+      if (test_T < 0.0001f) break;
+      T = test_T;
+    }
+    count += hit;
+  }
+  return count;
+}
+
 /* ------------------------------- backward ------------------------------- */
 /* per-Gaussian accumulators: 0,1 mean2D.xy  2,3,4 conic (x, y, w slots of the fork's float4)  5 opacity
  * 6,7,8 colour  9 depth */
@@ -411,20 +477,16 @@ void oracle_copy_geom(const oracle_ctx* c, float* means2D, float* depths, float*
 
 static void render_backward(const oracle_ctx* c, const float* bg, const float* alphas, const float* dL_dpixels,
                             const float* dL_ddepths, const float* dL_dalphas, double* acc /* [P,NACC] */) {
-  const int H = c->H, W = c->W, P = c->P;
+  const int H = c->H, W = c->W;
   const int tiles = c->tiles_x * c->tiles_y;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-  int nthreads = 1;
-#ifdef _OPENMP
-  nthreads = omp_get_max_threads();
-#endif
-  double* priv = (nthreads > 1) ? (double*)calloc((size_t)nthreads * P * NACC, sizeof(double)) : NULL;
+  const int exact_final_T = getenv("ORACLE_EXACT_FINAL_T") != NULL;
+  /* One row of NACC sums per (tile, Gaussian) instance, filled by the tile's own thread; the rows are then added to
+   * the per-Gaussian accumulators in list order by one thread.  The result does not depend on the thread count and
+   * the scratch is R x NACC doubles (it used to be nthreads x P x NACC, 2 GB at 256 threads). */
+  double* rows = (double*)calloc((size_t)(c->num_rendered ? c->num_rendered : 1) * NACC, sizeof(double));
 #pragma omp parallel for schedule(dynamic, 1)
   for (int tile = 0; tile < tiles; tile++) {
-    double* A = acc;
-#ifdef _OPENMP
-    if (priv) A = priv + (size_t)omp_get_thread_num() * P * NACC;
-#endif
     const int tx = tile % c->tiles_x, ty = tile / c->tiles_x;
     const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
     for (int ly = 0; ly < TILE; ly++)
@@ -433,7 +495,7 @@ static void render_backward(const oracle_ctx* c, const float* bg, const float* a
         if (px >= W || py >= H) continue;
         const int pix_id = W * py + px;
         const float pixf[2] = {(float)px, (float)py};
-        const float T_final = getenv("ORACLE_EXACT_FINAL_T") ? c->final_T[pix_id] : 1.f - alphas[pix_id];
+        const float T_final = exact_final_T ? c->final_T[pix_id] : 1.f - alphas[pix_id];
         float T = T_final;
         const uint32_t last_contributor = c->n_contrib[pix_id];
         float accum_rec[3] = {0, 0, 0}, accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
@@ -446,6 +508,7 @@ static void render_backward(const oracle_ctx* c, const float* bg, const float* a
           const uint32_t contributor = k - r0; /* 0-based position in the tile list */
           if (contributor >= last_contributor) continue;
           const uint32_t g = c->values[k];
+          double* A = rows + (size_t)k * NACC;
           const float dx = c->means2D[2 * g] - pixf[0], dy = c->means2D[2 * g + 1] - pixf[1];
           const float* co = c->conic_opacity + 4 * g;
           const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
@@ -461,13 +524,13 @@ static void render_backward(const oracle_ctx* c, const float* bg, const float* a
             accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
             last_color[ch] = col;
             dL_dalpha += (col - accum_rec[ch]) * dL_dpixel[ch];
-            A[(size_t)g * NACC + 6 + ch] += (double)(dchannel_dcolor * dL_dpixel[ch]);
+            A[6 + ch] += (double)(dchannel_dcolor * dL_dpixel[ch]);
           }
           const float c_d = c->depths[g];
           accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
           last_depth = c_d;
           dL_dalpha += (c_d - accum_depth_rec) * dL_dpixel_depth;
-          A[(size_t)g * NACC + 9] += (double)(dchannel_dcolor * dL_dpixel_depth);
+          A[9] += (double)(dchannel_dcolor * dL_dpixel_depth);
           accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
           dL_dalpha += (1.f - accum_alpha_rec) * dL_dpixel_alpha;
           dL_dalpha *= T;
@@ -479,23 +542,23 @@ static void render_backward(const oracle_ctx* c, const float* bg, const float* a
           const float gdx = G * dx, gdy = G * dy;
           const float dG_ddelx = -gdx * co[0] - gdy * co[1];
           const float dG_ddely = -gdy * co[2] - gdx * co[1];
-          A[(size_t)g * NACC + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-          A[(size_t)g * NACC + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
-          A[(size_t)g * NACC + 2] += (double)(-0.5f * gdx * dx * dL_dG);
-          A[(size_t)g * NACC + 3] += (double)(-0.5f * gdx * dy * dL_dG);
-          A[(size_t)g * NACC + 4] += (double)(-0.5f * gdy * dy * dL_dG);
-          A[(size_t)g * NACC + 5] += (double)(G * dL_dalpha);
+          A[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+          A[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+          A[2] += (double)(-0.5f * gdx * dx * dL_dG);
+          A[3] += (double)(-0.5f * gdx * dy * dL_dG);
+          A[4] += (double)(-0.5f * gdy * dy * dL_dG);
+          A[5] += (double)(G * dL_dalpha);
         }
       }
   }
-  if (priv) {
-    for (int t = 0; t < nthreads; t++) {
-      const double* S = priv + (size_t)t * P * NACC;
-      for (size_t i = 0; i < (size_t)P * NACC; i++) acc[i] += S[i];
-    }
-    free(priv);
+  for (uint64_t k = 0; k < c->num_rendered; k++) {
+    double* dst = acc + (size_t)c->values[k] * NACC;
+    const double* src = rows + (size_t)k * NACC;
+    for (int j = 0; j < NACC; j++) dst[j] += src[j];
   }
+  free(rows);
 }
+
 
 static void preprocess_backward(const oracle_ctx* c, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,

@@ -45,9 +45,15 @@ def _dev(a):
 
 
 def _check_forward(oracle, kind, P, H, W, seed, sh_degree, cam_args, bg=(0.0, 0.0, 0.0), nc_mismatch_frac=2e-4):
-    from gaussianip_amd import rasterizer as R
     sc = scenes.make_scene(kind, P, seed=seed, sh_degree=sh_degree)
     cam = scenes.camera(*cam_args, H, W)
+    return _check_forward_scene(oracle, sc, cam, H, W, sh_degree, bg, nc_mismatch_frac)[0]
+
+
+def _check_forward_scene(oracle, sc, cam, H, W, sh_degree, bg=(0.0, 0.0, 0.0), nc_mismatch_frac=2e-4):
+    """Forward of one view through the C-ABI against the oracle: integer buffers bit-exact, images within IMG_TOL.
+    Returns (num_rendered, oracle object with its forward state) so a backward comparison can follow."""
+    from gaussianip_amd import rasterizer as R
     ro, (o_color, o_radii, o_depth, o_alpha) = _oracle_forward(oracle, sc, cam, H, W, bg, sh_degree)
     st = _settings(cam, H, W, bg, sh_degree)
     (color, radii, depth, alpha), plan = R.forward_with_state(
@@ -80,12 +86,35 @@ def _check_forward(oracle, kind, P, H, W, seed, sh_degree, cam_args, bg=(0.0, 0.
     assert np.array_equal(ts[:-1][ne], ranges[ne, 0].astype(np.int64)), "ranges.x"
     assert np.array_equal(ts[1:][ne], ranges[ne, 1].astype(np.int64)), "ranges.y"
     # ---- images ----
-    np.testing.assert_allclose(color[0].cpu().numpy(), o_color, atol=IMG_TOL, rtol=0)
-    np.testing.assert_allclose(depth[0].cpu().numpy(), o_depth, atol=IMG_TOL * max(1.0, float(o_depth.max())), rtol=0)
-    np.testing.assert_allclose(alpha[0].cpu().numpy(), o_alpha, atol=IMG_TOL, rtol=0)
-    mism = (sv["n_contrib"][0].cpu().numpy().astype(np.uint32) != nc).mean()
-    assert mism <= nc_mismatch_frac, "n_contrib mismatch fraction %.2e" % mism
-    return Rn
+    _assert_images(ro, color[0], depth[0], alpha[0], o_color, o_depth, o_alpha, sv["n_contrib"][0], nc, nc_mismatch_frac)
+    return Rn, ro
+
+
+KNIFE_EDGE = 2e-5
+
+
+def _assert_images(ro, color, depth, alpha, o_color, o_depth, o_alpha, n_contrib=None, o_n_contrib=None,
+                   max_frac=2e-4):
+    """colour / alpha within IMG_TOL, depth within IMG_TOL * max(1, depth), n_contrib equal — at every pixel except
+    PROVEN knife-edge pixels: pixels where one of the walk's threshold tests (alpha >= 1/255, T (1 - alpha) >= 1e-4,
+    power <= 0) sits within KNIFE_EDGE (relative) of flipping in the oracle, so that libm expf and v_exp_f32 may
+    legitimately decide differently (the same holds between the CUDA fork's expf and any CPU statement).  Their number is
+    bounded by `max_frac` of the image as well."""
+    color, depth, alpha = (t.detach().cpu().numpy() for t in (color, depth, alpha))
+    bad = (np.abs(color - o_color) > IMG_TOL).any(0)
+    bad |= np.abs(depth[0] - o_depth[0]) > IMG_TOL * max(1.0, float(o_depth.max()))
+    bad |= np.abs(alpha[0] - o_alpha[0]) > IMG_TOL
+    if n_contrib is not None:
+        bad |= n_contrib.cpu().numpy().astype(np.uint32) != o_n_contrib
+    ids = np.flatnonzero(bad.reshape(-1))
+    assert ids.size <= max_frac * bad.size, "%d pixels out of tolerance" % ids.size
+    if ids.size:
+        margins = ro.pixel_margins(ids)
+        worst = int(np.argmax(margins))
+        assert margins[worst] < KNIFE_EDGE, (
+            "pixel %d differs from the oracle by more than the tolerance and is NOT a knife-edge pixel (margin %.2e)"
+            % (ids[worst], margins[worst]))
+    return ids.size
 
 
 @pytest.mark.parametrize("kind,P,H,W,seed,deg", [
