@@ -9,8 +9,9 @@ Differences: networks come from gaussianip_amd.guidance.networks (no diffusers d
 dicts are supplied); text / face-ID embeddings are inputs (`PromptEmbeddings`, `set_image_embeds`) because CLIP,
 insightface and the checkpoints are outside this path; the frozen LoRA is folded into the base weights once.
 """
+from collections.abc import Mapping
 from dataclasses import dataclass, field, fields
-from typing import Any, Optional
+from typing import Any, Callable, Optional
 
 import torch
 import torch.nn.functional as F
@@ -49,12 +50,22 @@ class GuidanceConfig:
                 "enable_sequential_cpu_offload", "enable_attention_slicing", "enable_channels_last_format",
                 "ipa_faceid_s_scale", "grad_clip", "max_items_eval", "lw_depth", "original_size", "target_size")
 
+    # the reference's own Config defaults (ipa_guidance.py:74-123) for the keys modelled above: a cfg mapping that
+    # omits a key gets THESE (what `threestudio.find("ipa-guidance")(cfg)` would give), not the shipped-YAML values
+    # that the dataclass defaults carry for the benchmark and the tests
+    _REFERENCE_DEFAULTS = dict(use_ipa_faceid=True, use_pose_controlnet=True, batch_size=4, guidance_scale=7.5,
+                               ipa_scale=0.6, ipa_faceid_scale=0.6, half_precision_weights=True, use_anpg=False,
+                               weighting_strategy="sds", view_dependent_prompting=True, guidance_rescale=0.0,
+                               grad_clip_pixel=False, grad_clip_threshold=0.1)
+
     @classmethod
     def from_dict(cls, d: dict) -> "GuidanceConfig":
         """Build from the `system.guidance` section of the reference's YAML (configs/exp.yaml:78-120): the keys the
-        per-step path reads become fields, the remaining reference keys are kept in `extra`, unknown keys raise."""
+        per-step path reads become fields (missing ones take the reference Config's defaults), the remaining reference
+        keys are kept in `extra`, unknown keys raise."""
         names = {f.name for f in fields(cls)} - {"extra"}
-        own = {k: v for k, v in d.items() if k in names}
+        own = dict(cls._REFERENCE_DEFAULTS)
+        own.update({k: v for k, v in d.items() if k in names})
         rest = {k: v for k, v in d.items() if k not in names}
         unknown = [k for k in rest if k not in cls._PASSIVE]
         if unknown:
@@ -84,13 +95,22 @@ class PromptEmbeddings:
 class StableDiffusionGuidance:
     registry_name = "ipa-guidance"
 
-    def __init__(self, cfg: Optional[GuidanceConfig] = None, device="cuda", unet=None, controlnet=None, vae=None,
-                 schedule: Optional[AHDSSchedule] = None, checkpoints: Optional[dict] = None):
-        """`checkpoints` (optional): {"unet": path, "controlnet": path, "vae": path, "ip_adapter": path} — diffusers-format
+    def __init__(self, cfg=None, device="cuda", unet=None, controlnet=None, vae=None,
+                 schedule: Optional[AHDSSchedule] = None, checkpoints: Optional[dict] = None,
+                 image_embeds_provider: Optional[Callable] = None):
+        """`cfg`: a GuidanceConfig, or the mapping `threestudio.find("ipa-guidance")(cfg)` hands over (the
+        `system.guidance` YAML section, dict or DictConfig; GaussianIP.py:355) -> GuidanceConfig.from_dict.
+        `image_embeds_provider(guidance) -> (pos, neg, null)` image-prompt tokens, each [1, 4, 768]: what the reference's
+        prepare_for_sds computes with insightface + the IP-Adapter projection (ipa_guidance.py:236-275); called by
+        prepare_for_sds.  `checkpoints` (optional): {"unet": path, "controlnet": path, "vae": path, "ip_adapter": path} — diffusers-format
         .safetensors / .bin files (runwayml/stable-diffusion-v1-5 unet, lllyasviel/control_v11p_sd15_openpose,
         stabilityai/sd-vae-ft-mse, h94/IP-Adapter-FaceID ip-adapter-faceid-plusv2_sd15.bin; the names the reference loads at
         ipa_guidance.py:127-185).  Without it the networks keep their deterministic random initialisation."""
+        if isinstance(cfg, Mapping):
+            cfg = GuidanceConfig.from_dict(dict(cfg))
         self.cfg = cfg or GuidanceConfig()
+        self.image_embeds_provider = image_embeds_provider
+        self._image_embeds_set = False
         self.device = torch.device(device)
         self.weights_dtype = torch.float16 if self.cfg.half_precision_weights else torch.float32
         scale = self.cfg.ipa_faceid_scale if self.cfg.use_ipa_faceid else self.cfg.ipa_scale
@@ -132,23 +152,35 @@ class StableDiffusionGuidance:
             ck.load_ip_adapter_faceid(self.unet, state.get("ip_adapter", state))
 
     def prepare_for_sds(self, prompt=None, negative_prompt=None, null_prompt=None, image_embeds=None):
-        """Same entry point as ipa_guidance.py:236-275.  The reference runs insightface FaceAnalysis + the IP-Adapter
-        image projection here to turn the identity photo into (pos, null, neg) image-token triples; those models are the
-        caller's (not shippable, not on the per-step path), so the triple is passed in: image_embeds = (pos, neg, null),
-        each [1 or B, 4, 768].  The text prompts are accepted for signature compatibility (they are consumed by the
-        prompt processor, `prompt_utils`, exactly as in the reference)."""
-        if image_embeds is None:
-            raise ValueError("prepare_for_sds: pass image_embeds=(pos, neg, null) image-prompt tokens "
-                             "(face-ID analysis and the IP-Adapter image projection run outside this package)")
-        self.set_image_embeds(*image_embeds)
-        self.bs_embed, self.seq_len = self.pos_image_embeds.shape[0], self.pos_image_embeds.shape[1]
-        self.num_samples = self.cfg.batch_size if hasattr(self.cfg, "batch_size") else 1
+        """Same entry point and positional signature as ipa_guidance.py:236 — `guidance.prepare_for_sds(prompt,
+        negative_prompt, null_prompt)` at GaussianIP.py:356.  The reference runs insightface FaceAnalysis + the
+        IP-Adapter image projection here to turn the identity photo into (pos, null, neg) image tokens; those models are
+        the caller's (not shippable, not on the per-step path), so the tokens come from, in this order: the
+        `image_embeds` keyword, the `image_embeds_provider` given at construction, or an earlier `set_image_embeds`.
+        With none of the three the call fails loudly.  The tokens are tiled to `cfg.batch_size` rows like :279-288.
+        The text prompts are consumed by the prompt processor (`prompt_utils`), exactly as in the reference's
+        view-dependent path; they are kept as attributes."""
+        self.prompt, self.negative_prompt, self.null_prompt = prompt, negative_prompt, null_prompt
+        if image_embeds is None and self.image_embeds_provider is not None:
+            image_embeds = self.image_embeds_provider(self)
+        if image_embeds is not None:
+            self.set_image_embeds(*image_embeds)
+        if not self._image_embeds_set:
+            raise RuntimeError("prepare_for_sds: no image-prompt tokens — construct the guidance with "
+                               "image_embeds_provider=..., or call set_image_embeds(pos, neg, null) first (face-ID "
+                               "analysis and the IP-Adapter image projection run outside this package)")
+        self.num_samples = int(self.cfg.batch_size)
+        tile = lambda e: e.expand(self.num_samples, -1, -1).contiguous() if e.shape[0] == 1 else e  # noqa: E731
+        self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = (
+            tile(self.pos_image_embeds), tile(self.neg_image_embeds), tile(self.null_image_embeds))
+        self.bs_embed, self.seq_len = 1, self.pos_image_embeds.shape[1]
 
     def set_image_embeds(self, pos, neg, null):
         """[1 or B, 4, 768] face-ID image tokens: pos = identity, null = irrelevant face, neg = zeros
         (ip_adapter_faceid.py:362-382, ipa_guidance.py:250-257)."""
         cast = lambda t: t.to(self.device, self.weights_dtype)  # noqa: E731
         self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = cast(pos), cast(neg), cast(null)
+        self._image_embeds_set = True
 
     # ------------------------------------------------------------------ networks
     def embed_control(self, control_img):
@@ -188,11 +220,11 @@ class StableDiffusionGuidance:
         text = prompt_utils.get_text_embeddings(elevation, azimuth, center, all_vis_all, camera_distances,
                                                 self.cfg.view_dependent_prompting).to(self.weights_dtype)
         pos_t, neg_t, null_t = text[:B], text[B:2 * B], text[2 * B:3 * B]
-        ex = lambda e: e.expand(B, -1, -1) if e.shape[0] == 1 else e  # noqa: E731
+        ex = lambda e: e.expand(B, -1, -1) if e.shape[0] == 1 else e[:B]  # noqa: E731
         pos = torch.cat([pos_t, ex(self.pos_image_embeds)], dim=1)
         neg = torch.cat([neg_t, ex(self.neg_image_embeds)], dim=1)
         if n_sets == 2:
-            return torch.cat([pos, neg], dim=0)
+            return torch.cat([neg, pos], dim=0)                    # ipa_guidance.py:470
         null = torch.cat([null_t, ex(self.null_image_embeds)], dim=1)
         return torch.cat([neg, pos, null], dim=0)
 
@@ -222,9 +254,8 @@ class StableDiffusionGuidance:
             noise_pred = self.forward_unet(torch.cat([latents_noisy] * 2, dim=0), control_img,
                                            torch.cat([t] * 2), embeds, use_pose_controlnet)
             direction = sds.cfg_direction(noise_pred, noise, self.cfg.guidance_scale, self.cfg.guidance_rescale)
+        # no per-pixel clip here: the reference applies grad_clip_pixel only on the ANPG path (:427-431 vs :513)
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
-        if self.cfg.grad_clip_pixel:
-            grad = sds.clip_grad_pixel(grad, self.cfg.grad_clip_threshold)
         return grad, {"t_orig": t, "latents_noisy": latents_noisy, "noise_pred": noise_pred}
 
     # ------------------------------------------------------------------ the plugin call
@@ -241,3 +272,18 @@ class StableDiffusionGuidance:
                      camera_distances, generator)
         loss_sds, grad = sds.sds_loss(latents, grad)
         return {"loss_sds": loss_sds, "grad_norm": grad.norm()}
+
+
+def _register_with_threestudio():
+    """`@threestudio.register("ipa-guidance")` (ipa_guidance.py:71) when the host framework is importable: the system's
+    `threestudio.find(self.cfg.guidance_type)(self.cfg.guidance)` (GaussianIP.py:355) then returns this class."""
+    try:
+        import threestudio
+        register = threestudio.register
+    except Exception:       # threestudio itself needs pytorch_lightning / omegaconf / tinycudann at import time
+        return False
+    register(StableDiffusionGuidance.registry_name)(StableDiffusionGuidance)
+    return True
+
+
+REGISTERED = _register_with_threestudio()

@@ -3,7 +3,7 @@
 Mirrors `refine_rgb` (threestudio/models/guidance/refine.py:115-239), `IPAdapterFaceID.refine_with_small_noise`
 (ip_adapter_faceid.py:451-515) and the denoising loop of `__call_refine__` (pipeline_ipa_controlnet.py:1447-1877):
 every render is VAE-encoded at full resolution, noised with ONE shared noise tensor to the first of the last 8 of 50
-DDIM timesteps, denoised for those 8 steps with ControlNet + U-Net under classifier-free guidance 7.5, and decoded.
+DDIM timesteps (142 ... 0), denoised for those 8 steps with ControlNet + U-Net under classifier-free guidance 7.5, and decoded.
 The nine self-attentions of up_blocks.1-3 run in the 'refine' state (`networks.Attention._forward_refine`): the four
 canonical views store their tokens, the four diagonal key views attend mutually with front / back, all other views blend
 their own attention with attentions over their two neighbouring key views (weights 0.75/0.5/0.25, lambda_self 0.55).
@@ -33,8 +33,11 @@ NEGATIVE_PROMPT = "blurry face, bad face, poorly drawn face, duplicate face, ext
 
 
 def refine_timesteps(num_steps=8, num_inference_steps=50, device=None):
-    """linspace(0, 999, 50).round().flip()[-num_steps:]  (refine.py:176-178) = 143, 122, 102, 82, 61, 41, 20, 0."""
-    ts = torch.linspace(0, 999, num_inference_steps, dtype=torch.float64).round().to(torch.int64).flip(dims=[0])
+    """torch.linspace(0, 999, 50, dtype=torch.int64).round().flip()[-num_steps:]  (refine.py:176-178).  The int64
+    linspace TRUNCATES each sample (the .round() after it is a no-op), so the last eight are
+    142, 122, 101, 81, 61, 40, 20, 0 — not the rounded 143, 122, 102, 82, 61, 41, 20, 0.  Pinned by
+    tests/golden/refine_timesteps.npz (the reference's expression evaluated as written)."""
+    ts = torch.linspace(0, 999, num_inference_steps, dtype=torch.int64).flip(dims=[0])
     return ts[-num_steps:].to(device) if device is not None else ts[-num_steps:]
 
 

@@ -41,8 +41,9 @@ def anpg_direction(noise_pred, t, guidance_scale=7.5, t_switch=170):
 
 
 def cfg_direction(noise_pred, noise, guidance_scale=7.5, guidance_rescale=0.0):
-    """Plain SDS (use_anpg = False, :443-519): noise_pred [2B,...] ordered (text | uncond)."""
-    eps_text, eps_uncond = noise_pred.chunk(2)
+    """Plain SDS (use_anpg = False, :443-519): noise_pred [2B,...] ordered (neg | pos) like the reference's batch
+    (`final_prompt_embeds = cat([neg, pos])` :470, `noise_pred_neg, noise_pred_pos = chunk(2)` :495)."""
+    eps_uncond, eps_text = noise_pred.chunk(2)
     eps = eps_uncond + guidance_scale * (eps_text - eps_uncond)
     if guidance_rescale > 0:
         eps = rescale_noise_cfg(eps, eps_text, guidance_rescale)

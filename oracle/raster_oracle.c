@@ -560,6 +560,116 @@ static void render_backward(const oracle_ctx* c, const float* bg, const float* a
 }
 
 
+/* SH colour backward of one Gaussian (preprocessCUDA backward -> computeColorFromSH backward): gcol = dL/d(rgb after
+ * the +0.5 / clamp), already zeroed on clamped channels by the caller's `clamped` flags.  Writes dL/dsh [M,3] and ADDS the
+ * view-direction part to dmean.  Pinned against autograd through the reference's own Python statement of the same
+ * forward (gaussian_renderer/__init__.py:74-78 + sh_utils.py:57-112) by tests/test_golden_host.py. */
+static void sh_backward(int D, int M, const float* m, const float* campos, const float* sh, const uint8_t* clamped,
+                        const float* gcol_in, float* dsh, float* dmean) {
+  float gcol[3] = {gcol_in[0], gcol_in[1], gcol_in[2]};
+  (void)M;
+  float dir0[3] = {m[0] - campos[0], m[1] - campos[1], m[2] - campos[2]};
+  const float len = sqrtf(dir0[0] * dir0[0] + dir0[1] * dir0[1] + dir0[2] * dir0[2]);
+  const float x = dir0[0] / len, y = dir0[1] / len, z = dir0[2] / len;
+  for (int ch = 0; ch < 3; ch++) gcol[ch] *= clamped[ch] ? 0.f : 1.f;
+  float ddir[3] = {0, 0, 0};
+  for (int ch = 0; ch < 3; ch++) {
+#define SH(k) sh[(k) * 3 + ch]
+#define DSH(k, v) do { if (dsh) dsh[(k) * 3 + ch] = (v) * gcol[ch]; } while (0)
+    float dx_ = 0, dy_ = 0, dz_ = 0;
+    DSH(0, SH_C0);
+    if (D > 0) {
+      DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
+      dx_ = -SH_C1 * SH(3); dy_ = -SH_C1 * SH(1); dz_ = SH_C1 * SH(2);
+      if (D > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        DSH(4, SH_C2[0] * xy); DSH(5, SH_C2[1] * yz); DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+        DSH(7, SH_C2[3] * xz); DSH(8, SH_C2[4] * (xx - yy));
+        dx_ += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+        dy_ += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+        dz_ += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+        if (D > 2) {
+          DSH(9, SH_C3[0] * y * (3.f * xx - yy)); DSH(10, SH_C3[1] * xy * z);
+          DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy)); DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+          DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy)); DSH(14, SH_C3[5] * z * (xx - yy));
+          DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+          dx_ += SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                 SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                 SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy);
+          dy_ += SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz + SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                 SH_C3[3] * SH(12) * -3.f * 2.f * yz + SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
+                 SH_C3[6] * SH(15) * -3.f * 2.f * xy;
+          dz_ += SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz + SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                 SH_C3[4] * SH(13) * 4.f * 2.f * xz + SH_C3[5] * SH(14) * (xx - yy);
+        }
+      }
+    }
+#undef SH
+#undef DSH
+    ddir[0] += dx_ * gcol[ch]; ddir[1] += dy_ * gcol[ch]; ddir[2] += dz_ * gcol[ch];
+  }
+  /* through the normalisation dir / |dir| */
+  const float sum2 = dir0[0] * dir0[0] + dir0[1] * dir0[1] + dir0[2] * dir0[2];
+  const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+  dmean[0] += ((sum2 - dir0[0] * dir0[0]) * ddir[0] - dir0[1] * dir0[0] * ddir[1] - dir0[2] * dir0[0] * ddir[2]) * invsum32;
+  dmean[1] += (-dir0[0] * dir0[1] * ddir[0] + (sum2 - dir0[1] * dir0[1]) * ddir[1] - dir0[2] * dir0[1] * ddir[2]) * invsum32;
+  dmean[2] += (-dir0[0] * dir0[2] * ddir[0] - dir0[1] * dir0[2] * ddir[1] + (sum2 - dir0[2] * dir0[2]) * ddir[2]) * invsum32;
+}
+
+/* computeCov3D backward of one Gaussian: dcov = dL/d(packed xx,xy,xz,yy,yz,zz) -> dL/dscale, dL/dquaternion.
+ * Reference quirks reproduced: the scale gradient is taken w.r.t. scale_modifier*scale (not multiplied by the modifier)
+ * and the quaternion is differentiated as given (no normalisation inside; GaussianModel.get_rotation normalises
+ * upstream).  Pinned against autograd through general_utils.build_scaling_rotation / strip_symmetric by
+ * tests/test_golden_host.py (which applies exactly those two relations). */
+static void cov3D_backward(const float* scale, float scale_modifier, const float* q, const float* dcov, float* ds_out,
+                           float* dq_out) {
+  const float s[3] = {scale_modifier * scale[0], scale_modifier * scale[1], scale_modifier * scale[2]};
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                      2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                      2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
+  /* full symmetric dSigma (off-diagonals halved), dL/dL = 2 dSigma L with L = R diag(s) */
+  const float dS[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                       0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+  float dLm[9]; /* dL/dL[i][k] */
+  for (int ii = 0; ii < 3; ii++)
+    for (int k = 0; k < 3; k++)
+      dLm[ii * 3 + k] = 2.0f * (dS[ii * 3 + 0] * R[0 * 3 + k] * s[k] + dS[ii * 3 + 1] * R[1 * 3 + k] * s[k] + dS[ii * 3 + 2] * R[2 * 3 + k] * s[k]);
+  /* NOTE (reference quirk, reproduced): the fork's dL_dscale is the gradient w.r.t. mod*scale, it is
+   * not multiplied by scale_modifier.  Identical at scale_modifier = 1 (the only differentiated case). */
+  if (ds_out)
+    for (int k = 0; k < 3; k++)
+      ds_out[k] = R[0 * 3 + k] * dLm[0 * 3 + k] + R[1 * 3 + k] * dLm[1 * 3 + k] + R[2 * 3 + k] * dLm[2 * 3 + k];
+  if (dq_out) {
+    float dR[9];
+    for (int ii = 0; ii < 3; ii++)
+      for (int k = 0; k < 3; k++) dR[ii * 3 + k] = dLm[ii * 3 + k] * s[k];
+#define DR(i_, j_) dR[(i_) * 3 + (j_)]
+    dq_out[0] = 2 * z * (DR(1, 0) - DR(0, 1)) + 2 * y * (DR(0, 2) - DR(2, 0)) + 2 * x * (DR(2, 1) - DR(1, 2));
+    dq_out[1] = 2 * y * (DR(0, 1) + DR(1, 0)) + 2 * z * (DR(0, 2) + DR(2, 0)) + 2 * r * (DR(2, 1) - DR(1, 2)) - 4 * x * (DR(2, 2) + DR(1, 1));
+    dq_out[2] = 2 * x * (DR(0, 1) + DR(1, 0)) + 2 * r * (DR(0, 2) - DR(2, 0)) + 2 * z * (DR(1, 2) + DR(2, 1)) - 4 * y * (DR(2, 2) + DR(0, 0));
+    dq_out[3] = 2 * r * (DR(1, 0) - DR(0, 1)) + 2 * x * (DR(0, 2) + DR(2, 0)) + 2 * y * (DR(1, 2) + DR(2, 1)) - 4 * z * (DR(1, 1) + DR(0, 0));
+#undef DR
+  }
+}
+
+/* entry points for the reference-pinned checks of the two per-Gaussian backward stages */
+void oracle_sh_backward(int P, int D, int M, const float* means3D, const float* campos, const float* shs,
+                        const uint8_t* clamped, const float* gcol, float* dL_dshs, float* dL_dmeans3D) {
+  for (int i = 0; i < P; i++) {
+    float dmean[3] = {0, 0, 0};
+    float g[3];
+    for (int ch = 0; ch < 3; ch++) g[ch] = gcol[3 * i + ch] * (clamped[3 * i + ch] ? 0.f : 1.f);
+    sh_backward(D, M, means3D + 3 * i, campos, shs + (size_t)i * M * 3, clamped + 3 * i, g, dL_dshs + (size_t)i * M * 3, dmean);
+    for (int k = 0; k < 3; k++) dL_dmeans3D[3 * i + k] = dmean[k];
+  }
+}
+void oracle_cov3D_backward(int P, const float* scales, float scale_modifier, const float* rotations, const float* dcov,
+                           float* dL_dscales, float* dL_drots) {
+  for (int i = 0; i < P; i++)
+    cov3D_backward(scales + 3 * i, scale_modifier, rotations + 4 * i, dcov + 6 * i, dL_dscales + 3 * i, dL_drots + 4 * i);
+}
+
 static void preprocess_backward(const oracle_ctx* c, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 float scale_modifier, const float* view, const float* proj, const float* campos,
@@ -647,54 +757,8 @@ static void preprocess_backward(const oracle_ctx* c, const float* means3D, const
     if (colors_precomp) {
       if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
     } else if (shs) {
-      const float* sh = shs + (size_t)i * M * 3;
-      float dir0[3] = {m[0] - campos[0], m[1] - campos[1], m[2] - campos[2]};
-      const float len = sqrtf(dir0[0] * dir0[0] + dir0[1] * dir0[1] + dir0[2] * dir0[2]);
-      const float x = dir0[0] / len, y = dir0[1] / len, z = dir0[2] / len;
-      for (int ch = 0; ch < 3; ch++) gcol[ch] *= c->clamped[3 * i + ch] ? 0.f : 1.f;
-      float ddir[3] = {0, 0, 0};
-      float* dsh = dL_dshs ? dL_dshs + (size_t)i * M * 3 : NULL;
-      for (int ch = 0; ch < 3; ch++) {
-#define SH(k) sh[(k) * 3 + ch]
-#define DSH(k, v) do { if (dsh) dsh[(k) * 3 + ch] = (v) * gcol[ch]; } while (0)
-        float dx_ = 0, dy_ = 0, dz_ = 0;
-        DSH(0, SH_C0);
-        if (D > 0) {
-          DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
-          dx_ = -SH_C1 * SH(3); dy_ = -SH_C1 * SH(1); dz_ = SH_C1 * SH(2);
-          if (D > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            DSH(4, SH_C2[0] * xy); DSH(5, SH_C2[1] * yz); DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
-            DSH(7, SH_C2[3] * xz); DSH(8, SH_C2[4] * (xx - yy));
-            dx_ += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
-            dy_ += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
-            dz_ += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
-            if (D > 2) {
-              DSH(9, SH_C3[0] * y * (3.f * xx - yy)); DSH(10, SH_C3[1] * xy * z);
-              DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy)); DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-              DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy)); DSH(14, SH_C3[5] * z * (xx - yy));
-              DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
-              dx_ += SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
-                     SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
-                     SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy);
-              dy_ += SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz + SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
-                     SH_C3[3] * SH(12) * -3.f * 2.f * yz + SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
-                     SH_C3[6] * SH(15) * -3.f * 2.f * xy;
-              dz_ += SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz + SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
-                     SH_C3[4] * SH(13) * 4.f * 2.f * xz + SH_C3[5] * SH(14) * (xx - yy);
-            }
-          }
-        }
-#undef SH
-#undef DSH
-        ddir[0] += dx_ * gcol[ch]; ddir[1] += dy_ * gcol[ch]; ddir[2] += dz_ * gcol[ch];
-      }
-      /* through the normalisation dir / |dir| */
-      const float sum2 = dir0[0] * dir0[0] + dir0[1] * dir0[1] + dir0[2] * dir0[2];
-      const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-      dmean[0] += ((sum2 - dir0[0] * dir0[0]) * ddir[0] - dir0[1] * dir0[0] * ddir[1] - dir0[2] * dir0[0] * ddir[2]) * invsum32;
-      dmean[1] += (-dir0[0] * dir0[1] * ddir[0] + (sum2 - dir0[1] * dir0[1]) * ddir[1] - dir0[2] * dir0[1] * ddir[2]) * invsum32;
-      dmean[2] += (-dir0[0] * dir0[2] * ddir[0] - dir0[1] * dir0[2] * ddir[1] + (sum2 - dir0[2] * dir0[2]) * ddir[2]) * invsum32;
+      sh_backward(D, M, m, campos, shs + (size_t)i * M * 3, c->clamped + 3 * i, gcol,
+                  dL_dshs ? dL_dshs + (size_t)i * M * 3 : NULL, dmean);
     }
     if (dL_dmeans3D) { dL_dmeans3D[3 * i] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2]; }
 
@@ -702,35 +766,8 @@ static void preprocess_backward(const oracle_ctx* c, const float* means3D, const
     if (cov3D_precomp) {
       if (dL_dcov3D) memcpy(dL_dcov3D + 6 * i, dcov, 6 * sizeof(float));
     } else if (scales) {
-      const float* q = rotations + 4 * i;
-      const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1], scale_modifier * scales[3 * i + 2]};
-      const float r = q[0], x = q[1], y = q[2], z = q[3];
-      const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-                          2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-                          2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
-      /* full symmetric dSigma (off-diagonals halved), dL/dL = 2 dSigma L with L = R diag(s) */
-      const float dS[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
-                           0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
-      float dLm[9]; /* dL/dL[i][k] */
-      for (int ii = 0; ii < 3; ii++)
-        for (int k = 0; k < 3; k++)
-          dLm[ii * 3 + k] = 2.0f * (dS[ii * 3 + 0] * R[0 * 3 + k] * s[k] + dS[ii * 3 + 1] * R[1 * 3 + k] * s[k] + dS[ii * 3 + 2] * R[2 * 3 + k] * s[k]);
-      /* NOTE (reference quirk, reproduced): the fork's dL_dscale is the gradient w.r.t. mod*scale, it is
-       * not multiplied by scale_modifier.  Identical at scale_modifier = 1 (the only differentiated case). */
-      if (dL_dscales)
-        for (int k = 0; k < 3; k++)
-          dL_dscales[3 * i + k] = R[0 * 3 + k] * dLm[0 * 3 + k] + R[1 * 3 + k] * dLm[1 * 3 + k] + R[2 * 3 + k] * dLm[2 * 3 + k];
-      if (dL_drots) {
-        float dR[9];
-        for (int ii = 0; ii < 3; ii++)
-          for (int k = 0; k < 3; k++) dR[ii * 3 + k] = dLm[ii * 3 + k] * s[k];
-#define DR(i_, j_) dR[(i_) * 3 + (j_)]
-        dL_drots[4 * i + 0] = 2 * z * (DR(1, 0) - DR(0, 1)) + 2 * y * (DR(0, 2) - DR(2, 0)) + 2 * x * (DR(2, 1) - DR(1, 2));
-        dL_drots[4 * i + 1] = 2 * y * (DR(0, 1) + DR(1, 0)) + 2 * z * (DR(0, 2) + DR(2, 0)) + 2 * r * (DR(2, 1) - DR(1, 2)) - 4 * x * (DR(2, 2) + DR(1, 1));
-        dL_drots[4 * i + 2] = 2 * x * (DR(0, 1) + DR(1, 0)) + 2 * r * (DR(0, 2) - DR(2, 0)) + 2 * z * (DR(1, 2) + DR(2, 1)) - 4 * y * (DR(2, 2) + DR(0, 0));
-        dL_drots[4 * i + 3] = 2 * r * (DR(1, 0) - DR(0, 1)) + 2 * x * (DR(0, 2) + DR(2, 0)) + 2 * y * (DR(1, 2) + DR(2, 1)) - 4 * z * (DR(1, 1) + DR(0, 0));
-#undef DR
-      }
+      cov3D_backward(scales + 3 * i, scale_modifier, rotations + 4 * i, dcov, dL_dscales ? dL_dscales + 3 * i : NULL,
+                     dL_drots ? dL_drots + 4 * i : NULL);
     }
   }
 }

@@ -84,3 +84,38 @@ def _two_sets(g, D):
         ref = F.scaled_dot_product_attention(sp(q), sp(k1), sp(v1)) + 0.5 * F.scaled_dot_product_attention(sp(q), sp(k2), sp(v2))
         ref = ref.transpose(1, 2).reshape(B, N, H * D)
     assert float((o.float() - ref).abs().max()) <= 3e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_reference_processor_fixtures_through_the_hip_attention(monkeypatch, fold):
+    """The outputs of the REFERENCE's LoRAAttnProcessor2_0 / LoRAIPAttnProcessor2_0 (tests/golden/attention_processors.npz,
+    attention_processor_faceid.py:211-523) reproduced by networks.Attention in fp16 with the MFMA attention kernel:
+    256-token cases run the HIP kernel (asserted), the 64-token ones its fallback.  fp16 tolerance: 1e-2 of max|out|."""
+    import os
+    import numpy as np
+    import fixture_inputs as fx
+    from test_golden_guidance import GOLD, make_attention
+    from gaussianip_amd.guidance import fused
+    d = np.load(os.path.join(GOLD, "attention_processors.npz"))
+    dim, heads, rank, B = int(d["dim"]), int(d["heads"]), int(d["rank"]), int(d["batch"])
+    calls = []
+    orig = fused.attention
+    monkeypatch.setattr(fused, "attention", lambda *a: (calls.append(len(a)), orig(*a))[1])
+    dev = dict(device="cuda", dtype=torch.float16)
+    a_self = make_attention(fx.attn_weights(11, dim, None, rank), dim, None, heads, rank, False, fold=fold, **dev)
+    a_cross = make_attention(fx.attn_weights(12, dim, 768, rank, ip=True), dim, 768, heads, rank, True, float(d["ip_scale"]),
+                             fold=fold, **dev)
+    with torch.no_grad():
+        for n_tok, nb in ((64, B), (256, 1)):
+            before = len(calls)
+            x = torch.from_numpy(fx.attn_tokens(21 + n_tok, nb, n_tok, dim)).cuda().half()
+            want = d["self_normal_%d" % n_tok]
+            got = a_self(x).float().cpu().numpy()
+            assert np.abs(got - want).max() < 1e-2 * np.abs(want).max(), ("self", n_tok)
+            x = torch.from_numpy(fx.attn_tokens(31 + n_tok, nb, n_tok, dim)).cuda().half()
+            ctx = torch.from_numpy(fx.attn_tokens(41, nb, 81, 768)).cuda().half()
+            want = d["cross_ip_%d" % n_tok]
+            got = a_cross(x, ctx).float().cpu().numpy()
+            assert np.abs(got - want).max() < 1e-2 * np.abs(want).max(), ("cross", n_tok)
+            if n_tok == 256:
+                assert calls[before:] == [4, 7], calls[before:]     # one plain call, one two-key-set call of the HIP kernel

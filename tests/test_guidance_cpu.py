@@ -120,7 +120,7 @@ def test_refine_tables_ddim_and_attention_state_machine():
     import torch.nn.functional as F
     from gaussianip_amd.guidance import refine as rf, sds
     from gaussianip_amd.guidance.networks import Attention, init_for_benchmark
-    assert rf.refine_timesteps(8).tolist() == [143, 122, 102, 82, 61, 41, 20, 0]
+    assert rf.refine_timesteps(8).tolist() == [142, 122, 101, 81, 61, 40, 20, 0]   # tests/golden/refine_timesteps.npz
     assert len(rf.VIEW_IDX_ALL) == 32 and sorted(rf.VIEW_IDX_ALL) == list(range(32)) and rf.VIEW_NAME_ALL[8] == "v0"
     assert rf.KEY_VIEW_NAME_PAIR["v0"] == ("left", "k0") and rf.KEY_VIEW_NAME_PAIR["v5"] == ("k0", "front")
     assert rf.KEY_VIEW_NAME_PAIR["v17"] == ("k2", "back") and rf.KEY_VIEW_NAME_PAIR["v23"] == ("k3", "left")
@@ -129,9 +129,9 @@ def test_refine_tables_ddim_and_attention_state_machine():
     acp = sds.alphas_cumprod()
     g = torch.Generator().manual_seed(0)
     x0, eps = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
-    xt = sds.add_noise(x0, eps, torch.tensor([143]), acp)
-    prev = rf.ddim_step(xt, eps, 143, acp)
-    assert torch.allclose(prev, acp[123].sqrt() * x0 + (1 - acp[123]).sqrt() * eps, atol=1e-5)
+    xt = sds.add_noise(x0, eps, torch.tensor([142]), acp)
+    prev = rf.ddim_step(xt, eps, 142, acp)
+    assert torch.allclose(prev, acp[122].sqrt() * x0 + (1 - acp[122]).sqrt() * eps, atol=1e-5)
     last = rf.ddim_step(sds.add_noise(x0, eps, torch.tensor([0]), acp), eps, 0, acp)          # prev < 0 -> alphas[0]
     assert torch.allclose(last, acp[0].sqrt() * x0 + (1 - acp[0]).sqrt() * eps, atol=1e-5)
     # attention state machine against a direct restatement with torch SDPA
@@ -282,3 +282,92 @@ def test_lpips_vgg_restatement_properties_and_state_dict_names():
     assert torch.allclose(d2, d, rtol=1e-6, atol=1e-8)
     d2.sum().backward()
     assert float(a.grad.abs().max()) > 0 and all(not p.requires_grad for p in m.parameters())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# drop-in boundary of the guidance plugin: constructed from the cfg mapping and called exactly as
+# threestudio/systems/GaussianIP.py:355-356 (on_fit_start) and :362-373 (training_step) do
+# ---------------------------------------------------------------------------------------------------------------
+class _TinyVAE(torch.nn.Module):
+    scaling_factor = 0.18215
+
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(3, 4, 8, stride=8)
+
+    def encode(self, x, generator=None):
+        return self.conv(x) * self.scaling_factor
+
+
+class _TinyControlNet(torch.nn.Module):
+    def embed_condition(self, cond):
+        return torch.nn.functional.adaptive_avg_pool2d(cond, 64).mean(1, keepdim=True)
+
+    def forward(self, x, t, ctx, cond, scale=1.0, cond_embedding=None):
+        c = cond_embedding
+        if c.shape[0] != x.shape[0]:
+            c = c.repeat(x.shape[0] // c.shape[0], 1, 1, 1)
+        return [c], c
+
+
+class _TinyUNet(torch.nn.Module):
+    def fold_lora(self, scale=1.0):
+        return self
+
+    def forward(self, x, t, ctx, down=None, mid=None):
+        out = 0.9 * x + ctx.mean(dim=(1, 2)).view(-1, 1, 1, 1) + 1e-3 * t.view(-1, 1, 1, 1).to(x.dtype)
+        return out if mid is None else out + 0.1 * mid
+
+
+_EXP_YAML_GUIDANCE = dict(     # configs/exp.yaml:78-120 (paths shortened), half precision off for the CPU run
+    batch_size=4, enable_memory_efficient_attention=True, grad_clip=[0, 1.5, 2.0, 1000], grad_clip_pixel=True,
+    grad_clip_threshold=1.0, guidance_rescale=0.75, guidance_scale=7.5, image_encoder_faceid_path="/p/clip",
+    image_encoder_path="/p/enc", ip_ckpt_faceid_v1_path="/p/v1.bin", ip_ckpt_faceid_v2_path="/p/v2.bin", ip_ckpt_path="/p/ip.bin",
+    ipa_faceid_s_scale=0.4, ipa_faceid_scale=0.5, ipa_scale=0.6, irr_pil_image_path="/p/irr.png", lw_depth=0.5,
+    negative_prompt="cloned face", negative_prompt_faceid="cloned face", null_prompt="", original_size=1024,
+    pil_image_faceid_path="/p/face.png", pose_controlnet_path="/p/cn", pretrained_realistic_model_name_or_path="/p/rv",
+    pretrained_sd_model_name_or_path="/p/sd", prompt="Audrey Hepburn wearing a tailored blazer", target_size=1024, use_anpg=True,
+    use_ipa_faceid=True, use_pose_controlnet=True, vae_path="/p/vae", view_dependent_prompting=True, weighting_strategy="sds",
+    half_precision_weights=False)
+
+
+def test_guidance_plugin_is_called_like_the_reference_system_calls_it():
+    from gaussianip_amd.guidance import StableDiffusionGuidance
+    from gaussianip_amd.guidance.ahds import AHDSSchedule
+    from gaussianip_amd.guidance.prompts import PromptProcessor
+    g = torch.Generator().manual_seed(0)
+    tokens = (torch.randn(1, 4, 768, generator=g) * 0.1, torch.zeros(1, 4, 768), torch.randn(1, 4, 768, generator=g) * 0.1)
+    mk = lambda provider: StableDiffusionGuidance(  # noqa: E731        threestudio.find("ipa-guidance")(cfg)
+        _EXP_YAML_GUIDANCE, device="cpu", unet=_TinyUNet(), controlnet=_TinyControlNet(), vae=_TinyVAE(),
+        schedule=AHDSSchedule(list(range(799, -1, -1)) * 3), image_embeds_provider=provider)
+    guidance = mk(lambda gd: tokens)
+    assert guidance.registry_name == "ipa-guidance"
+    cfg = guidance.cfg
+    assert (cfg.use_anpg, cfg.grad_clip_pixel, cfg.grad_clip_threshold, cfg.ipa_faceid_scale, cfg.guidance_rescale) == (True, True, 1.0, 0.5, 0.75)
+    assert cfg.extra["pose_controlnet_path"] == "/p/cn"
+    prompt_processor = PromptProcessor(_EXP_YAML_GUIDANCE["prompt"], lambda texts: torch.stack(
+        [torch.full((77, 768), 0.01 * len(t)) for t in texts]), negative_prompt="cloned face", null_prompt="")
+    # GaussianIP.py:355-356
+    guidance.prepare_for_sds(prompt_processor.prompt, prompt_processor.negative_prompt, prompt_processor.null_prompt)
+    assert guidance.pos_image_embeds.shape == (4, 4, 768) and guidance.num_samples == 4
+    # GaussianIP.py:362-373
+    B = 4
+    images = torch.rand(B, 64, 64, 3, generator=g, requires_grad=True)
+    control_images = torch.rand(B, 32, 32, 3, generator=g)
+    all_vis_all = torch.tensor([1.0, 1.0, 0.0, 1.0])
+    batch = dict(elevation=torch.tensor([5.0, -10.0, 20.0, 0.0]), azimuth=torch.tensor([30.0, -100.0, 150.0, 90.0]),
+                 center=torch.tensor([0.0, 0.65, 0.0, 0.65]), camera_distances=torch.full((B,), 1.5),
+                 c2w=torch.eye(4).expand(B, 4, 4), fovy=torch.full((B,), 1.2), height=64, width=64)    # extra keys are absorbed
+    prompt_utils = prompt_processor()
+    guidance_out = guidance(10, images, control_images, prompt_utils, True, all_vis_all, **batch)
+    assert set(guidance_out) == {"loss_sds", "grad_norm"}
+    guidance_out["loss_sds"].backward()
+    assert torch.isfinite(images.grad).all() and float(images.grad.abs().max()) > 0
+    # a cfg mapping that omits keys falls back to the reference Config's defaults (ipa_guidance.py:74-123)
+    bare = StableDiffusionGuidance({"half_precision_weights": False}, device="cpu", unet=_TinyUNet(), controlnet=_TinyControlNet(),
+                                   vae=_TinyVAE(), schedule=AHDSSchedule(list(range(2400))))
+    assert (bare.cfg.use_anpg, bare.cfg.grad_clip_pixel, bare.cfg.grad_clip_threshold, bare.cfg.ipa_faceid_scale) == (False, False, 0.1, 0.6)
+    with pytest.raises(RuntimeError, match="image-prompt tokens"):
+        bare.prepare_for_sds("p", "n", "")                      # nothing to make the image tokens from: loud failure
+    with pytest.raises(KeyError):
+        StableDiffusionGuidance({"no_such_key": 1}, device="cpu", unet=_TinyUNet(), controlnet=_TinyControlNet(), vae=_TinyVAE())

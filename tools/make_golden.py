@@ -208,38 +208,43 @@ def main():
     print("golden vectors written to", OUT)
 
 
-def ahds():
-    """(5) AHDS timestep table: loads threestudio/models/guidance/ipa_guidance.py by path with permissive stubs
-    (SURVEY.md Appendix B item 6) and calls the two schedule functions unbound."""
-    class Stub(types.ModuleType):
-        def __getattr__(self, name):
-            if name.startswith("__") and name.endswith("__"):
-                raise AttributeError(name)
-            child = Stub(self.__name__ + "." + name)
-            setattr(self, name, child)
-            return child
+class _Stub(types.ModuleType):
+    """Permissive stand-in for a package that is absent here: attribute access fabricates
+    child stubs, calling it is an identity decorator, subscripting returns itself, usable as a base class."""
 
-        def __call__(self, *a, **k):
-            if len(a) == 1 and callable(a[0]) and not k:
-                return a[0]
-            return self
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        child = _Stub(self.__name__ + "." + name)
+        setattr(self, name, child)
+        return child
 
-        def __getitem__(self, k):
-            return self
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return self
 
-        def __mro_entries__(self, bases):
-            return (object,)
+    def __getitem__(self, k):
+        return self
 
+    def __mro_entries__(self, bases):
+        return (object,)
+
+
+def _install_threestudio_stubs():
     import typing
     names = ["threestudio", "threestudio.utils", "threestudio.utils.base", "threestudio.utils.misc", "threestudio.utils.typing",
-             "threestudio.models", "threestudio.models.prompt_processors", "threestudio.models.prompt_processors.base",
+             "threestudio.utils.ops", "threestudio.models", "threestudio.models.prompt_processors",
+             "threestudio.models.prompt_processors.base",
              "threestudio.models.guidance", "threestudio.models.guidance.models", "threestudio.models.guidance.models.ip_adapter",
              "threestudio.models.guidance.models.ip_adapter.ip_adapter_faceid", "threestudio.models.guidance.models.pipeline_ipa",
              "threestudio.models.guidance.models.pipeline_ipa_controlnet", "diffusers", "diffusers.utils", "diffusers.utils.import_utils",
+             "diffusers.models", "diffusers.models.lora", "pytorch_lightning", "pytorch_lightning.utilities",
+             "pytorch_lightning.utilities.rank_zero",
              "cv2", "insightface", "insightface.app", "insightface.utils", "PIL", "PIL.Image", "tqdm"]
     for n in names:
         if n not in sys.modules:
-            sys.modules[n] = Stub(n)
+            sys.modules[n] = _Stub(n)
     ty = sys.modules["threestudio.utils.typing"]
     for k in dir(typing):
         if not k.startswith("_"):
@@ -247,18 +252,34 @@ def ahds():
     ty.Tensor = torch.Tensor
     jt = ["Bool", "Complex", "Float", "Inexact", "Int", "Integer", "Num", "Shaped", "UInt", "DictConfig", "typechecker"]
     for k in jt:
-        setattr(ty, k, Stub("jaxtyping_stub"))
+        setattr(ty, k, _Stub("jaxtyping_stub"))
     ty.__all__ = [k for k in dir(typing) if not k.startswith("_")] + ["Tensor"] + jt
 
     class BaseObject:
         class Config:
             pass
     sys.modules["threestudio.utils.base"].BaseObject = BaseObject
-    path = os.path.join(REF, "threestudio/models/guidance/ipa_guidance.py")
-    spec = importlib.util.spec_from_file_location("threestudio.models.guidance.ipa_guidance", path)
+
+
+def _load_by_path(module_name, rel_path, package):
+    path = os.path.join(REF, rel_path)
+    spec = importlib.util.spec_from_file_location(module_name, path)
     mod = importlib.util.module_from_spec(spec)
-    mod.__package__ = "threestudio.models.guidance"
+    mod.__package__ = package
     spec.loader.exec_module(mod)
+    return mod
+
+
+def _load_reference_guidance():
+    _install_threestudio_stubs()
+    return _load_by_path("threestudio.models.guidance.ipa_guidance", "threestudio/models/guidance/ipa_guidance.py",
+                         "threestudio.models.guidance")
+
+
+def ahds():
+    """(5) AHDS timestep table: loads threestudio/models/guidance/ipa_guidance.py by path with permissive stubs
+    (SURVEY.md Appendix B item 6) and calls the two schedule functions unbound."""
+    mod = _load_reference_guidance()
     G = mod.StableDiffusionGuidance
     self = object.__new__(G)
     # ipa_guidance.py:200-210 (1-D x0: the trailing comma at :206 makes a 2-D x0 that scipy >= 1.11 rejects)
@@ -275,8 +296,245 @@ def ahds():
     print("AHDS table written:", table[:5], table[-5:])
 
 
+def guidance():
+    """Reference-derived fixtures for the guidance math (outputs only; the inputs come from tests/fixture_inputs.py):
+      attention_processors.npz  LoRAAttnProcessor2_0 'normal' + 'refine' states and LoRAIPAttnProcessor2_0
+                                (ip_adapter/attention_processor_faceid.py:211-395, 398-523)
+      sds_grad.npz              compute_grad_anpg / compute_grad_sds (ipa_guidance.py:361-519) around a stand-in forward_unet
+      prompt_directions.npz     the 13 view-dependent prompt directions + PromptProcessorOutput.get_text_embeddings
+                                (prompt_processors/base.py:52-81, 252-335)
+      refine_timesteps.npz      the timestep expression of refine.py:176-178
+    Absent third-party pieces restated as stand-ins, by their published behaviour (diffusers 0.27, not vendored):
+    diffusers.models.lora.LoRALinearLayer (down / up bias-free linears, optional network_alpha / rank factor) and
+    DDIMScheduler.add_noise (sqrt(acp_t) x + sqrt(1 - acp_t) eps on the scaled-linear 0.00085 -> 0.012 betas)."""
+    import torch.nn as nn
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import fixture_inputs as fx
+    _install_threestudio_stubs()
+
+    class LoRALinearLayer(nn.Module):
+        def __init__(self, in_features, out_features, rank=4, network_alpha=None, device=None, dtype=None):
+            super().__init__()
+            self.down = nn.Linear(in_features, rank, bias=False)
+            self.up = nn.Linear(rank, out_features, bias=False)
+            self.network_alpha, self.rank = network_alpha, rank
+
+        def forward(self, hidden_states):
+            orig = hidden_states.dtype
+            up = self.up(self.down(hidden_states.to(self.down.weight.dtype)))
+            if self.network_alpha is not None:
+                up = up * (self.network_alpha / self.rank)
+            return up.to(orig)
+    sys.modules["diffusers.models.lora"].LoRALinearLayer = LoRALinearLayer
+    ap = _load_by_path("threestudio.models.guidance.models.ip_adapter.attention_processor_faceid",
+                       "threestudio/models/guidance/models/ip_adapter/attention_processor_faceid.py",
+                       "threestudio.models.guidance.models.ip_adapter")
+
+    T = torch.from_numpy
+
+    def fake_attn(w, dim, ctx_dim, heads):
+        """The fields of diffusers' Attention the processors read (SD1.5 transformer blocks: no norms, no residual)."""
+        lin = lambda W, b=None: (lambda x: torch.nn.functional.linear(x, T(W), None if b is None else T(b)))  # noqa: E731
+        return SimpleNamespace(spatial_norm=None, group_norm=None, norm_cross=False, residual_connection=False,
+                               rescale_output_factor=1.0, heads=heads, prepare_attention_mask=lambda m, n, b: None,
+                               to_q=lin(w["to_q"]), to_k=lin(w["to_k"]), to_v=lin(w["to_v"]),
+                               to_out=[lin(w["to_out_w"], w["to_out_b"]), lambda x: x])
+
+    def load_lora(proc, w):
+        with torch.no_grad():
+            for n in ("q", "k", "v", "out"):
+                layer = getattr(proc, "to_%s_lora" % n)
+                layer.down.weight.copy_(T(w["lora_%s_down" % n]))
+                layer.up.weight.copy_(T(w["lora_%s_up" % n]))
+
+    out = {}
+    dim, heads, rank, B = 320, 8, 128, 2
+    with torch.no_grad():
+        # --- self-attention, 'normal' state (stage 1), 64 and 256 tokens
+        w = fx.attn_weights(11, dim, None, rank)
+        proc = ap.LoRAAttnProcessor2_0(name="p", target_processor_names=[], state="normal", stored_zt={}, hidden_size=dim,
+                                       cross_attention_dim=None, rank=rank)
+        load_lora(proc, w)
+        attn = fake_attn(w, dim, None, heads)
+        for n_tok, nb in ((64, B), (256, 1)):
+            out["self_normal_%d" % n_tok] = proc(attn, T(fx.attn_tokens(21 + n_tok, nb, n_tok, dim))).numpy()
+        # --- self-attention, 'refine' state: canonical views store tokens, k-views attend mutually, v-views blend
+        n_tok, nb = fx.REFINE_TOKENS, 1
+        names = ["tgt"]
+        proc = ap.LoRAAttnProcessor2_0(name="tgt", target_processor_names=names, state="refine", stored_zt={},
+                                       total_denoise_step=fx.REFINE_STEPS, lambda_self=fx.REFINE_LAMBDA_SELF, hidden_size=dim,
+                                       cross_attention_dim=None, rank=rank)
+        load_lora(proc, w)
+        other = ap.LoRAAttnProcessor2_0(name="other", target_processor_names=names, state="refine", stored_zt={},
+                                        total_denoise_step=fx.REFINE_STEPS, hidden_size=dim, cross_attention_dim=None, rank=rank)
+        load_lora(other, w)
+        for vi, (view, pair, weights) in enumerate(fx.REFINE_VIEWS):
+            for p_ in (proc, other):
+                p_.cur_view_name = view
+                p_.stored_zt[view] = []                                   # refine.py:205-207
+                if "v" in view:
+                    p_.cur_key_view_name_pair, p_.cur_key_view_weight_pair = pair, weights
+            for step in range(fx.REFINE_STEPS):
+                x = T(fx.refine_tokens(vi, step, nb, n_tok, dim))
+                out["refine_%s_%d" % (view, step)] = proc(attn, x).numpy()
+                if view == "front":      # a non-target layer in the refine state only works for the key views in the reference
+                    out["refine_other_%s_%d" % (view, step)] = other(attn, x).numpy()
+        # --- decoupled text / image cross-attention
+        wc = fx.attn_weights(12, dim, 768, rank, ip=True)
+        procx = ap.LoRAIPAttnProcessor2_0(hidden_size=dim, cross_attention_dim=768, rank=rank, scale=0.5, num_tokens=4)
+        load_lora(procx, wc)
+        procx.to_k_ip.weight.copy_(T(wc["to_k_ip"]))
+        procx.to_v_ip.weight.copy_(T(wc["to_v_ip"]))
+        attnx = fake_attn(wc, dim, 768, heads)
+        for n_tok, nb in ((64, B), (256, 1)):
+            out["cross_ip_%d" % n_tok] = procx(attnx, T(fx.attn_tokens(31 + n_tok, nb, n_tok, dim)),
+                                               encoder_hidden_states=T(fx.attn_tokens(41, nb, 81, 768))).numpy()
+    np.savez_compressed(os.path.join(OUT, "attention_processors.npz"), dim=dim, heads=heads, rank=rank, batch=B, ip_scale=0.5, **out)
+
+    # ---------------- view-dependent prompt directions ----------------
+    rz = sys.modules["pytorch_lightning.utilities.rank_zero"]
+    rz.rank_zero_only = lambda f: f
+    real_tf = sys.modules.get("transformers")
+    sys.modules["transformers"] = _Stub("transformers")      # base.py:9 imports BertForMaskedLM (prompt debiasing, unused)
+    try:
+        base = _load_by_path("threestudio.models.prompt_processors.base", "threestudio/models/prompt_processors/base.py",
+                             "threestudio.models.prompt_processors")
+    finally:
+        if real_tf is not None:
+            sys.modules["transformers"] = real_tf
+        else:
+            del sys.modules["transformers"]
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    pp = object.__new__(base.PromptProcessor)
+    prompt = "a person wearing a coat"
+    pp.cfg = Cfg(prompt=prompt, negative_prompt="ugly", negative_prompt_faceid="blurry", null_prompt="", head_offset=0.65,
+                 view_dependent_prompt_front=False, use_prompt_debiasing=False, use_cache=False, spawn=False,
+                 use_ipa_faceid=True, pretrained_realistic_model_name_or_path="m", pretrained_sd_model_name_or_path="m")
+    cwd = os.getcwd()
+    os.chdir(REF)                              # configure() opens load/prompt_library.json relative to the working directory
+    try:
+        try:
+            pp.configure()
+        except NotImplementedError:            # spawn_func of the base class: the text encoder is out of reach; the
+            pass                               # directions / prompts are already built at that point
+    finally:
+        os.chdir(cwd)
+    case = fx.sds_case(7)
+    el, az, cent, vis, dist = [T(a) for a in fx.direction_grid()]
+    marker = torch.arange(13, dtype=torch.float32).view(13, 1, 1).expand(13, 2, 3).contiguous()      # row i holds the value i
+    ppo = base.PromptProcessorOutput(
+        text_embeddings=torch.full((1, 2, 3), 100.0), uncond_text_embeddings=torch.full((1, 2, 3), 200.0),
+        null_embeddings=torch.full((1, 2, 3), 300.0), text_embeddings_vd=marker, uncond_text_embeddings_vd=marker + 1000.0,
+        directions=pp.directions, direction2idx=pp.direction2idx, use_perp_neg=False, perp_neg_f_sb=(1, 0.5, -0.606),
+        perp_neg_f_fsb=(1, 0.5, 0.967), perp_neg_f_fs=(4, 0.5, -2.426), perp_neg_f_sf=(4, 0.5, -2.426))
+    emb = ppo.get_text_embeddings(el, az, cent, vis, dist, True)
+    n = el.shape[0]
+    emb_flat = ppo.get_text_embeddings(el, az, cent, vis, dist, False)
+    np.savez(os.path.join(OUT, "prompt_directions.npz"), names=np.array([d.name for d in pp.directions]),
+             direction2idx_keys=np.array(list(pp.direction2idx.keys())), direction2idx_values=np.array(list(pp.direction2idx.values())),
+             prompt=prompt, prompts_vd=np.array(pp.prompts_vd), negative_prompts_vd=np.array(pp.negative_prompts_vd),
+             direction_idx=emb[:n, 0, 0].numpy().astype(np.int64), uncond_idx=(emb[n:2 * n, 0, 0] - 1000.0).numpy().astype(np.int64),
+             null_value=emb[2 * n:, 0, 0].numpy(), not_view_dependent=emb_flat[:, 0, 0].numpy())
+
+    # ---------------- compute_grad_anpg / compute_grad_sds ----------------
+    mod = _load_reference_guidance()
+    G = mod.StableDiffusionGuidance
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1.0 - betas, dim=0)
+
+    class Scheduler:                                  # stand-in for diffusers.DDIMScheduler (configured at ipa_guidance.py:139-147)
+        def add_noise(self, x, noise, t):
+            a = acp.to(x.dtype)[t]
+            return a.sqrt().view(-1, 1, 1, 1) * x + (1 - a).sqrt().view(-1, 1, 1, 1) * noise
+    ppo_real = base.PromptProcessorOutput(
+        text_embeddings=T(case["text"]), uncond_text_embeddings=T(case["uncond"]), null_embeddings=T(case["null"]),
+        text_embeddings_vd=T(case["text_vd"]), uncond_text_embeddings_vd=T(case["uncond_vd"]), directions=pp.directions,
+        direction2idx=pp.direction2idx, use_perp_neg=False, perp_neg_f_sb=(1, 0.5, -0.606), perp_neg_f_fsb=(1, 0.5, 0.967),
+        perp_neg_f_fs=(4, 0.5, -2.426), perp_neg_f_sf=(4, 0.5, -2.426))
+    res = {}
+    for tag, vd, clip, weighting, rescale in (("anpg", True, True, "sds", 0.0), ("anpg_flat_noclip", False, False, "fantasia3d", 0.0),
+                                              ("sds", True, True, "sds", 0.0), ("sds_rescale", True, False, "uniform", 0.75)):
+        me = object.__new__(G)
+        me.cfg = SimpleNamespace(view_dependent_prompting=vd, guidance_scale=7.5, weighting_strategy=weighting,
+                                 grad_clip_pixel=clip, grad_clip_threshold=1.0, guidance_rescale=rescale)
+        me.alphas, me.scheduler = acp, Scheduler()
+        me.pos_image_embeds, me.neg_image_embeds, me.null_image_embeds = T(case["pos_image"]), T(case["neg_image"]), T(case["null_image"])
+        neg = torch.cat([T(case["uncond"]).expand(4, -1, -1), me.neg_image_embeds], dim=1)
+        pos = torch.cat([T(case["text"]).expand(4, -1, -1), me.pos_image_embeds], dim=1)
+        null = torch.cat([T(case["null"]).expand(4, -1, -1), me.null_image_embeds], dim=1)
+        me.final_prompt_embeds_npn = torch.cat([neg, pos, null])       # as prepare_for_sds builds them (:296-308)
+        me.final_prompt_embeds_np = torch.cat([neg, pos])
+        me.forward_unet = fx.fake_forward_unet
+        fn = G.compute_grad_anpg if tag.startswith("anpg") else G.compute_grad_sds
+        torch.manual_seed(2024)
+        grad, util = fn(me, T(case["latents"]), T(case["control"]), T(case["t"]), ppo_real, True, T(case["all_vis_all"]),
+                        T(case["elevation"]), T(case["azimuth"]), T(case["center"]), T(case["camera_distances"]))
+        res[tag + "_grad"] = grad.numpy()
+        res[tag + "_latents_noisy"] = util["latents_noisy"].numpy()
+    np.savez_compressed(os.path.join(OUT, "sds_grad.npz"), seed=2024, case_seed=7, **res)
+
+    # ---------------- refine timesteps (refine.py:176-178) ----------------
+    ts = torch.linspace(0, 999, 50, dtype=torch.int64).round().flip(dims=[0])
+    np.savez(os.path.join(OUT, "refine_timesteps.npz"), timesteps=ts.numpy(), timesteps_sub=ts[-8:].numpy())
+    print("guidance fixtures written; refine timesteps:", ts[-8:].tolist())
+    print("direction2idx:", pp.direction2idx)
+
+
+def backward():
+    """Reference-AUTOGRAD fixtures for the two per-Gaussian backward stages of the rasterizer that the reference also
+    states in Python: SH colour (gaussian_renderer/__init__.py:71-78 + sh_utils.eval_sh) and the 3-D covariance
+    (gaussian_model.py:16-20 + general_utils.build_scaling_rotation / strip_symmetric).  Widen the oracle's pinned
+    perimeter into its backward (oracle_sh_backward / oracle_cov3D_backward)."""
+    _install_device_shim()
+    _install_stub_modules()
+    from gaussiansplatting.utils import sh_utils, general_utils
+    rng = np.random.default_rng(77)
+    Pn = 128
+    xyz = rng.uniform(-0.5, 0.5, (Pn, 3)).astype(np.float32)
+    campos = np.array([0.3, -1.4, 0.5], np.float32)
+    feats = (rng.standard_normal((Pn, 16, 3)) * 0.4).astype(np.float32)       # model layout [P, K, 3] (gaussian_model.py:97-100)
+    feats[:, 0] *= 4.0                                                        # some colours below zero: the clamp has both branches
+    gcol = rng.standard_normal((Pn, 3)).astype(np.float32)
+    out = dict(xyz=xyz, campos=campos, features=feats, gcol=gcol)
+    for deg in range(4):
+        K = (deg + 1) ** 2
+        f = torch.from_numpy(feats[:, :K].copy()).requires_grad_(True)
+        x = torch.from_numpy(xyz).requires_grad_(True)
+        shs_view = f.transpose(1, 2).view(-1, 3, K)
+        dir_pp = x - torch.from_numpy(campos).repeat(Pn, 1)
+        dir_n = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        rgb = torch.clamp_min(sh_utils.eval_sh(deg, shs_view, dir_n) + 0.5, 0.0)
+        (rgb * torch.from_numpy(gcol)).sum().backward()
+        out["rgb%d" % deg] = rgb.detach().numpy()
+        out["dfeatures%d" % deg] = f.grad.numpy()
+        out["dxyz%d" % deg] = np.zeros_like(xyz) if x.grad is None else x.grad.numpy()    # degree 0 ignores the direction
+    s_ = (rng.uniform(0.002, 0.08, (Pn, 3))).astype(np.float32)
+    q_ = rng.standard_normal((Pn, 4))
+    q_ = (q_ / np.linalg.norm(q_, axis=1, keepdims=True)).astype(np.float32)
+    dcov = rng.standard_normal((Pn, 6)).astype(np.float32)
+    out.update(scales=s_, rotations=q_, dcov=dcov)
+    for tag, mod in (("m1", 1.0), ("m17", 1.7)):
+        s = torch.from_numpy(s_).requires_grad_(True)
+        q = torch.from_numpy(q_).requires_grad_(True)
+        L = general_utils.build_scaling_rotation(mod * s, q)
+        cov6 = general_utils.strip_symmetric(L @ L.transpose(1, 2))
+        (cov6 * torch.from_numpy(dcov)).sum().backward()
+        out["cov6_" + tag] = cov6.detach().numpy()
+        out["dscales_" + tag] = s.grad.numpy()
+        out["drotations_" + tag] = q.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "preprocess_backward.npz"), **out)
+    print("backward fixtures written")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ahds":
         ahds()
+    elif len(sys.argv) > 1 and sys.argv[1] == "guidance":
+        guidance()
+    elif len(sys.argv) > 1 and sys.argv[1] == "backward":
+        backward()
     else:
         main()
