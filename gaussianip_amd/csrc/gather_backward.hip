@@ -26,7 +26,25 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
                            const uint32_t* __restrict__ inst_offset, const float* __restrict__ partial,
                            GipRasterGradsOut gout, const GipRasterHeader* __restrict__ header) {
   const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
-  if (idx >= kp.P || header->overflow) return;      // overflowed forward: gradients are discarded by the host
+  if (idx >= kp.P) return;
+  if (header->overflow) {
+    // overflowed forward (tile lists truncated at the capacity): the step degenerates to a ZERO-gradient step, the same
+    // on every rank of a multi-GPU job; the host learns it from the header one step late, raises the capacity and
+    // reports it (rasterizer.py).  Every output is still written exactly once.
+    if (gout.dL_dmeans3D) { gout.dL_dmeans3D[3 * idx] = 0.f; gout.dL_dmeans3D[3 * idx + 1] = 0.f; gout.dL_dmeans3D[3 * idx + 2] = 0.f; }
+    if (gout.dL_dmeans2D)
+      for (int v = 0; v < kp.V; v++) {
+        float* d2 = gout.dL_dmeans2D + ((size_t)v * kp.P + idx) * 3;
+        d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f;
+      }
+    if (gout.dL_dopacities) gout.dL_dopacities[idx] = 0.f;
+    if (gout.dL_dcolors_precomp) { gout.dL_dcolors_precomp[3 * idx] = 0.f; gout.dL_dcolors_precomp[3 * idx + 1] = 0.f; gout.dL_dcolors_precomp[3 * idx + 2] = 0.f; }
+    if (gout.dL_dshs) for (int k = 0; k < kp.M * 3; k++) gout.dL_dshs[(size_t)idx * kp.M * 3 + k] = 0.f;
+    if (gout.dL_dcov3D_precomp) for (int k = 0; k < 6; k++) gout.dL_dcov3D_precomp[6 * idx + k] = 0.f;
+    if (gout.dL_dscales) { gout.dL_dscales[3 * idx] = 0.f; gout.dL_dscales[3 * idx + 1] = 0.f; gout.dL_dscales[3 * idx + 2] = 0.f; }
+    if (gout.dL_drotations) reinterpret_cast<float4*>(gout.dL_drotations)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const float m0 = means3D[3 * idx], m1 = means3D[3 * idx + 1], m2 = means3D[3 * idx + 2];
 
   // 3-D covariance (recomputed rather than stored: 6 floats of state per view saved)

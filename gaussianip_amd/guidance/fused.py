@@ -168,7 +168,40 @@ class LayerNorm(nn.LayerNorm):
 # ---------------------------------------------------------------------------------------------------------------------
 _MIN_CONV_TILES = 32         # tile counts below 256 run split-K (fp32 slabs in the shared workspace); tiny problems stay on MIOpen
 _SPLITK_WS_BYTES = 64 << 20
-_wt_cache = {}
+_WT_CACHE_MAX = 256
+
+
+class _WeightCache:
+    """Derived (flipped / transposed) copies of frozen convolution weights, keyed by (tag, data_ptr, version, shape).
+    Every entry keeps a STRONG reference to the source tensor: while the entry lives the source's storage cannot be freed,
+    so the allocator cannot hand the same address (at version 0, same shape) to a different weight and make the entry
+    stale.  Least-recently-used entries beyond _WT_CACHE_MAX are dropped (a rebuilt network does not pin the old one's
+    weights forever)."""
+
+    def __init__(self):
+        from collections import OrderedDict
+        self._d = OrderedDict()
+
+    def get(self, tag, w, make):
+        key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+        hit = self._d.get(key)
+        if hit is not None:
+            self._d.move_to_end(key)
+            return hit[1]
+        wt = make(w)
+        self._d[key] = (w, wt)
+        while len(self._d) > _WT_CACHE_MAX:
+            self._d.popitem(last=False)
+        return wt
+
+    def __len__(self):
+        return len(self._d)
+
+    def clear(self):
+        self._d.clear()
+
+
+_wt_cache = _WeightCache()
 
 
 def _conv_tiles(N, H, W, cout):
@@ -192,11 +225,7 @@ def _conv_call(x, w, cout, bias=None, residual=None):
 
 def _transposed_weight(w):
     """Weight of the data-gradient convolution: w_t[ci][2-dy][2-dx][co] = w[co][dy][dx][ci] (frozen weights: cached)."""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    wt = _wt_cache.get(key)
-    if wt is None:
-        wt = _wt_cache[key] = w.detach().flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-    return wt
+    return _wt_cache.get("t", w, lambda t: t.detach().flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -376,12 +405,11 @@ class _ConvFewInputChannels(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
-        key = ("few", w.data_ptr(), w._version, tuple(w.shape))
-        wt = _wt_cache.get(key)
-        if wt is None:
-            wt4 = torch.zeros((4, w.shape[0], 3, 3), dtype=w.dtype, device=w.device)
-            wt4[:w.shape[1]] = w.detach().flip(2, 3).transpose(0, 1)
-            wt = _wt_cache[key] = wt4.contiguous(memory_format=torch.channels_last)
+        def make(t):
+            wt4 = torch.zeros((4, t.shape[0], 3, 3), dtype=t.dtype, device=t.device)
+            wt4[:t.shape[1]] = t.detach().flip(2, 3).transpose(0, 1)
+            return wt4.contiguous(memory_format=torch.channels_last)
+        wt = _wt_cache.get("few", w, make)
         dy = dy.contiguous(memory_format=torch.channels_last)
         return _conv_call(dy, wt, 4)[:, :w.shape[1]], None, None
 

@@ -14,9 +14,14 @@ loops over its 4 cameras, threestudio/systems/GaussianIP.py:154-173); V = 1 is e
 
 No host synchronisation on the training path: the reference's blocking read of `num_rendered` is replaced by a
 capacity hint + a device-side overflow flag that is checked when backward starts.
+An overflowed training forward never aborts the run and never desynchronises a multi-GPU job: the backward kernels
+write ZERO gradients (the step degenerates to a zero-gradient step on every rank alike), the host reads the header one
+step late, raises the hint, counts the event in `overflow_events` and warns.  `GIP_RASTER_ON_OVERFLOW=raise` restores
+the exception.  No-grad calls (output renders) are checked immediately and re-run at the exact requirement.
 """
 import ctypes
 import os
+import warnings
 from typing import NamedTuple, Optional, Sequence
 
 import torch
@@ -45,7 +50,12 @@ class GaussianRasterizationSettings(NamedTuple):
 _MIN_CAPACITY = 1 << 20
 _CAPACITY_MARGIN = 65536
 _capacity_hint = {}     # (device index, P, V, H, W) -> last observed num_rendered
-_pending_checks = []    # (event, pinned header, key, capacity) of no-grad-free calls not yet verified
+_pending_checks = []    # [event, pinned header, key, capacity] of deferred-check forwards whose header is not read yet
+overflow_events = 0     # forwards that overflowed their capacity hint (their steps ran with zero gradients)
+
+
+def _on_overflow():
+    return os.environ.get("GIP_RASTER_ON_OVERFLOW", "zero")
 
 
 def _strict():
@@ -149,7 +159,41 @@ def _read_header_async(plan):
     return ev, host
 
 
+def _settle(entry):
+    """Reads a completed header copy: teaches the capacity policy the real size; reports an overflow.  Returns the
+    overflow flag."""
+    global overflow_events
+    ev, host, key, cap = entry
+    num_rendered, overflow = int(host[1]), int(host[2])
+    _capacity_hint[key] = max(num_rendered, 1)
+    if overflow:
+        overflow_events += 1
+        msg = ("gaussianip_amd rasterizer: %d tile instances exceeded the capacity hint %d; that forward's images are "
+               "truncated and its backward produced zero gradients (zero-gradient step). The hint has been raised." %
+               (num_rendered, cap))
+        if _on_overflow() == "raise":
+            raise RuntimeError(msg + " (GIP_RASTER_ON_OVERFLOW=raise)")
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    return num_rendered, bool(overflow)
+
+
+def _drain_pending(block=False):
+    """Settles the deferred checks of earlier forwards whose header copy has landed — including grad-enabled renders
+    that were never back-propagated (their check would otherwise never run)."""
+    i = 0
+    while i < len(_pending_checks):
+        entry = _pending_checks[i]
+        if block or entry[0].query():
+            if block:
+                entry[0].synchronize()
+            _pending_checks.pop(i)
+            _settle(entry)
+        else:
+            i += 1
+
+
 def _forward_with_policy(plan, need_backward):
+    _drain_pending()
     key = _hint_key(plan.means3D.device, plan.P, plan.V, plan.H, plan.W)
     cap = _pick_capacity(key, plan.P, plan.V)
     sync_now = _strict() or cap is None or not need_backward
@@ -159,7 +203,8 @@ def _forward_with_policy(plan, need_backward):
         outs = _run_forward(plan, cap)
         ev, host = _read_header_async(plan)
         if not sync_now:
-            plan.pending = (ev, host, key, cap)
+            plan.pending = [ev, host, key, cap]
+            _pending_checks.append(plan.pending)
             return outs
         ev.synchronize()
         num_rendered, overflow = int(host[1]), int(host[2])
@@ -173,19 +218,18 @@ def _forward_with_policy(plan, need_backward):
 
 def _verify_pending(plan):
     """Deferred overflow check, run once the backward kernels are enqueued (see _RasterizeGaussians.backward)."""
-    if getattr(plan, "pending", None) is None:
+    entry = getattr(plan, "pending", None)
+    if entry is None:
         return
-    ev, host, key, cap = plan.pending
-    ev.synchronize()
     plan.pending = None
-    num_rendered, overflow = int(host[1]), int(host[2])
-    _capacity_hint[key] = max(num_rendered, 1)
-    plan.num_rendered = num_rendered
-    if overflow:
-        raise RuntimeError(
-            "gaussianip_amd rasterizer: %d tile instances exceeded the capacity hint %d; the forward outputs of this "
-            "call are invalid. The hint has been raised — re-run the step, or set GIP_RASTER_SYNC=1 to size "
-            "buffers synchronously like the reference does." % (num_rendered, cap))
+    for i, e in enumerate(_pending_checks):
+        if e is entry:
+            _pending_checks.pop(i)
+            break
+    else:
+        return                      # already settled by _drain_pending
+    entry[0].synchronize()
+    plan.num_rendered, plan.overflowed = _settle(entry)
 
 
 def _run_backward(plan, outs, g_color, g_depth, g_alpha):
@@ -246,14 +290,14 @@ def _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3
     plan.tanfovx = [float(s.tanfovx) for s in settings_list]
     plan.tanfovy = [float(s.tanfovy) for s in settings_list]
     if V == 1:
-        plan.viewmatrix = _f32c(s0.viewmatrix, "viewmatrix").reshape(1, 16)
-        plan.projmatrix = _f32c(s0.projmatrix, "projmatrix").reshape(1, 16)
-        plan.campos = _f32c(s0.campos, "campos").reshape(1, 3)
+        # same treatment as the multi-view branch: host-side camera tensors (Camera's documented no-sync path) are moved
+        mv = lambda t: t.float().reshape(1, -1).to(dev, non_blocking=True).contiguous()  # noqa: E731
+        plan.viewmatrix, plan.projmatrix, plan.campos = mv(s0.viewmatrix), mv(s0.projmatrix), mv(s0.campos)
     else:
         plan.viewmatrix = torch.stack([s.viewmatrix.float().reshape(16) for s in settings_list]).to(dev).contiguous()
         plan.projmatrix = torch.stack([s.projmatrix.float().reshape(16) for s in settings_list]).to(dev).contiguous()
         plan.campos = torch.stack([s.campos.float().reshape(3) for s in settings_list]).to(dev).contiguous()
-    plan.bg = _f32c(s0.bg, "bg")
+    plan.bg = s0.bg.float().to(dev, non_blocking=True).contiguous()
     return plan
 
 
@@ -286,8 +330,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         g = _run_backward(plan, (color, depth, alpha), prep(g_color), prep(g_depth), prep(g_alpha))
         # The deferred overflow check runs AFTER the backward kernels are enqueued: waiting for the forward's header copy
         # then overlaps with GPU work instead of idling the device when backward follows forward immediately.  The
-        # kernels are capacity-clamped, so running them on an overflowed forward is safe; its gradients are discarded
-        # by the exception below and never reach the caller.
+        # kernels are capacity-clamped, so running them on an overflowed forward is safe: they write zero gradients.
         _verify_pending(plan)
         g2d = None if ctx.means2D_shape is None else g["means2D"].reshape(ctx.means2D_shape)
         return (g["means3D"], g2d, g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"],
@@ -333,8 +376,8 @@ class GaussianRasterizer(torch.nn.Module):
             rs = self.raster_settings
             pos = _f32c(positions, "positions")
             out = torch.empty(pos.shape[0], dtype=torch.uint8, device=pos.device)
-            vm = _f32c(rs.viewmatrix, "viewmatrix")
-            pm = _f32c(rs.projmatrix, "projmatrix")
+            vm = rs.viewmatrix.float().to(pos.device, non_blocking=True).contiguous()
+            pm = rs.projmatrix.float().to(pos.device, non_blocking=True).contiguous()
             rc = _lib.raster_lib().gip_raster_mark_visible(
                 int(pos.shape[0]), _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out),
                 ctypes.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream))

@@ -194,8 +194,9 @@ int gip_raster_forward(const GipRasterConfig* cfg, const GipRasterInputs* in, co
  * partial rows, then a deterministic per-Gaussian gather fused with the cov2D / projection / SH /
  * cov3D backward.  No float atomics: results are bitwise reproducible.
  * If the forward overflowed its capacity (GipRasterHeader.overflow != 0) the backward kernels read the flag on the
- * device and exit without touching memory: the gradient buffers are then UNDEFINED and the caller must discard them
- * after reading the header (this lets a caller enqueue backward before it has looked at the header). */
+ * device: every gradient output is written as ZERO (a caller may enqueue backward, the optimizer and a multi-GPU
+ * gradient exchange before it has looked at the header: the step degenerates to a zero-gradient step, identically on
+ * every rank, and the caller raises the capacity for the next call after reading the header). */
 int gip_raster_backward(const GipRasterConfig* cfg, const GipRasterInputs* in, const GipRasterGradsIn* gin,
                         const void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
                         const GipRasterGradsOut* gout, void* stream);

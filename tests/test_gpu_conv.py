@@ -114,3 +114,28 @@ def test_stride2_convolution(N, C, Co, H, W, pad, monkeypatch):
         (dxr,) = torch.autograd.grad(F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.float(), b.float(), stride=2), xr, dy.float())
         assert float((y.float() - ref).abs().max()) <= 1.5e-3 * float(ref.abs().max())
         assert float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())
+
+
+def test_transposed_weight_cache_is_never_stale(monkeypatch):
+    """The data-gradient convolution caches the flipped / transposed copy of a frozen weight.  A weight that is freed and
+    whose address the allocator hands to a NEW weight of the same shape (a rebuilt network, a checkpoint loaded later)
+    must not be served the old copy: the cache pins its source tensor, so the address cannot be reused while the entry
+    lives."""
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setattr(fused, "_MIN_CONV_TILES", 0)
+    fused._wt_cache.clear()
+    cl = dict(memory_format=torch.channels_last)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(2, 64, 16, 16, device="cuda", generator=g).half().contiguous(**cl)
+    dy = torch.randn(2, 64, 16, 16, device="cuda", generator=g).half().contiguous(**cl)
+    ptrs = set()
+    for trial in range(6):
+        w = (torch.randn(64, 64, 3, 3, device="cuda", generator=g) / 24.0).half().contiguous(**cl)
+        ptrs.add(w.data_ptr())
+        xi = x.clone().requires_grad_(True)
+        fused.conv3x3(xi, w).backward(dy)
+        ref = torch.nn.grad.conv2d_input(xi.shape, w.float(), dy.float(), padding=1)
+        assert float((xi.grad.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), trial
+        del w
+    assert len(ptrs) == 6 and len(fused._wt_cache) == 6          # every weight kept its own address while cached
+    fused._wt_cache.clear()

@@ -75,7 +75,7 @@ def test_full_size_properties_100k_and_1m():
         assert bool((inc | seg[1:]).all()), "a tile list is not strictly increasing in (depth, index)"
 
 
-def test_capacity_overflow_protocol():
+def test_capacity_overflow_protocol(monkeypatch):
     from gaussianip_amd import GaussianRasterizer
     from gaussianip_amd import rasterizer as R
     H = W = 256
@@ -92,12 +92,25 @@ def test_capacity_overflow_protocol():
     old_min, old_margin = R._MIN_CAPACITY, R._CAPACITY_MARGIN
     try:
         R._MIN_CAPACITY, R._CAPACITY_MARGIN = 1024, 0
-        # (a) grad mode with a hint that is far too small: deferred check raises when backward starts
+        # (a) grad mode with a hint that is far too small: the step is a zero-gradient step, reported, and teaches the policy
         R._capacity_hint[key] = 100
+        events = R.overflow_events
+        color = rast(**kw)[0]
+        with pytest.warns(RuntimeWarning, match="exceeded the capacity hint"):
+            color.sum().backward()
+        assert R.overflow_events == events + 1 and R._capacity_hint[key] == true_r
+        for k, v in t.items():
+            assert v.grad is not None and float(v.grad.abs().max()) == 0.0, k      # exactly zero, not garbage
+            v.grad = None
+        # (a') GIP_RASTER_ON_OVERFLOW=raise restores the exception
+        R._capacity_hint[key] = 100
+        monkeypatch.setenv("GIP_RASTER_ON_OVERFLOW", "raise")
         color = rast(**kw)[0]
         with pytest.raises(RuntimeError, match="exceeded the capacity hint"):
             color.sum().backward()
-        assert R._capacity_hint[key] == true_r                      # the failed call taught the policy the real size
+        monkeypatch.delenv("GIP_RASTER_ON_OVERFLOW")
+        for v in t.values():
+            v.grad = None
         # (b) no-grad call with a bad hint: checked immediately and re-run transparently
         R._capacity_hint[key] = 100
         with torch.no_grad():
@@ -106,7 +119,22 @@ def test_capacity_overflow_protocol():
         # (c) after recovery the training path works again and matches
         c3 = rast(**kw)[0]
         c3.sum().backward()
-        assert torch.equal(c3.detach(), color_ref)
+        assert torch.equal(c3.detach(), color_ref) and float(t["means3D"].grad.abs().max()) > 0
+        # (d) a grad-enabled render that is never back-propagated is settled by the next call
+        R._capacity_hint[key] = 100
+        events = R.overflow_events
+        dropped = rast(**kw)[0]
+        torch.cuda.synchronize()
+        del dropped
+        with pytest.warns(RuntimeWarning, match="exceeded the capacity hint"):
+            c4 = rast(**kw)[0]                      # drains the pending header first; its own hint is already repaired
+        assert R.overflow_events == events + 1 and torch.equal(c4.detach(), color_ref)
+        c4.sum().backward()
+        # (e) host-side camera tensors work for a single view as they do for several (Camera's no-sync path)
+        st_cpu = st._replace(viewmatrix=st.viewmatrix.cpu(), projmatrix=st.projmatrix.cpu(), campos=st.campos.cpu())
+        with torch.no_grad():
+            c5 = GaussianRasterizer(st_cpu)(**kw)[0]
+        assert torch.equal(c5, color_ref)
     finally:
         R._MIN_CAPACITY, R._CAPACITY_MARGIN = old_min, old_margin
 
