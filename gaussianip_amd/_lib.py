@@ -61,6 +61,28 @@ def _missing(name):
         "There is no CPU fallback for the product path." % (name, LIB_DIR))
 
 
+call_counts = {}       # C-ABI entry point -> number of calls through this module (tests assert that the HIP path ran)
+
+
+class _Counted:
+    """The loaded library with a per-symbol call counter in front of every entry point."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        w = self._wrapped.get(name)
+        if w is None:
+            fn = getattr(self._lib, name)
+
+            def w(*args, _fn=fn, _name=name):
+                call_counts[_name] = call_counts.get(_name, 0) + 1
+                return _fn(*args)
+            self._wrapped[name] = w
+        return w
+
+
 def raster_lib():
     global _raster
     if _raster is None:
@@ -92,7 +114,7 @@ def raster_lib():
         lib.gip_raster_read_header.argtypes = [_vp, _vp, _vp]
         lib.gip_raster_mark_visible.restype = ctypes.c_int
         lib.gip_raster_mark_visible.argtypes = [ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]
-        _raster = lib
+        _raster = _Counted(lib)
     return _raster
 
 
@@ -107,7 +129,7 @@ def knn_lib():
         lib.gip_knn_workspace_bytes.argtypes = [ctypes.c_int32]
         lib.gip_knn_mean_dist2.restype = ctypes.c_int
         lib.gip_knn_mean_dist2.argtypes = [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_size_t, _vp]
-        _knn = lib
+        _knn = _Counted(lib)
     return _knn
 
 
@@ -138,7 +160,7 @@ def model_lib():
         lib.gip_unpack_bucket.restype = ctypes.c_int
         lib.gip_unpack_bucket.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, _vp,
                                           ctypes.c_int64, _vp, ctypes.c_float, _vp]
-        _model = lib
+        _model = _Counted(lib)
     return _model
 
 
@@ -182,7 +204,7 @@ def nn_lib():
         lib.gip_linear_f16.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]
         lib.gip_conv3x3_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp, ctypes.c_size_t, _vp]
-        _nn = lib
+        _nn = _Counted(lib)
     return _nn
 
 

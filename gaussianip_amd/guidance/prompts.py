@@ -46,7 +46,7 @@ def direction_index(elevation, azimuth, center, all_vis_all, camera_distances=No
             cond = (center == head_offset) & (azimuth > 0)
         else:
             cond = (all_vis_all == d.all_vis) & (azimuth > d.lo) & (azimuth < d.hi)
-        idx[cond] = DIRECTION2IDX[d.name]
+        idx = torch.where(cond, DIRECTION2IDX[d.name], idx)       # (a masked assignment would synchronise on the GPU)
     return idx
 
 

@@ -91,7 +91,7 @@ class Skeleton:
         """mvp [V,4,4] (or [4,4]) -> (canvas [V,H,W,3] float32 in [0,1], all_vis [V] (1 if every key point is drawn),
         xy [V,18,2]).  Same outputs as poser.py:832-904 per view, batched."""
         single = mvp.dim() == 2
-        mvp = mvp.reshape(-1, 4, 4).to(self.device, torch.float32)
+        mvp = mvp.reshape(-1, 4, 4).to(self.device, torch.float32, non_blocking=True)
         V = mvp.shape[0]
         ndc, xs, ys = self.project(mvp, H, W)
         mask = self.visibility(ndc, xs, ys, H, W, azimuth, head_zoom, enable_occlusion)

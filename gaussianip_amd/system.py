@@ -71,10 +71,15 @@ def binary_cross_entropy(inp, target):
 
 class StageOneStep:
     def __init__(self, gaussian, pipe, background: torch.Tensor, cfg: Optional[StageOneConfig] = None,
-                 hand_centers: Optional[torch.Tensor] = None):
+                 hand_centers: Optional[torch.Tensor] = None, skeleton=None, pose_height: int = 512, pose_width: int = 512,
+                 head_offset: float = 0.65):
+        """`skeleton`: a gaussianip_amd.poser.Skeleton; when given and the batch carries `mvp_mtx`, forward() also
+        draws the ControlNet pose maps of all views (one HIP launch) and returns `pose` / `all_vis_all` like
+        GaussianIP.forward (:175-196, 218-222); `pose_height/width` = cfg.height / cfg.width (512, configs/exp.yaml)."""
         self.gaussian, self.pipe, self.background = gaussian, pipe, background
         self.cfg = cfg or StageOneConfig()
         self.hand_centers = hand_centers
+        self.skeleton, self.pose_hw, self.head_offset = skeleton, (pose_height, pose_width), head_offset
         self.viewspace_points = None
         self.radii = None
         self.visibility_filter = None
@@ -94,8 +99,51 @@ class StageOneStep:
             self.visibility_filter = self.visibility_filter & ~(dist.min(dim=-1).values < self.cfg.hand_radius)
         images = pkg["render"].permute(0, 2, 3, 1)                   # [B,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)               # [B,H,W,1]
-        return {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (depths.max() + 1e-5),
-                "scale": self.gaussian.get_scaling}
+        out = {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (depths.max() + 1e-5),
+               "scale": self.gaussian.get_scaling}
+        if self.skeleton is not None and "mvp_mtx" in batch:
+            dev = images.device
+            az = torch.as_tensor(batch["azimuth"]).to(dev, non_blocking=True)
+            cent = torch.as_tensor(batch["center"]).to(dev, non_blocking=True)
+            head_zoom = (cent == self.head_offset) & (az > 0)        # :176
+            pose, all_vis, _ = self.skeleton.openpose_draw(batch["mvp_mtx"], self.pose_hw[0], self.pose_hw[1], az, head_zoom, True)
+            out["pose"], out["all_vis_all"] = pose, all_vis
+        return out
+
+    # GaussianIP.training_step (stage 1 branch, :362-395)
+    def training_step(self, step: int, batch: Dict, guidance, prompt_utils, use_pose_controlnet: bool = True):
+        """update_learning_rate -> forward (render + pose maps) -> guidance(...) -> loss.  `prompt_utils` = prompt_processor()."""
+        self.gaussian.update_learning_rate(step)
+        out = self.forward(batch)
+        guidance_out = guidance(step, out["comp_rgb"], out["pose"], prompt_utils, use_pose_controlnet, out["all_vis_all"],
+                                **{k: v for k, v in batch.items() if k not in ("height", "width")})
+        return self.loss(out, guidance_out), out, guidance_out
+
+    def optimizer_step(self, loss, step: int, scaler=None, exchange=None) -> Optional[str]:
+        """backward -> (unscale) -> on_before_optimizer_step -> optimizer.step, in Lightning's order.
+
+        `scaler`: a torch.amp.GradScaler reproduces the reference's `precision: 16-mixed` (configs/exp.yaml:193): the loss
+        is multiplied by the scaler's scale before backward and the PARAMETER gradients are unscaled before the hook —
+        but `viewspace_points.grad` is a retained non-leaf gradient that the scaler never sees, so the densification
+        statistics (and the `max_grad` = 0.0002 threshold, GaussianIP.py:452-462) see gradients that are still
+        multiplied by the scale (65536 at the start).  Reference behaviour, reproduced rather than fixed (SURVEY §7);
+        with scaler=None the statistics are unscaled.  `exchange(self)`: multi-GPU gradient / statistics exchange."""
+        opt = self.gaussian.optimizer
+        opt.zero_grad(set_to_none=True)
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+        else:
+            loss.backward()
+        if exchange is not None:
+            exchange(self)
+        action = self.on_before_optimizer_step(step)
+        if scaler is not None:
+            scaler.step(opt)
+            scaler.update()
+        else:
+            opt.step()
+        return action
 
     # GaussianIP.training_step (loss assembly)
     def loss(self, out: Dict, guidance_out: Dict) -> torch.Tensor:
@@ -146,29 +194,41 @@ class StageThreeStep:
 
     CROP = (slice(60, 890), slice(220, 800))
 
-    def __init__(self, gaussian, pipe, background, cameras, refined_rgbs, view_idx_all, lambda_l1=1.0, lambda_lpips=0.0,
-                 perceptual=None, train_bs=4):
-        import torch.nn.functional as F
+    def __init__(self, gaussian, pipe, background, cameras, refined_rgbs=None, view_idx_all=None, lambda_l1=1.0,
+                 lambda_lpips=0.0, perceptual=None, train_bs=4, cfg: Optional[StageOneConfig] = None,
+                 refined_rgbs_small=None):
+        """Either `refined_rgbs` [n, H, W, 3] in refinement order with `view_idx_all` (the refiner's return values), or
+        `refined_rgbs_small` [n, 3, h, w] in orbit order as stored in after_refine.pth (`load_after_refine`)."""
         self.gaussian, self.pipe, self.background, self.cameras = gaussian, pipe, background, cameras
         self.lambda_l1, self.lambda_lpips, self.perceptual, self.train_bs = lambda_l1, lambda_lpips, perceptual, train_bs
-        # refined_rgbs come in refinement order; put them back into orbit order (GaussianIP.py:418 idx_mapper)
-        order = torch.argsort(torch.as_tensor(view_idx_all))
-        gt = refined_rgbs[order.to(refined_rgbs.device)].permute(0, 3, 1, 2)
-        gt = gt[:, :, self.CROP[0], self.CROP[1]] if gt.shape[2] >= 890 and gt.shape[3] >= 800 else gt
-        self.gt_small = F.interpolate(gt, scale_factor=0.5, mode="bilinear", align_corners=False)
-        self.orbit_ids = torch.as_tensor(view_idx_all)[order].tolist()
+        self.cfg = cfg or StageOneConfig()
+        self.viewspace_points = self.refine_radii = self.refine_visibility_filter = None
+        if refined_rgbs_small is not None:
+            self.gt_small = refined_rgbs_small.to(gaussian.get_xyz.device)
+            self.orbit_ids = list(range(self.gt_small.shape[0]))
+        else:
+            self.gt_small, order = prepare_refined_targets(refined_rgbs, view_idx_all, self.CROP)
+            self.orbit_ids = torch.as_tensor(view_idx_all)[order].tolist()
         self.gt_feats = None
         if perceptual is not None and lambda_lpips and hasattr(perceptual, "target_features"):
             self.gt_feats = perceptual.target_features(self.gt_small, normalize=True)
 
-    def training_step(self, id_list=None, generator=None):
+    def training_step(self, id_list=None, generator=None, step: Optional[int] = None):
+        """`step` = the stage's own true_global_step (starts at 0): when given, the position learning rate follows
+        `update_learning_rate(step + refine_start_step)` (GaussianIP.py:424)."""
         import random
         import torch.nn.functional as F
         from .renderer import render_views
+        if step is not None:
+            self.gaussian.update_learning_rate(step + self.cfg.refine_start_step)
         if id_list is None:
             id_list = random.sample(range(len(self.orbit_ids)), min(self.train_bs, len(self.orbit_ids)))
         cams = [self.cameras[self.orbit_ids[i]] for i in id_list]
         pkg = render_views(cams, self.gaussian, self.pipe, self.background)
+        # render_refine_rgb bookkeeping (GaussianIP.py:304-313, 343): grad carriers, radii maximum over the views
+        self.viewspace_points = pkg["viewspace_points"]
+        self.refine_radii = pkg["radii"].max(dim=0).values
+        self.refine_visibility_filter = self.refine_radii > 0.0
         img = pkg["render"]
         img = img[:, :, self.CROP[0], self.CROP[1]] if img.shape[2] >= 890 and img.shape[3] >= 800 else img
         small = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=False)
@@ -184,6 +244,71 @@ class StageThreeStep:
                 d = self.perceptual(small, gt)
             loss = loss + self.lambda_lpips * d.mean()
         return {"loss": loss, "render_pkg": pkg, "id_list": id_list}
+
+    # GaussianIP.on_before_optimizer_step (stage 3 branch, GaussianIP.py:476-506), quirks included
+    @torch.no_grad()
+    def on_before_optimizer_step(self, step: int) -> Optional[str]:
+        c, g = self.cfg, self.gaussian
+        gstep = step + c.refine_start_step
+        action = None
+
+        def accumulate():
+            grad = self.viewspace_points.grad.sum(dim=0)
+            vis = self.refine_visibility_filter
+            g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], self.refine_radii[vis].to(g.max_radii2D.dtype))
+            g.add_densification_stats(grad, vis)
+
+        if gstep < 10000:
+            if step == 0:
+                # "When stage 3 starts, the loaded gaussians don't have max_radii2D" (:483-485)
+                g.max_radii2D = self.refine_radii.to(g.max_radii2D.dtype).clone()
+            accumulate()
+            if gstep == 2500:
+                # the threshold test uses the STAGE's step (100 here), so the screen-size limit is off (:491)
+                screen = c.densify_prune_screen_size_threshold if step > c.densify_prune_screen_size_threshold_fix_step else None
+                g.densify_and_prune(c.max_grad, 0.05, c.cameras_extent, screen, c.densify_prune_world_size_threshold)
+                action = "densify_and_prune"
+                return action          # the statistics tensors were rebuilt for the new point count (:492 is the last use)
+        if 2500 < gstep < 3000:
+            accumulate()               # second accumulation of the same step inside this window, as the reference does
+            # operator precedence of the reference's test (:504): step + (refine_start_step % interval) == 0
+            if step + c.refine_start_step % c.prune_only_interval == 0:
+                g.prune_only(min_opacity=c.prune_opacity_threshold, max_world_size=c.prune_world_size_threshold)
+                action = "prune_only"
+        return action
+
+
+def prepare_refined_targets(refined_rgbs, view_idx_all, crop=(slice(60, 890), slice(220, 800))):
+    """refine.py:307-311: refinement order -> orbit order (idx_mapper = argsort(view_idx_all)), NCHW, crop
+    [60:890, 220:800], bilinear half resolution.  Returns (refined_rgbs_small [n,3,h,w], order)."""
+    import torch.nn.functional as F
+    order = torch.argsort(torch.as_tensor(view_idx_all))
+    gt = refined_rgbs[order.to(refined_rgbs.device)].permute(0, 3, 1, 2)
+    gt = gt[:, :, crop[0], crop[1]] if gt.shape[2] >= 890 and gt.shape[3] >= 800 else gt
+    return F.interpolate(gt, scale_factor=0.5, mode="bilinear", align_corners=False), order
+
+
+# ---- hand-off files between the stages (GaussianIP.py:404, refine.py:271-274, 315, GaussianIP.py:359) ----
+def save_before_refine(path, images, control_images):
+    """stage 1 -> stage 2: {'images': [n,H,W,3], 'control_images': [n,H,W,3]} on the CPU."""
+    torch.save({"images": images.detach().to("cpu"), "control_images": control_images.detach().to("cpu")}, path)
+
+
+def load_before_refine(path, device=None):
+    d = torch.load(path, map_location="cpu")
+    images, control = d["images"], d["control_images"]
+    return (images.to(device), control.to(device)) if device is not None else (images, control)
+
+
+def save_after_refine(path, refined_rgbs, view_idx_all):
+    """stage 2 -> stage 3: {'refined_rgbs_small': [n,3,415,290]} (orbit order, cropped, half resolution) on the CPU."""
+    small, _ = prepare_refined_targets(refined_rgbs, view_idx_all)
+    torch.save({"refined_rgbs_small": small.detach().cpu()}, path)
+
+
+def load_after_refine(path, device=None):
+    small = torch.load(path, map_location="cpu")["refined_rgbs_small"]
+    return small.to(device) if device is not None else small
 
 
 def create_refine_batch(n_views=32, elevation_deg=17.0, camera_distance=1.5, fovy_deg=70.0, height=1024, width=1024):

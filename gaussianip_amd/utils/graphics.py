@@ -38,3 +38,25 @@ def getProjectionMatrix(znear, zfar, fovX, fovY):
     m[2, 3] = -(zfar * znear) / (zfar - znear)
     del f32
     return m
+
+
+def get_projection_matrix(fovy, aspect_wh, near, far):
+    """threestudio's OpenGL projection with the y axis flipped (threestudio/utils/ops.py:266-278); fovy [B] radians.
+    The data module builds the per-view mvp matrices from it with near 0.1 / far 1000 (camera_data.py:462-463)."""
+    B = fovy.shape[0]
+    proj = torch.zeros(B, 4, 4, dtype=torch.float32)
+    proj[:, 0, 0] = 1.0 / (torch.tan(fovy / 2.0) * aspect_wh)
+    proj[:, 1, 1] = -1.0 / torch.tan(fovy / 2.0)
+    proj[:, 2, 2] = -(far + near) / (far - near)
+    proj[:, 2, 3] = -2.0 * far * near / (far - near)
+    proj[:, 3, 2] = -1.0
+    return proj
+
+
+def get_mvp_matrix(c2w, proj_mtx):
+    """proj @ w2c with w2c = [R^T | -R^T t] (threestudio/utils/ops.py:281-292).  Pinned by tests/golden/mvp.npz."""
+    w2c = torch.zeros(c2w.shape[0], 4, 4).to(c2w)
+    w2c[:, :3, :3] = c2w[:, :3, :3].permute(0, 2, 1)
+    w2c[:, :3, 3:] = -c2w[:, :3, :3].permute(0, 2, 1) @ c2w[:, :3, 3:]
+    w2c[:, 3, 3] = 1.0
+    return proj_mtx.to(c2w) @ w2c

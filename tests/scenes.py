@@ -116,3 +116,38 @@ def train_cameras(n, seed, H, W):
         az = az0 + 360.0 * i / n
         cams.append(camera(el, az, rng.uniform(1.3, 1.7), rng.uniform(40, 70), H, W))
     return cams
+
+
+def orbit_c2w(elev_deg, azim_deg, dist, center_z=0.0):
+    """threestudio camera-to-world [4,4] torch float32 (camera_data.py:423-454): z up, camera on the sphere of radius
+    `dist` around (0, 0, center_z), looking at that centre."""
+    import torch
+    el, az = math.radians(elev_deg), math.radians(azim_deg)
+    center = torch.tensor([0.0, 0.0, float(center_z)])
+    pos = torch.tensor([dist * math.cos(el) * math.cos(az), dist * math.cos(el) * math.sin(az), dist * math.sin(el)]) + center
+    up = torch.tensor([0.0, 0.0, 1.0])
+    lookat = torch.nn.functional.normalize(center - pos, dim=-1)
+    right = torch.nn.functional.normalize(torch.linalg.cross(lookat, up), dim=-1)
+    upv = torch.nn.functional.normalize(torch.linalg.cross(right, lookat), dim=-1)
+    c2w = torch.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, upv, -lookat, pos
+    return c2w
+
+
+def train_batch(rng, B=4, H=1024, W=1024, device=None):
+    """One batch of the random-camera data module (camera_data.py:330-470 with the ranges of configs/exp.yaml:6-45):
+    elevation U(-30, 30), batch-uniform azimuth over (-180, 180), distance U(1.3, 1.7), fovy U(40, 70) degrees, looking
+    at the origin.  Camera algebra stays on the host (c2w, fovy, mvp_mtx: CPU tensors, like the data module's), the
+    per-view scalars the prompt lookup reads go to `device`.  Keys as the reference's batch dict."""
+    import torch
+    from gaussianip_amd.utils.graphics import get_mvp_matrix, get_projection_matrix
+    el = rng.uniform(-30, 30, B).astype(np.float32)
+    az = (((rng.random(B) + np.arange(B)) / B) * 360.0 - 180.0).astype(np.float32)
+    dist = rng.uniform(1.3, 1.7, B).astype(np.float32)
+    fovy = np.radians(rng.uniform(40, 70, B)).astype(np.float32)
+    c2w = torch.stack([orbit_c2w(float(el[k]), float(az[k]), float(dist[k])) for k in range(B)])
+    fovy_t = torch.from_numpy(fovy)
+    mvp = get_mvp_matrix(c2w, get_projection_matrix(fovy_t, W / H, 0.1, 1000.0))
+    dev = (lambda t: t.to(device, non_blocking=True)) if device is not None else (lambda t: t)
+    return dict(c2w=c2w, fovy=fovy_t, mvp_mtx=mvp, height=H, width=W, elevation=dev(torch.from_numpy(el)),
+                azimuth=dev(torch.from_numpy(az)), center=dev(torch.zeros(B)), camera_distances=dev(torch.from_numpy(dist)))

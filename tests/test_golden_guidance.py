@@ -229,3 +229,16 @@ def test_oracle_cov3D_backward_matches_reference_autograd(oracle, tag, mod):
     np.testing.assert_allclose(mod * ds, ref_ds, atol=1e-6 * np.abs(ref_ds).max(), rtol=2e-4)
     proj = dq - (dq * q).sum(1, keepdims=True) * q
     np.testing.assert_allclose(proj, ref_dq, atol=2e-5 * np.abs(ref_dq).max(), rtol=1e-3)
+
+
+def test_mvp_matrices_and_bce_match_reference_ops():
+    from gaussianip_amd.system import binary_cross_entropy
+    from gaussianip_amd.utils.graphics import get_mvp_matrix, get_projection_matrix
+    d = np.load(os.path.join(GOLD, "mvp.npz"))
+    fovy, c2w = T(d["fovy"]), T(d["c2w"])
+    proj = get_projection_matrix(fovy, 1.0, 0.1, 1000.0)
+    assert np.array_equal(proj.numpy(), d["proj"])
+    assert np.array_equal(get_projection_matrix(fovy, 1.5, 0.1, 1000.0).numpy(), d["proj_aspect_1p5"])
+    np.testing.assert_allclose(get_mvp_matrix(c2w, proj).numpy(), d["mvp"], atol=1e-6)
+    x = T(d["bce_x"])
+    np.testing.assert_allclose(binary_cross_entropy(x, x).numpy(), d["bce"], rtol=1e-6)

@@ -47,8 +47,7 @@ def _model(P=5000, seed=7, sh_degree=0):
 def _camera(el, az, dist, fovy_deg, H, W):
     from gaussianip_amd.scene import Camera
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
-    from make_golden import orbit_c2w
+    from scenes import orbit_c2w
     return Camera(c2w=orbit_c2w(el, az, dist).cuda(), FoVy=math.radians(fovy_deg), height=H, width=W)
 
 
@@ -150,8 +149,7 @@ def test_stage_one_step_schedule_and_loss():
     import sys
     from gaussianip_amd.arguments import PipelineParams
     from gaussianip_amd.system import StageOneStep
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
-    from make_golden import orbit_c2w
+    from scenes import orbit_c2w
     gm = _model(P=6000, seed=3)
     st = StageOneStep(gm, PipelineParams(ArgumentParser()), torch.zeros(3, device="cuda"))
     batch = dict(c2w=torch.stack([orbit_c2w(5.0, 90.0 * i, 1.5) for i in range(4)]).cuda(),

@@ -25,7 +25,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     import numpy as np
     import torch
     import scenes
-    from make_golden import orbit_c2w
+    from scenes import orbit_c2w
     from gaussianip_amd.arguments import OptimizationParams, PipelineParams
     from gaussianip_amd.guidance import GuidanceConfig, PromptEmbeddings, StableDiffusionGuidance
     from gaussianip_amd.renderer import render_views

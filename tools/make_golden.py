@@ -529,6 +529,24 @@ def backward():
     print("backward fixtures written")
 
 
+def ops():
+    """threestudio/utils/ops.py:266-300 (get_projection_matrix, get_mvp_matrix, binary_cross_entropy) — the data module's
+    mvp matrices (camera_data.py:462-463) that the pose-map drawing consumes (GaussianIP.py:177)."""
+    _install_threestudio_stubs()
+    sys.modules.setdefault("igl", _Stub("igl"))
+    mod = _load_by_path("threestudio.utils.ops_by_path", "threestudio/utils/ops.py", "threestudio.utils")
+    rng = np.random.default_rng(5)
+    c2w = torch.stack([orbit_c2w(rng.uniform(-30, 30), rng.uniform(-180, 180), rng.uniform(1.3, 1.7)) for _ in range(8)])
+    fovy = torch.tensor(np.radians(rng.uniform(40, 70, 8)), dtype=torch.float32)
+    proj = mod.get_projection_matrix(fovy, 1.0, 0.1, 1000.0)
+    proj_wide = mod.get_projection_matrix(fovy, 1.5, 0.1, 1000.0)
+    mvp = mod.get_mvp_matrix(c2w, proj)
+    x = torch.rand(64, generator=torch.Generator().manual_seed(3)) * 0.98 + 0.01
+    np.savez(os.path.join(OUT, "mvp.npz"), c2w=c2w.numpy(), fovy=fovy.numpy(), proj=proj.numpy(), proj_aspect_1p5=proj_wide.numpy(),
+             mvp=mvp.numpy(), bce_x=x.numpy(), bce=mod.binary_cross_entropy(x, x).numpy())
+    print("ops fixtures written")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ahds":
         ahds()
@@ -536,5 +554,7 @@ if __name__ == "__main__":
         guidance()
     elif len(sys.argv) > 1 and sys.argv[1] == "backward":
         backward()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ops":
+        ops()
     else:
         main()
