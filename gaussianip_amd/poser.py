@@ -36,6 +36,9 @@ class Skeleton:
         self.device = torch.device(device)
         self.points3D = torch.cat([torch.from_numpy(pts), torch.ones(pts.shape[0], 1)], dim=1).to(self.device)   # homogeneous
         self.lines = torch.tensor(LINES, dtype=torch.long, device=self.device)
+        zoom = torch.zeros(18, dtype=torch.bool)
+        zoom[[0, 1, 3, 6, 14, 15, 16, 17]] = True              # key points kept in a head zoom (poser.py:846-849)
+        self._zoom = zoom.to(self.device)
         self.name = list(NAMES)
 
     def scale(self, delta):
@@ -59,9 +62,7 @@ class Skeleton:
         V = mask.shape[0]
         az = torch.as_tensor(azimuth, device=mask.device, dtype=torch.float32).reshape(V)
         hz = torch.as_tensor(head_zoom, device=mask.device, dtype=torch.bool).reshape(V, 1)
-        zoom = torch.zeros(18, dtype=torch.bool, device=mask.device)
-        zoom[[0, 1, 3, 6, 14, 15, 16, 17]] = True
-        mask = torch.where(hz, zoom[None].expand(V, 18), mask).clone()
+        mask = torch.where(hz, self._zoom.to(mask.device)[None].expand(V, 18), mask).clone()
         mask[:, 16] &= ~((az > 0) & (az < 60))
         mask[:, 17] &= ~((az > 120) & (az < 180))
         z0, z_l, z_r = ndc[:, 0, 2], ndc[:, 17, 2], ndc[:, 16, 2]

@@ -294,9 +294,9 @@ def _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3
         mv = lambda t: t.float().reshape(1, -1).to(dev, non_blocking=True).contiguous()  # noqa: E731
         plan.viewmatrix, plan.projmatrix, plan.campos = mv(s0.viewmatrix), mv(s0.projmatrix), mv(s0.campos)
     else:
-        plan.viewmatrix = torch.stack([s.viewmatrix.float().reshape(16) for s in settings_list]).to(dev).contiguous()
-        plan.projmatrix = torch.stack([s.projmatrix.float().reshape(16) for s in settings_list]).to(dev).contiguous()
-        plan.campos = torch.stack([s.campos.float().reshape(3) for s in settings_list]).to(dev).contiguous()
+        plan.viewmatrix = torch.stack([s.viewmatrix.float().reshape(16) for s in settings_list]).to(dev, non_blocking=True).contiguous()
+        plan.projmatrix = torch.stack([s.projmatrix.float().reshape(16) for s in settings_list]).to(dev, non_blocking=True).contiguous()
+        plan.campos = torch.stack([s.campos.float().reshape(3) for s in settings_list]).to(dev, non_blocking=True).contiguous()
     plan.bg = s0.bg.float().to(dev, non_blocking=True).contiguous()
     return plan
 

@@ -166,7 +166,8 @@ class StageOneStep:
         def accumulate():
             grad = self.viewspace_points.grad.sum(dim=0)             # sum of the per-view grads (:451-454)
             vis = self.visibility_filter
-            g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], self.radii[vis].to(g.max_radii2D.dtype))
+            # same values as the reference's masked assignment (:456), without nonzero() = without a host synchronisation
+            g.max_radii2D = torch.where(vis, torch.max(g.max_radii2D, self.radii.to(g.max_radii2D.dtype)), g.max_radii2D)
             g.add_densification_stats(grad, vis)
 
         if step < c.densify_prune_end_step:
@@ -255,7 +256,7 @@ class StageThreeStep:
         def accumulate():
             grad = self.viewspace_points.grad.sum(dim=0)
             vis = self.refine_visibility_filter
-            g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], self.refine_radii[vis].to(g.max_radii2D.dtype))
+            g.max_radii2D = torch.where(vis, torch.max(g.max_radii2D, self.refine_radii.to(g.max_radii2D.dtype)), g.max_radii2D)
             g.add_densification_stats(grad, vis)
 
         if gstep < 10000:
