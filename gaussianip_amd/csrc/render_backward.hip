@@ -7,7 +7,7 @@
 //
 // MI355X-first formulation:
 //   * NO serial walk.  The forward kernel checkpoints the per-pixel blend state (T, C, D) every
-//     GIP_SEGMENT = 256 list entries.  With kappa_j = c_j.gC + d_j gD, S_tot = C_tot.gC + D_tot gD and the
+//     GIP_SEGMENT = 64 list entries.  With kappa_j = c_j.gC + d_j gD, S_tot = C_tot.gC + D_tot gD and the
 //     running prefix Sp_{j+1} = sum_{k<=j} a_k T_k kappa_k, the gradient of entry j is
 //         dL/dalpha_j = T_j kappa_j + [Sp_{j+1} - S_tot + T_final (gA - bg.gC)] / (1 - a_j)
 //     which is algebraically the reference's back-to-front recurrence (its accum_rec is
@@ -123,7 +123,14 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
   uint32_t nseg = header->num_segments;
   if (nseg > kp.seg_capacity) nseg = kp.seg_capacity;
 
-  for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+  // XCD-aware work assignment: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share one), each XCD has
+  // its own L2, and every segment of a tile re-reads that tile's per-pixel inputs (48 B / pixel) and neighbouring tiles
+  // share Gaussian records.  Giving XCD k the CONTIGUOUS eighth [k * per, (k + 1) * per) of the tile-ordered segment
+  // list keeps those re-reads inside one L2 (fabric fetches 544 -> ~250 MB per launch; speed only, never correctness).
+  const uint32_t per = (nseg + 7u) >> 3, xcd = blockIdx.x & 7u;
+  for (uint32_t local = blockIdx.x >> 3; local < per; local += gridDim.x >> 3) {
+    const uint32_t seg = xcd * per + local;
+    if (seg >= nseg) break;
     const uint32_t vt = seg_tile[seg];
     const uint32_t b = seg - seg_start[vt];              // segment index inside the tile
     const uint32_t start = tile_start[vt];

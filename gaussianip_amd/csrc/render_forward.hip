@@ -39,6 +39,13 @@ __device__ __forceinline__ float xchg32(float x, int hh) {
   return hh ? a : b;
 }
 
+// both halves' values of x: after v_permlane32_swap(a, b) with a = b = x, a holds the LOW half's value in every lane and
+// b the HIGH half's (a <- [a_lo | b_lo], b <- [a_hi | b_hi]) — no per-lane select needed
+__device__ __forceinline__ void both32(float x, float& lo, float& hi) {
+  lo = x; hi = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+}
+
 __global__ void __launch_bounds__(FWD_THREADS)
 gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_order,
                           const uint32_t* __restrict__ tile_start, const unsigned long long* __restrict__ keys,
@@ -165,21 +172,22 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
           bool any_stop = false;
 #pragma unroll
           for (int u = 0; u < FWD_PAIRS; u++) {
-            const float ao = xchg32(al[u], hh);
-            const float a_e = hh ? ao : al[u], a_o = hh ? al[u] : ao;            // first / second entry of the pair
-            // the reference's per-entry rule, applied to both entries in order by both lane halves
+            float a_e, a_o;                                                      // first / second entry of the pair
+            both32(al[u], a_e, a_o);
+            // the reference's per-entry rule, applied to both entries in order by both lane halves; a terminated pixel
+            // sees alpha 0, which leaves T and the sums unchanged
+            a_e = done ? 0.f : a_e;
             const float t1 = T * (1.f - a_e);
-            const bool stop1 = !done && t1 < GIP_T_MIN;
-            const bool live1 = !done && !stop1;
-            const float T1 = live1 ? t1 : T;
+            const bool stop1 = t1 < GIP_T_MIN;                                   // only reachable with a_e > 0
+            const float T1 = stop1 ? T : t1;
+            a_o = (done || stop1) ? 0.f : a_o;
             const float t2 = T1 * (1.f - a_o);
-            const bool stop2 = live1 && t2 < GIP_T_MIN;
-            const bool live2 = live1 && !stop2;
-            const bool acc = al[u] > 0.f && (hh ? live2 : live1);
-            const float w = acc ? al[u] * (hh ? T1 : T) : 0.f;
+            const bool stop2 = t2 < GIP_T_MIN;
+            float w = hh ? a_o * T1 : a_e * T;
+            w = (hh ? stop2 : stop1) ? 0.f : w;
             C0 += cc[u].x * w; C1 += cc[u].y * w; C2 += cc[u].z * w; Wt += w; Dp += cc[u].w * w;
-            last_contributor = acc ? (base - start) + jj[u] + 1 : last_contributor;
-            T = live2 ? t2 : T1;
+            last_contributor = w > 0.f ? (base - start) + jj[u] + 1 : last_contributor;
+            T = stop2 ? T1 : t2;
             done = done || stop1 || stop2;
             any_stop = any_stop || stop1 || stop2;
           }
@@ -209,6 +217,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     final_T[(size_t)v * HW + pix] = T;
   }
 }
+
 
 void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth,
                                float* alpha, hipStream_t s) {

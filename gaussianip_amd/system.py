@@ -81,6 +81,8 @@ class StageOneStep:
         self.hand_centers = hand_centers
         self.skeleton, self.pose_hw, self.head_offset = skeleton, (pose_height, pose_width), head_offset
         self.viewspace_points = None
+        self.viewspace_grad_sum = None      # [P,3], set by a multi-GPU exchange hook (sum over ALL ranks' views)
+        self.depth_max_reduce = None        # callable(0-d tensor) -> all-reduced maximum, set for view-sharded runs
         self.radii = None
         self.visibility_filter = None
 
@@ -92,6 +94,7 @@ class StageOneStep:
                               for i in range(B)]
         pkg = render_views(cams, self.gaussian, self.pipe, bg)
         self.viewspace_points = pkg["viewspace_points"]              # [B,P,3]; .grad after backward
+        self.viewspace_grad_sum = None
         self.radii = pkg["radii"].max(dim=0).values                  # running max over the views (:165-168)
         self.visibility_filter = self.radii > 0.0
         if self.cfg.disable_hand_densification and self.hand_centers is not None:
@@ -99,7 +102,12 @@ class StageOneStep:
             self.visibility_filter = self.visibility_filter & ~(dist.min(dim=-1).values < self.cfg.hand_radius)
         images = pkg["render"].permute(0, 2, 3, 1)                   # [B,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)               # [B,H,W,1]
-        out = {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (depths.max() + 1e-5),
+        dmax = depths.max()                                          # batch-global maximum (:225)
+        if self.depth_max_reduce is not None:
+            # view-sharded ranks: the maximum over ALL ranks' views; its gradient flows on the rank that holds it
+            gmax = self.depth_max_reduce(dmax.detach().clone())
+            dmax = torch.where(dmax.detach() == gmax, dmax, gmax)
+        out = {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (dmax + 1e-5),
                "scale": self.gaussian.get_scaling}
         if self.skeleton is not None and "mvp_mtx" in batch:
             dev = images.device
@@ -164,7 +172,8 @@ class StageOneStep:
         action = None
 
         def accumulate():
-            grad = self.viewspace_points.grad.sum(dim=0)             # sum of the per-view grads (:451-454)
+            # sum of the per-view grads (:451-454); a multi-GPU exchange leaves the all-reduced sum in viewspace_grad_sum
+            grad = self.viewspace_grad_sum if self.viewspace_grad_sum is not None else self.viewspace_points.grad.sum(dim=0)
             vis = self.visibility_filter
             # same values as the reference's masked assignment (:456), without nonzero() = without a host synchronisation
             g.max_radii2D = torch.where(vis, torch.max(g.max_radii2D, self.radii.to(g.max_radii2D.dtype)), g.max_radii2D)

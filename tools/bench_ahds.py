@@ -18,18 +18,24 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None):
-    """Runs the step `warmup + steps` times and returns the result dict.  With world > 1 (process group initialised by
-    the caller) every rank trains on its own 4 cameras of the replicated Gaussians and the per-step exchange of
-    parallel.exchange_step (gradients, densification statistics, depth maximum) runs inside the timed step."""
+def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None, amp=True):
+    """Runs the step `warmup + steps` times and returns the result dict.  The timed step is the reference's
+    training_step + optimizer step as the system runs them (system.StageOneStep.training_step / optimizer_step):
+    learning-rate update, render of the 4 cameras, OpenPose pose maps drawn on the GPU from the batch's mvp matrices,
+    view-dependent prompt lookup, guidance call, loss assembly, backward, densification statistics, Adam — with a
+    GradScaler when `amp` (the reference trains with `precision: 16-mixed`, configs/exp.yaml:193; its scaler.step() is
+    the one host synchronisation of the step, as in the reference).
+    With world > 1 (process group initialised by the caller) every rank trains on its own 4 cameras of the replicated
+    Gaussians and the per-step exchange (gradients, densification statistics, depth maximum) runs inside the timed step."""
     import numpy as np
     import torch
     import scenes
-    from scenes import orbit_c2w
     from gaussianip_amd.arguments import OptimizationParams, PipelineParams
-    from gaussianip_amd.guidance import GuidanceConfig, PromptEmbeddings, StableDiffusionGuidance
-    from gaussianip_amd.renderer import render_views
-    from gaussianip_amd.scene import Camera, GaussianModel
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance
+    from gaussianip_amd.guidance.prompts import PromptProcessor
+    from gaussianip_amd.poser import Skeleton
+    from gaussianip_amd.scene import GaussianModel
+    from gaussianip_amd.system import StageOneStep
     from gaussianip_amd.utils import BasicPointCloud
 
     from gaussianip_amd import parallel
@@ -44,46 +50,39 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     with contextlib.redirect_stdout(sys.stderr):      # the model announces its size on stdout like the reference; keep stdout for the JSON line
         gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
     gm.training_setup(OptimizationParams(ArgumentParser()))
-    pipe = PipelineParams(ArgumentParser())
-    bg = torch.zeros(3, device=dev)
+    skel = Skeleton(dev)
+    skel.scale(-10)
+    stage = StageOneStep(gm, PipelineParams(ArgumentParser()), torch.zeros(3, device=dev), skeleton=skel)
     t0 = time.time()
-    guidance = StableDiffusionGuidance(GuidanceConfig(channels_last=channels_last))
     g = torch.Generator(device=dev).manual_seed(1)
-    tabs = [torch.randn(13, 77, 768, device=dev, generator=g) * 0.1 for _ in range(3)]
-    prompts = PromptEmbeddings(*tabs, direction_fn=lambda el, az, c, v, d: ((az % 360) / 90).long())
-    guidance.set_image_embeds(torch.randn(1, 4, 768, device=dev, generator=g) * 0.1, torch.zeros(1, 4, 768, device=dev),
-                              torch.randn(1, 4, 768, device=dev, generator=g) * 0.1)
+    tokens = (torch.randn(1, 4, 768, device=dev, generator=g) * 0.1, torch.zeros(1, 4, 768, device=dev),
+              torch.randn(1, 4, 768, device=dev, generator=g) * 0.1)
+    guidance = StableDiffusionGuidance(GuidanceConfig(channels_last=channels_last), image_embeds_provider=lambda gd: tokens)
+    pp = PromptProcessor("a person wearing a coat", lambda texts: torch.randn(len(texts), 77, 768, device=dev, generator=g).half() * 0.1,
+                         negative_prompt="blurry")
+    guidance.prepare_for_sds(pp.prompt, pp.negative_prompt, pp.null_prompt)
+    prompt_utils = pp()
     setup_s = time.time() - t0
+    scaler = torch.amp.GradScaler("cuda") if amp else None
+    if world > 1:
+        def all_max(x):
+            torch.distributed.all_reduce(x, op=torch.distributed.ReduceOp.MAX)
+            return x
+        stage.depth_max_reduce = all_max
     pose = torch.rand(B, 512, 512, 3, device=dev, generator=g)
 
+    def exchange(st):
+        # replicated Gaussians, rank-specific cameras = one global batch of 4 * world views: gradients averaged, the
+        # view-space gradient vectors summed, radii maximum (GaussianIP.py:452-457 over all ranks' views)
+        vs = st.viewspace_points.grad.sum(0)
+        parallel.exchange_step([g_["params"][0] for g_ in gm.optimizer.param_groups], vs, st.radii, None, average=True)
+        st.viewspace_grad_sum = vs
+        st.visibility_filter = st.radii > 0
+
     def step(i):
-        gm.update_learning_rate(i)
-        rng = cam_rng
-        el_h = rng.uniform(-30, 30, B).astype(np.float32)      # camera parameters live on the host (data module), like the reference
-        az0 = rng.uniform(-180, 180)
-        az_h = np.array([az0 + 90.0 * k for k in range(B)], np.float32)
-        el = torch.from_numpy(el_h).to(dev, non_blocking=True)
-        az = torch.from_numpy(az_h).to(dev, non_blocking=True)
-        cams = [Camera(c2w=orbit_c2w(float(el_h[k]), float(az_h[k]), rng.uniform(1.3, 1.7)), data_device=dev, FoVy=math.radians(rng.uniform(40, 70)),
-                       height=H, width=W) for k in range(B)]
-        pkg = render_views(cams, gm, pipe, bg)
-        rgb = pkg["render"].permute(0, 2, 3, 1)
-        depth = pkg["depth_3dgs"].permute(0, 2, 3, 1)
-        out = guidance(i, rgb, pose, prompts, True, torch.ones(B, device=dev), el, az, None, None)
-        dmax = depth.detach().max()
-        if world > 1:
-            torch.distributed.all_reduce(dmax, op=torch.distributed.ReduceOp.MAX)   # GaussianIP.py:225: batch-global max
-        opacity = depth / (dmax + 1e-5)
-        loss = out["loss_sds"] + torch.sqrt(opacity ** 2 + 0.01).mean()
-        gm.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        vs = pkg["viewspace_points"].grad.sum(0)
-        radii = pkg["radii"].max(dim=0).values
-        if world > 1:
-            parallel.exchange_step([g_["params"][0] for g_ in gm.optimizer.param_groups], vs, radii, None, average=True)
-        gm.max_radii2D = torch.max(gm.max_radii2D, radii.float())
-        gm.add_densification_stats(vs, radii > 0)
-        gm.optimizer.step()
+        batch = scenes.train_batch(cam_rng, B, H, W, device=dev)
+        loss, out, gout = stage.training_step(i, batch, guidance, prompt_utils, True)
+        stage.optimizer_step(loss, i, scaler=scaler, exchange=exchange if world > 1 else None)
         return loss
 
     for i in range(warmup):
@@ -134,8 +133,9 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
             guidance.forward_unet(torch.cat([lat] * 3), torch.cat([ctrl] * 3), torch.cat([tt] * 3), emb, True)
         nflops = fc.get_total_flops()
     flops = nflops
-    out = {"metric": "ahds_train_steps_per_s", "value": round(world / dt, 3), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2),
-           "views_per_s": round(world * B / dt, 2), "n_gpus": world, "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
+    out = {"metric": "ahds_train_steps_per_s", "value": round(1.0 / dt, 3), "unit": "optimizer steps/s", "ms_per_step": round(dt * 1e3, 2),
+           "views_per_s": round(world * B / dt, 2), "views_per_optimizer_step": world * B, "n_gpus": world, "amp_gradscaler": bool(amp),
+           "timed_step": "lr update + render 4 views + GPU pose maps + prompt lookup + VAE/ControlNet/U-Net ANPG + loss + backward + densification stats + Adam", "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
            "denoise_ms": round(den_ms, 2), "vae_enc_fwd_bwd_ms": round(vae_ms, 2), "setup_s": round(setup_s, 1),
            "denoise_flops": flops, "denoise_tflops_per_s": None if not flops else round(flops / (den_ms * 1e-3) / 1e12, 1),
            "denoise_mfma_frac": None if not flops else round(flops / (den_ms * 1e-3) / 2.5e15, 4),   # fp16 dense peak ~2.5 PFLOP/s
@@ -150,8 +150,9 @@ def main():
     ap.add_argument("--gaussians", type=int, default=100000)
     ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--flops", action="store_true")
+    ap.add_argument("--no-amp", action="store_true", help="no GradScaler (the reference trains with 16-mixed)")
     args = ap.parse_args()
-    print(json.dumps(measure(args.steps, args.warmup, args.gaussians, not args.no_channels_last, args.flops)), flush=True)
+    print(json.dumps(measure(args.steps, args.warmup, args.gaussians, not args.no_channels_last, args.flops, amp=not args.no_amp)), flush=True)
 
 
 if __name__ == "__main__":

@@ -33,6 +33,7 @@ print("\n".join(lines))
 PY
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv
 # full AHDS training step (raster + VAE + ControlNet + U-Net + Adam): steady-state per-step kernel summary
+if [ -n "$SKIP_AHDS" ]; then tail -1 $OUT/bench_stats.log | cut -c1-600; exit 0; fi
 rocprofv3 --kernel-trace -d /tmp/prof_ahds -o st -- python3 $GRAFT_REPO_ROOT/tools/bench_ahds.py --steps 6 --warmup 4 > $OUT/ahds_trace.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/analyze_db.py /tmp/prof_ahds/st_results.db gip_preprocess_kernel 60 > $OUT/ahds_step_summary.txt
 head -16 $OUT/ahds_step_summary.txt
