@@ -37,17 +37,36 @@ DIRECTIONS: Tuple[Direction, ...] = tuple(
 DIRECTION2IDX: Dict[str, int] = {d.name: i for i, d in enumerate(DIRECTIONS)}
 
 
+_TABLES = {}
+
+
+def _tables(device):
+    """Window bounds / visibility flags of the 12 azimuth directions and the name-keyed target index of all 13, as
+    device tensors (built once per device)."""
+    t = _TABLES.get(device)
+    if t is None:
+        win = [d for d in DIRECTIONS if d.name != "overhead"]
+        t = _TABLES[device] = dict(
+            lo=torch.tensor([d.lo for d in win], dtype=torch.float32, device=device),
+            hi=torch.tensor([d.hi for d in win], dtype=torch.float32, device=device),
+            vis=torch.tensor([float(d.all_vis) for d in win], dtype=torch.float32, device=device),
+            order=torch.arange(1, len(DIRECTIONS) + 1, device=device),
+            target=torch.tensor([0] + [DIRECTION2IDX[d.name] for d in DIRECTIONS], dtype=torch.long, device=device))
+    return t
+
+
 def direction_index(elevation, azimuth, center, all_vis_all, camera_distances=None, head_offset=0.65):
     """Per-view index into the [13, 77, 768] tables (base.py:66-68): the conditions are applied in list order, each
-    writing direction2idx[name]; "overhead" = (center == head_offset) & (azimuth > 0) comes last and wins."""
-    idx = torch.zeros_like(elevation, dtype=torch.long)
-    for d in DIRECTIONS:
-        if d.name == "overhead":
-            cond = (center == head_offset) & (azimuth > 0)
-        else:
-            cond = (all_vis_all == d.all_vis) & (azimuth > d.lo) & (azimuth < d.hi)
-        idx = torch.where(cond, DIRECTION2IDX[d.name], idx)       # (a masked assignment would synchronise on the GPU)
-    return idx
+    writing direction2idx[name]; "overhead" = (center == head_offset) & (azimuth > 0) comes last and wins; views that
+    match nothing keep index 0.  Evaluated as one [B, 13] condition matrix (a dozen small kernels, no masked
+    assignment, no host synchronisation) — the LAST matching direction decides, like the reference's loop."""
+    t = _tables(azimuth.device)
+    az = azimuth.to(torch.float32)[:, None]
+    cond = (all_vis_all.to(torch.float32)[:, None] == t["vis"]) & (az > t["lo"]) & (az < t["hi"])          # [B, 12]
+    over = (center.to(az.device) == head_offset) & (azimuth > 0)
+    cond = torch.cat([cond, over[:, None]], dim=1)                                                        # [B, 13]
+    last = (cond.to(torch.long) * t["order"]).amax(dim=1)                  # 1-based position of the last match, 0 = none
+    return t["target"][last]
 
 
 def view_dependent_prompts(prompt: str) -> List[str]:

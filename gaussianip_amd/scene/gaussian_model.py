@@ -123,7 +123,10 @@ class GaussianModel:
         self._opacity = nn.Parameter(opac.requires_grad_(True))
         self.max_radii2D = torch.zeros((n,), device=dev)
 
-    def training_setup(self, training_args):
+    def training_setup(self, training_args, fused: bool = False):
+        """`fused=True` (GPU only): torch's fused Adam — the same update rule in one multi-tensor kernel, and the form that
+        lets a GradScaler skip / unscale on the device: `scaler.step()` then issues no host synchronisation (the
+        reference's plain Adam under `precision: 16-mixed` pays one `.item()` per step)."""
         n, dev = self.get_xyz.shape[0], self.get_xyz.device
         self.percent_dense = training_args.percent_dense
         self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
@@ -132,7 +135,7 @@ class GaussianModel:
                "f_rest": training_args.feature_lr / 20.0, "opacity": training_args.opacity_lr,
                "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
         self.params_list = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in _GROUPS]
-        self.optimizer = torch.optim.Adam(self.params_list, lr=0.0, eps=1e-15)
+        self.optimizer = torch.optim.Adam(self.params_list, lr=0.0, eps=1e-15, **({"fused": True} if fused else {}))
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=training_args.position_lr_init * self.spatial_lr_scale,
             lr_final=training_args.position_lr_final * self.spatial_lr_scale,

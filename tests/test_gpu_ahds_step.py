@@ -32,7 +32,7 @@ def rig():
     rng = np.random.default_rng(42)
     gm = GaussianModel(0)
     gm.create_from_pcd(BasicPointCloud(scenes.human_points(P, rng).astype(np.float32), np.full((P, 3), 0.5, np.float32), None), 4.0)
-    gm.training_setup(OptimizationParams(ArgumentParser()))
+    gm.training_setup(OptimizationParams(ArgumentParser()), fused=True)
     skel = Skeleton(dev)
     skel.scale(-10)                                              # GaussianIP.py:128: the skeleton of the 1.1^10-scaled body
     stage = StageOneStep(gm, PipelineParams(ArgumentParser()), torch.zeros(3, device=dev), skeleton=skel)
@@ -58,6 +58,7 @@ def test_three_full_ahds_steps(rig):
     assert names == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
     before = dict(_lib.call_counts)
     losses = []
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)     # precision: 16-mixed; with the fused Adam its step() stays on the device
     for step in range(3):
         batch = scenes.train_batch(cam_rng, B, H, W, device=dev)
         if step > 0:
@@ -66,7 +67,7 @@ def test_three_full_ahds_steps(rig):
             torch.cuda.set_sync_debug_mode("error")
         try:
             loss, out, gout = stage.training_step(step, batch, guidance, prompt_utils, True)
-            action = stage.optimizer_step(loss, step)
+            action = stage.optimizer_step(loss, step, scaler=scaler if step == 2 else None)
         finally:
             torch.cuda.set_sync_debug_mode("default")
         assert action is None and set(gout) == {"loss_sds", "grad_norm"}

@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None, amp=True):
+def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None, amp=True,
+            fused_adam=True):
     """Runs the step `warmup + steps` times and returns the result dict.  The timed step is the reference's
     training_step + optimizer step as the system runs them (system.StageOneStep.training_step / optimizer_step):
     learning-rate update, render of the 4 cameras, OpenPose pose maps drawn on the GPU from the batch's mvp matrices,
@@ -49,7 +50,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the model announces its size on stdout like the reference; keep stdout for the JSON line
         gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
-    gm.training_setup(OptimizationParams(ArgumentParser()))
+    gm.training_setup(OptimizationParams(ArgumentParser()), fused=fused_adam)
     skel = Skeleton(dev)
     skel.scale(-10)
     stage = StageOneStep(gm, PipelineParams(ArgumentParser()), torch.zeros(3, device=dev), skeleton=skel)
@@ -134,7 +135,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         nflops = fc.get_total_flops()
     flops = nflops
     out = {"metric": "ahds_train_steps_per_s", "value": round(1.0 / dt, 3), "unit": "optimizer steps/s", "ms_per_step": round(dt * 1e3, 2),
-           "views_per_s": round(world * B / dt, 2), "views_per_optimizer_step": world * B, "n_gpus": world, "amp_gradscaler": bool(amp),
+           "views_per_s": round(world * B / dt, 2), "views_per_optimizer_step": world * B, "n_gpus": world, "amp_gradscaler": bool(amp), "fused_adam": bool(fused_adam),
            "timed_step": "lr update + render 4 views + GPU pose maps + prompt lookup + VAE/ControlNet/U-Net ANPG + loss + backward + densification stats + Adam", "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
            "denoise_ms": round(den_ms, 2), "vae_enc_fwd_bwd_ms": round(vae_ms, 2), "setup_s": round(setup_s, 1),
            "denoise_flops": flops, "denoise_tflops_per_s": None if not flops else round(flops / (den_ms * 1e-3) / 1e12, 1),
@@ -151,8 +152,9 @@ def main():
     ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--flops", action="store_true")
     ap.add_argument("--no-amp", action="store_true", help="no GradScaler (the reference trains with 16-mixed)")
+    ap.add_argument("--plain-adam", action="store_true", help="torch's default Adam like the reference (GradScaler.step then synchronises)")
     args = ap.parse_args()
-    print(json.dumps(measure(args.steps, args.warmup, args.gaussians, not args.no_channels_last, args.flops, amp=not args.no_amp)), flush=True)
+    print(json.dumps(measure(args.steps, args.warmup, args.gaussians, not args.no_channels_last, args.flops, amp=not args.no_amp, fused_adam=not args.plain_adam)), flush=True)
 
 
 if __name__ == "__main__":
