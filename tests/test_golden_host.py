@@ -288,3 +288,34 @@ def test_refine_orbit_and_system_config_from_yaml_keys():
                                     "loss": {"lambda_sds": 2.0, "lambda_sparsity": 0.5, "lambda_opaque": 0, "scale_tau": 2}, "stage": "stage1"})
     assert cfg.densify_prune_start_step == 100 and cfg.max_grad == 3e-4 and cfg.lambda_sds == 2.0 and cfg.lambda_sparsity == 0.5
     assert cfg.refine_n_views == 16 and cfg.extra["pts_num"] == 100000 and "loss" in cfg.extra
+
+
+def test_ply_file_matches_the_reference_vertex_table(tmp_path):
+    """save_ply writes exactly the vertex table the reference hands to plyfile (gaussian_model.py:199-216; fixture
+    tools/make_golden.py `ply`): same property names in the same order, same float32 rows, in plyfile's
+    binary_little_endian layout; load_ply restores the parameters (and reads files whose columns come in any order)."""
+    from gaussianip_amd.scene import GaussianModel
+    d = np.load(os.path.join(GOLD, "ply_layout.npz"))
+    assert str(d["element_name"]) == "vertex"
+    for deg in (0, 2):
+        gm = GaussianModel(deg)
+        gm.device = torch.device("cpu")
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            setattr(gm, k, torch.nn.Parameter(torch.from_numpy(d["deg%d%s" % (deg, k)])))
+        names = list(d["names_deg%d" % deg])
+        assert gm.construct_list_of_attributes() == names
+        path = str(tmp_path / ("m%d.ply" % deg))
+        gm.save_ply(path)
+        raw = open(path, "rb").read()
+        head, body = raw.split(b"end_header\n", 1)
+        lines = head.decode("ascii").split("\n")
+        n = d["table_deg%d" % deg].shape[0]
+        assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex %d" % n]
+        assert lines[3:-1] == ["property float %s" % k for k in names] and lines[-1] == ""
+        table = np.frombuffer(body, dtype="<f4").reshape(n, len(names))
+        assert np.array_equal(table, d["table_deg%d" % deg])
+        back = GaussianModel(deg)
+        back.device = torch.device("cpu")
+        back.load_ply(path)
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            assert torch.equal(getattr(back, k).detach(), torch.from_numpy(d["deg%d%s" % (deg, k)])), k

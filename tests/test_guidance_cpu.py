@@ -371,3 +371,64 @@ def test_guidance_plugin_is_called_like_the_reference_system_calls_it():
         bare.prepare_for_sds("p", "n", "")                      # nothing to make the image tokens from: loud failure
     with pytest.raises(KeyError):
         StableDiffusionGuidance({"no_such_key": 1}, device="cpu", unet=_TinyUNet(), controlnet=_TinyControlNet(), vae=_TinyVAE())
+
+
+def test_stage_three_densify_schedule_matches_reference_quirks(tmp_path):
+    """GaussianIP.on_before_optimizer_step, stage 3 branch (GaussianIP.py:476-506): max_radii2D adopted at step 0,
+    statistics every step, ONE densify_and_prune at global step 2500 (stage step 100) with the screen-size limit off
+    (the test at :491 uses the stage's own step) and min opacity 0.05, a second accumulation per step in the
+    2500 < global < 3000 window, and a prune_only that never fires because of the operator precedence at :504.
+    Also the hand-off files before_refine.pth / after_refine.pth (GaussianIP.py:404, refine.py:307-315, GaussianIP.py:359)."""
+    from gaussianip_amd import system as S
+
+    class FakeGaussian:
+        def __init__(self, n):
+            self.max_radii2D = torch.zeros(n)
+            self.calls, self.stats, self.lr_steps = [], 0, []
+            self.get_xyz = torch.zeros(n, 3)
+
+        def add_densification_stats(self, grad, vis):
+            assert grad.shape == (self.max_radii2D.shape[0], 3)
+            self.stats += 1
+
+        def densify_and_prune(self, *a):
+            self.calls.append(("densify_and_prune",) + a)
+
+        def prune_only(self, **k):
+            self.calls.append(("prune_only", k))
+
+        def update_learning_rate(self, it):
+            self.lr_steps.append(it)
+
+    n = 7
+    g = FakeGaussian(n)
+    st = S.StageThreeStep(g, None, None, [], refined_rgbs_small=torch.zeros(4, 3, 8, 8), cfg=S.StageOneConfig())
+    st.refine_radii = torch.arange(n, dtype=torch.int32)
+    st.refine_visibility_filter = st.refine_radii > 2
+    st.viewspace_points = type("VS", (), {"grad": torch.ones(4, n, 3)})()
+    actions = {}
+    for step in range(0, 700):
+        before = g.stats
+        a = st.on_before_optimizer_step(step)
+        if a:
+            actions[step] = a
+        per_step = g.stats - before
+        assert per_step == (2 if 100 < step < 600 else 1), (step, per_step)
+        if step == 0:
+            assert torch.equal(g.max_radii2D, st.refine_radii.float())
+    assert actions == {100: "densify_and_prune"}
+    assert g.calls == [("densify_and_prune", 0.0002, 0.05, 4.0, None, 0.015)]            # no prune_only: `a + b % c == 0`
+    # hand-off files
+    imgs, ctrl = torch.rand(32, 6, 5, 3), torch.rand(32, 6, 5, 3)
+    S.save_before_refine(str(tmp_path / "before_refine.pth"), imgs, ctrl)
+    i2, c2 = S.load_before_refine(str(tmp_path / "before_refine.pth"))
+    assert torch.equal(i2, imgs) and torch.equal(c2, ctrl)
+    from gaussianip_amd.guidance.refine import VIEW_IDX_ALL
+    refined = torch.rand(32, 1024, 1024, 3)
+    S.save_after_refine(str(tmp_path / "after_refine.pth"), refined, VIEW_IDX_ALL)
+    small = S.load_after_refine(str(tmp_path / "after_refine.pth"))
+    assert small.shape == (32, 3, 415, 290)                                             # [60:890, 220:800] at half resolution
+    idx_mapper = [3, 20, 21, 22, 6, 23, 24, 25, 1, 26, 27, 28, 7, 29, 30, 31, 2, 8, 9, 10, 4, 11, 12, 13, 0, 14, 15, 16, 5, 17, 18, 19]
+    want = torch.nn.functional.interpolate(refined[idx_mapper].permute(0, 3, 1, 2)[:, :, 60:890, 220:800], scale_factor=0.5,
+                                           mode="bilinear", align_corners=False)     # refine.py:307-311 verbatim
+    assert torch.equal(small, want)

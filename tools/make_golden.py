@@ -547,6 +547,51 @@ def ops():
     print("ops fixtures written")
 
 
+def ply():
+    """The vertex table GaussianModel.save_ply hands to plyfile (gaussian_model.py:190-216): attribute names in order
+    and the float32 rows, captured at the PlyElement.describe boundary (plyfile itself is an absent third-party package:
+    it then writes "ply / format binary_little_endian 1.0 / element vertex N / property float <name> ... / end_header"
+    followed by the rows — its published format)."""
+    _install_device_shim()
+    _install_stub_modules()
+    captured = {}
+
+    class PlyElement:
+        @staticmethod
+        def describe(elements, name):
+            captured["elements"], captured["name"] = elements, name
+            return elements
+
+    class PlyData:
+        def __init__(self, els):
+            pass
+
+        def write(self, path):
+            captured["path"] = path
+    sys.modules["plyfile"].PlyElement, sys.modules["plyfile"].PlyData = PlyElement, PlyData
+    import gaussiansplatting.scene.gaussian_model as gmod
+    gmod.PlyElement, gmod.PlyData = PlyElement, PlyData
+    gmod.mkdir_p = lambda p: None
+    from gaussiansplatting.utils.graphics_utils import BasicPointCloud
+    out = {}
+    for deg in (0, 2):
+        rng = np.random.default_rng(9 + deg)
+        gm = gmod.GaussianModel(deg)
+        n = 40
+        gm.create_from_pcd(BasicPointCloud(rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32), rng.uniform(0, 1, (n, 3)).astype(np.float32), None), 4.0)
+        with torch.no_grad():
+            gm._features_rest += torch.from_numpy(rng.standard_normal(tuple(gm._features_rest.shape)).astype(np.float32))
+            gm._rotation += torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32)) * 0.2
+        gm.save_ply("/tmp/unused.ply")
+        el = captured["elements"]
+        out["names_deg%d" % deg] = np.array(el.dtype.names)
+        out["table_deg%d" % deg] = np.stack([el[k] for k in el.dtype.names], axis=1).astype(np.float32)
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            out["deg%d%s" % (deg, k)] = getattr(gm, k).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "ply_layout.npz"), element_name=captured["name"], **out)
+    print("ply layout written:", list(out["names_deg0"]))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ahds":
         ahds()
@@ -556,5 +601,7 @@ if __name__ == "__main__":
         backward()
     elif len(sys.argv) > 1 and sys.argv[1] == "ops":
         ops()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ply":
+        ply()
     else:
         main()
