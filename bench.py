@@ -166,16 +166,32 @@ def main():
         dom = max(kernel_stages, key=lambda s: stages[s])
         dom_bytes = stage_bytes(dom, P, K, Rv, T, N) * V
         achieved = dom_bytes / (stages[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # HBM traffic and vector-issue counters come from committed rocprofv3 --pmc passes of THIS build (separate passes,
+        # tools/collect_profiles.sh; FETCH_SIZE doubled and KiB units per the MI355X guide): they cannot be collected
+        # inside this run, so the line names its source
+        traffic, valu = None, None
+        ppath = os.path.join(ROOT, "profiles", "pmc.json")
+        if os.path.exists(ppath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                pmc = json.load(open(ppath))
+                c = pmc.get(dom, {})
+                traffic = int(c["hbm_fetch_bytes"] + c["hbm_write_bytes"])
+                # vector-issue roofline of the same kernel: one SIMD retires one wave64 vector instruction per
+                # 4 cycles (SQ_ACTIVE_INST_VALU counts those issue quad-cycles), the chip has 256 CUs x 4 SIMDs,
+                # the launch lasted GRBM_GUI_ACTIVE / 8 XCD cycles.  frac = busy SIMD-cycles / available SIMD-cycles.
+                cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+                valu = {"bound": "valu-issue", "kernel": "gip_%s_kernel" % dom, "wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
+                        "cycles_per_wave_instruction": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 2),
+                        "busy_simd_cycles": int(4.0 * c["SQ_ACTIVE_INST_VALU"]), "available_simd_cycles": int(cycles * 1024),
+                        "frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * 1024), 4),
+                        "launch_cycles": int(cycles), "source": "profiles/pmc.json (rocprofv3 --pmc, this build)",
+                        "formula": "4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         roofline = {"bound": "hbm", "kernel": "gip_%s_kernel" % dom, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": int(dom_bytes),
+                    "traffic": traffic, "traffic_source": "profiles/pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build)",
+                    "algorithmic_bytes_per_launch": int(dom_bytes),
                     "avg_launch_ms": round(stages[dom], 4),
                     "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                     "whole_step_GBs": round((b_f + b_b) * V / (ms_per_step * 1e-3) / 1e9, 2),
@@ -196,13 +212,19 @@ def main():
                       opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
             gc_h, gd_h = gC[0].cpu().numpy(), gD[0].cpu().numpy()
             ro.forward(**kw)  # warm-up (page-in)
-            reps, tt = 0, 0.0
-            while reps < 1 or (tt < 10.0 and reps < 20):
+            ro.backward(gc_h, gd_h, None)
+            t_fwd, t_both = [], []
+            for _ in range(5):                                   # median of 5 after one warm-up
                 c1 = time.perf_counter()
                 ro.forward(**kw)
+                c2 = time.perf_counter()
                 ro.backward(gc_h, gd_h, None)
-                tt += time.perf_counter() - c1
-                reps += 1
+                c3 = time.perf_counter()
+                t_fwd.append(c2 - c1)
+                t_both.append(c3 - c1)
+            t_fwd.sort()
+            t_both.sort()
+            reps, tt = 1, t_both[2]
             model = ""
             try:
                 with open("/proc/cpuinfo") as f:
@@ -210,7 +232,9 @@ def main():
             except OSError:
                 pass
             cpu = {"value": round(reps * H * W / tt / 1e6, 3), "unit": "Mpix/s", "cores": ncores, "cpu_model": model, "kind": "port",
-                   "sample": "%d x (1 view fwd+bwd, P=%d, %dx%d) on the C oracle, OpenMP over tiles" % (reps, P, H, W)}
+                   "forward_only_value": round(H * W / t_fwd[2] / 1e6, 3),
+                   "sample": "median of 5 x (1 view forward, then backward; P=%d, %dx%d) after one warm-up, on the C oracle "
+                             "(oracle/raster_oracle.c, OpenMP over tiles, %d threads); value = forward+backward" % (P, H, W, ncores)}
 
         out = {"metric": "raster_fwd_bwd_mpix_per_s", "value": round(mpix_s, 2), "unit": "Mpix/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -221,7 +245,7 @@ def main():
                           "num_rendered_per_view": int(Rv), "sh_degree": 0,
                           "parallelism": "view-sharded dp%d" % world},
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "roofline_valu": valu, "cpu_baseline": cpu}
     if rank == 0:
         out["ahds"] = ahds
         print(json.dumps(out), flush=True)

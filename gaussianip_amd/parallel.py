@@ -201,3 +201,78 @@ def shard_views(n_views: int, rank: int, world_size: int):
     if world_size <= n_views:
         return list(range(rank, n_views, world_size))
     return [rank % n_views]
+
+
+class _GroupMax(torch.autograd.Function):
+    """max over the ranks of a group of a 0-d tensor, differentiable like torch.max over the concatenated data: the
+    gradient of everything that used the maximum (on EVERY rank) flows to the rank that holds it."""
+
+    @staticmethod
+    def forward(ctx, local_max, group):
+        gmax = local_max.detach().clone()
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+        ctx.group = group
+        ctx.save_for_backward(local_max.detach() == gmax)
+        return gmax
+
+    @staticmethod
+    def backward(ctx, g):
+        (holds,) = ctx.saved_tensors
+        total = g.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
+        return total * holds.to(total.dtype), None
+
+
+class ViewSharding:
+    """BASELINE.json configs[3]: the 4 views of an optimizer step sharded over the ranks of one SEED GROUP, whole groups
+    replicated for independent seeds (2 GPUs = 2 views each, 4 GPUs = 1 view each, 8 GPUs = 4 views x 2
+    seeds; launch.py:80 offsets the seed by the rank).  Ranks [g * size, (g + 1) * size) form seed group g and exchange
+    only among themselves (their own process group; different seed groups never communicate in the step).
+
+    Equivalence with the single-process step (tests/test_gpu_sharded_step.py): every rank computes its SHARE of the global
+    loss — the loss of its local views times len(views) / n_views, since the reference's loss is a mean over the batch
+    (loss_sds / batch_size, ipa_guidance.py:653; the opacity term's .mean(), GaussianIP.py:387) — so that
+      * parameter gradients       = SUM over the group  (== average of the unscaled local gradients for equal shards)
+      * view-space gradient sum   = SUM over the group of the local sums (GaussianIP.py:451-454)
+      * radii                     = MAX over the group   (:165-168, :456)
+      * depth normaliser          = MAX over the group   (:225)
+    densify / prune then runs on every rank from identical statistics with an identically seeded generator."""
+
+    def __init__(self, n_views: int = 4, rank: Optional[int] = None, world: Optional[int] = None, make_groups: bool = True):
+        on = dist.is_available() and dist.is_initialized()
+        self.world = world if world is not None else (dist.get_world_size() if on else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if on else 0)
+        self.n_views = n_views
+        self.group_size = min(self.world, n_views)
+        self.n_seed_groups = max(1, self.world // self.group_size)
+        self.seed_id = self.rank // self.group_size
+        self.local_rank = self.rank % self.group_size
+        self.views = shard_views(n_views, self.local_rank, self.group_size)
+        self.share = len(self.views) / float(n_views)
+        self.group = None
+        if on and make_groups and self.n_seed_groups > 1:
+            for g in range(self.n_seed_groups):          # every rank creates every group (torch.distributed contract)
+                ranks = list(range(g * self.group_size, (g + 1) * self.group_size))
+                grp = dist.new_group(ranks)
+                if g == self.seed_id:
+                    self.group = grp
+
+    @property
+    def active(self):
+        return self.group_size > 1 and dist.is_available() and dist.is_initialized()
+
+    def depth_max(self, x: torch.Tensor) -> torch.Tensor:
+        """Group-wide maximum of the local depth maximum (GaussianIP.py:225), with the reference's gradient: every
+        rank's opacity depends on it, and all of that gradient reaches the pixel that holds the maximum."""
+        return _GroupMax.apply(x, self.group) if self.active else x
+
+    def exchange(self, stage) -> None:
+        """Hook for system.StageOneStep.optimizer_step(exchange=...): call after backward.  The local loss must already be
+        the rank's share (StageOneStep does that when `sharding` is set)."""
+        vs = stage.viewspace_points.grad.sum(dim=0)
+        if self.active:
+            params = [g["params"][0] for g in stage.gaussian.optimizer.param_groups]
+            exchange_max(stage.radii, None, self.group)
+            exchange_sum(params, vs, self.group, average=False)
+        stage.viewspace_grad_sum = vs
+        stage.visibility_filter = stage.radii > 0

@@ -83,6 +83,7 @@ class StageOneStep:
         self.viewspace_points = None
         self.viewspace_grad_sum = None      # [P,3], set by a multi-GPU exchange hook (sum over ALL ranks' views)
         self.depth_max_reduce = None        # callable(0-d tensor) -> all-reduced maximum, set for view-sharded runs
+        self.sharding = None                # parallel.ViewSharding: this rank renders batch views sharding.views only
         self.radii = None
         self.visibility_filter = None
 
@@ -90,8 +91,9 @@ class StageOneStep:
     def forward(self, batch: Dict, renderbackground=None) -> Dict:
         bg = self.background if renderbackground is None else renderbackground
         B = batch["c2w"].shape[0]
+        ids = list(range(B)) if self.sharding is None else list(self.sharding.views)
         cams: List[Camera] = [Camera(c2w=batch["c2w"][i], FoVy=batch["fovy"][i], height=batch["height"], width=batch["width"])
-                              for i in range(B)]
+                              for i in ids]
         pkg = render_views(cams, self.gaussian, self.pipe, bg)
         self.viewspace_points = pkg["viewspace_points"]              # [B,P,3]; .grad after backward
         self.viewspace_grad_sum = None
@@ -103,18 +105,20 @@ class StageOneStep:
         images = pkg["render"].permute(0, 2, 3, 1)                   # [B,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)               # [B,H,W,1]
         dmax = depths.max()                                          # batch-global maximum (:225)
-        if self.depth_max_reduce is not None:
-            # view-sharded ranks: the maximum over ALL ranks' views; its gradient flows on the rank that holds it
+        if self.sharding is not None and self.sharding.active:
+            dmax = self.sharding.depth_max(dmax)                     # over all ranks' views, differentiable
+        elif self.depth_max_reduce is not None:
+            # replicated batches: the maximum over ALL ranks' views; its gradient flows on the rank that holds it
             gmax = self.depth_max_reduce(dmax.detach().clone())
             dmax = torch.where(dmax.detach() == gmax, dmax, gmax)
         out = {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (dmax + 1e-5),
                "scale": self.gaussian.get_scaling}
         if self.skeleton is not None and "mvp_mtx" in batch:
             dev = images.device
-            az = torch.as_tensor(batch["azimuth"]).to(dev, non_blocking=True)
-            cent = torch.as_tensor(batch["center"]).to(dev, non_blocking=True)
+            az = torch.as_tensor(batch["azimuth"])[ids].to(dev, non_blocking=True)
+            cent = torch.as_tensor(batch["center"])[ids].to(dev, non_blocking=True)
             head_zoom = (cent == self.head_offset) & (az > 0)        # :176
-            pose, all_vis, _ = self.skeleton.openpose_draw(batch["mvp_mtx"], self.pose_hw[0], self.pose_hw[1], az, head_zoom, True)
+            pose, all_vis, _ = self.skeleton.openpose_draw(batch["mvp_mtx"][ids], self.pose_hw[0], self.pose_hw[1], az, head_zoom, True)
             out["pose"], out["all_vis_all"] = pose, all_vis
         return out
 
@@ -123,9 +127,16 @@ class StageOneStep:
         """update_learning_rate -> forward (render + pose maps) -> guidance(...) -> loss.  `prompt_utils` = prompt_processor()."""
         self.gaussian.update_learning_rate(step)
         out = self.forward(batch)
-        guidance_out = guidance(step, out["comp_rgb"], out["pose"], prompt_utils, use_pose_controlnet, out["all_vis_all"],
-                                **{k: v for k, v in batch.items() if k not in ("height", "width")})
-        return self.loss(out, guidance_out), out, guidance_out
+        per_view = {k: v for k, v in batch.items() if k not in ("height", "width")}
+        if self.sharding is not None:       # this rank's views only; the loss below is its share of the batch mean
+            ids = list(self.sharding.views)
+            per_view = {k: (v[ids] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == batch["c2w"].shape[0] else v)
+                        for k, v in per_view.items()}
+        guidance_out = guidance(step, out["comp_rgb"], out["pose"], prompt_utils, use_pose_controlnet, out["all_vis_all"], **per_view)
+        loss = self.loss(out, guidance_out)
+        if self.sharding is not None:
+            loss = loss * self.sharding.share
+        return loss, out, guidance_out
 
     def optimizer_step(self, loss, step: int, scaler=None, exchange=None) -> Optional[str]:
         """backward -> (unscale) -> on_before_optimizer_step -> optimizer.step, in Lightning's order.
