@@ -142,6 +142,47 @@ def main():
     views_total = world * V * args.steps
     mpix_s = views_total * H * W / elapsed / 1e6
 
+    # ---- BASELINE.json configs[3] layout of the same raster step (N > 1): the 4 views of ONE optimizer step sharded over
+    # the ranks of a seed group (8 GPUs: 2 seed groups with their own process groups), gradients SUM-reduced inside it
+    config3 = None
+    if world > 1:
+        shard = parallel.ViewSharding(V)
+        cams3 = scenes.train_cameras(V, seed=42 + shard.seed_id, H=H, W=W)        # one camera set per seed group
+        sts3 = [GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+            viewmatrix=torch.from_numpy(c["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(c["projmatrix"]).to(dev),
+            sh_degree=0, campos=torch.from_numpy(c["campos"]).to(dev), prefiltered=False, debug=False)
+            for i, c in enumerate(cams3) if i in shard.views]
+        Vl = len(sts3)
+
+        def step3():
+            m2d = torch.zeros((Vl, P, 3), device=dev, requires_grad=True)
+            color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], sts3, shs=t["shs"],
+                                                         scales=t["scales"], rotations=t["rotations"])
+            pending = parallel.exchange_forward_stats(radii, depth, group=shard.group)
+            grads = torch.autograd.grad([color, depth], plist + [m2d], [gC[:Vl], gD[:Vl]])
+            for p_, g_ in zip(plist, grads[:-1]):
+                p_.grad = g_
+            vs = grads[-1].sum(0)
+            parallel.exchange_sum(plist, vs, group=shard.group)
+            pending.wait()
+
+        for _ in range(args.warmup):
+            step3()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step3()
+        dist.barrier()
+        torch.cuda.synchronize()
+        et = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        dt3 = float(et.item()) / args.steps
+        config3 = {"layout": "4 views sharded over %d GPU(s) x %d seed group(s)" % (shard.group_size, shard.n_seed_groups),
+                   "ms_per_step": round(dt3 * 1e3, 4), "optimizer_steps_per_s": round(shard.n_seed_groups / dt3, 2),
+                   "views_per_s": round(shard.n_seed_groups * V / dt3, 2), "scaling": "strong within a seed group"}
+
     # ---- metric (i) of BASELINE.json: full AHDS training steps/s (configs[2]; at N>1 configs[3]'s view sharding) ----
     ahds = None
     if not args.no_ahds:
@@ -245,6 +286,7 @@ def main():
                           "num_rendered_per_view": int(Rv), "sh_degree": 0,
                           "parallelism": "view-sharded dp%d" % world},
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
+               "config3_layout": config3,
                "roofline": roofline, "roofline_valu": valu, "cpu_baseline": cpu}
     if rank == 0:
         out["ahds"] = ahds

@@ -19,15 +19,18 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None, amp=True,
-            fused_adam=True):
+            fused_adam=True, layout="views"):
     """Runs the step `warmup + steps` times and returns the result dict.  The timed step is the reference's
     training_step + optimizer step as the system runs them (system.StageOneStep.training_step / optimizer_step):
     learning-rate update, render of the 4 cameras, OpenPose pose maps drawn on the GPU from the batch's mvp matrices,
     view-dependent prompt lookup, guidance call, loss assembly, backward, densification statistics, Adam — with a
     GradScaler when `amp` (the reference trains with `precision: 16-mixed`, configs/exp.yaml:193; its scaler.step() is
     the one host synchronisation of the step, as in the reference).
-    With world > 1 (process group initialised by the caller) every rank trains on its own 4 cameras of the replicated
-    Gaussians and the per-step exchange (gradients, densification statistics, depth maximum) runs inside the timed step."""
+    With world > 1 (process group initialised by the caller) and layout "views" — BASELINE.json configs[3] — the 4 views
+    of an optimizer step are sharded over the ranks of a seed group (2 GPUs: 2 views each; 4: 1 view each; 8: two
+    independent seed groups of 4, each with its own process group: parallel.ViewSharding), the guidance runs on the local
+    views (batch 3 x local views) and the per-step exchange runs inside the timed step.  Layout "replicas": every rank
+    trains on its own 4 cameras (a 4 x world batch) with averaged gradients."""
     import numpy as np
     import torch
     import scenes
@@ -43,7 +46,10 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     dev = torch.device("cuda") if device is None else device
     torch.manual_seed(42)
     rng = np.random.default_rng(42)
-    cam_rng = np.random.default_rng(42 + rank)     # replicated Gaussians, rank-specific cameras
+    shard = parallel.ViewSharding(4) if (world > 1 and layout == "views") else None
+    # views layout: every rank of a seed group draws the SAME 4 cameras (seed offset per seed group, launch.py:80) and
+    # renders its share; replicas layout: rank-specific cameras
+    cam_rng = np.random.default_rng(42 + (shard.seed_id if shard is not None else rank))
     P, H, W, B = gaussians, 1024, 1024, 4
     gm = GaussianModel(0)
     pts = scenes.human_points(P, rng).astype(np.float32)
@@ -65,7 +71,9 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     prompt_utils = pp()
     setup_s = time.time() - t0
     scaler = torch.amp.GradScaler("cuda") if amp else None
-    if world > 1:
+    if shard is not None:
+        stage.sharding = shard
+    elif world > 1:
         def all_max(x):
             torch.distributed.all_reduce(x, op=torch.distributed.ReduceOp.MAX)
             return x
@@ -83,7 +91,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     def step(i):
         batch = scenes.train_batch(cam_rng, B, H, W, device=dev)
         loss, out, gout = stage.training_step(i, batch, guidance, prompt_utils, True)
-        stage.optimizer_step(loss, i, scaler=scaler, exchange=exchange if world > 1 else None)
+        stage.optimizer_step(loss, i, scaler=scaler, exchange=(shard.exchange if shard is not None else exchange) if world > 1 else None)
         return loss
 
     for i in range(warmup):
@@ -134,8 +142,15 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
             guidance.forward_unet(torch.cat([lat] * 3), torch.cat([ctrl] * 3), torch.cat([tt] * 3), emb, True)
         nflops = fc.get_total_flops()
     flops = nflops
-    out = {"metric": "ahds_train_steps_per_s", "value": round(1.0 / dt, 3), "unit": "optimizer steps/s", "ms_per_step": round(dt * 1e3, 2),
-           "views_per_s": round(world * B / dt, 2), "views_per_optimizer_step": world * B, "n_gpus": world, "amp_gradscaler": bool(amp), "fused_adam": bool(fused_adam),
+    if shard is not None:
+        views_per_step, opt_steps = B, shard.n_seed_groups          # every seed group takes one optimizer step per dt
+        lay = "configs[3]: 4 views sharded over %d GPU(s) x %d independent seed group(s)" % (shard.group_size, shard.n_seed_groups)
+    else:
+        views_per_step, opt_steps = world * B, 1
+        lay = "single GPU" if world == 1 else "replicas: %d ranks x 4 cameras, one averaged optimizer step" % world
+    out = {"metric": "ahds_train_steps_per_s", "value": round(opt_steps / dt, 3), "unit": "optimizer steps/s", "ms_per_step": round(dt * 1e3, 2),
+           "views_per_s": round(opt_steps * views_per_step / dt, 2), "views_per_optimizer_step": views_per_step, "n_gpus": world,
+           "layout": lay, "amp_gradscaler": bool(amp), "fused_adam": bool(fused_adam),
            "timed_step": "lr update + render 4 views + GPU pose maps + prompt lookup + VAE/ControlNet/U-Net ANPG + loss + backward + densification stats + Adam", "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
            "denoise_ms": round(den_ms, 2), "vae_enc_fwd_bwd_ms": round(vae_ms, 2), "setup_s": round(setup_s, 1),
            "denoise_flops": flops, "denoise_tflops_per_s": None if not flops else round(flops / (den_ms * 1e-3) / 1e12, 1),
