@@ -72,10 +72,17 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   if (end < start) end = start;
   const GipRecord* recs = records + (size_t)v * kp.P;
 
-  __shared__ float2 s_xy[FWD_THREADS];
-  __shared__ float4 s_con[FWD_THREADS];   // conic a,b,c (exp2 domain) + opacity
-  __shared__ float4 s_col[FWD_THREADS];   // r,g,b + depth
+  // entry FWD_THREADS of the staged arrays is a NULL entry (opacity 0 => alpha 0 => skipped by the alpha >= 1/255 test):
+  // a pair whose second (or first) entry does not exist reads it instead of carrying per-lane "have" flags
+  __shared__ float2 s_xy[FWD_THREADS + 1];
+  __shared__ float4 s_con[FWD_THREADS + 1];   // conic a,b,c (exp2 domain) + opacity
+  __shared__ float4 s_col[FWD_THREADS + 1];   // r,g,b + depth
   __shared__ uint32_t s_mask[FWD_THREADS];
+  if (threadIdx.x == 0) {
+    s_xy[FWD_THREADS] = make_float2(0.f, 0.f);
+    s_con[FWD_THREADS] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_col[FWD_THREADS] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   bool done = !inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, Dp = 0.f;   // C, W, D: this lane half's share of the sums
@@ -153,21 +160,18 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
           float4 cc[FWD_PAIRS];
 #pragma unroll
           for (int u = 0; u < FWD_PAIRS; u++) {
-            const int j1 = m ? __builtin_ctzll(m) : 0;
-            const bool have1 = m != 0;
+            const int j1 = m ? c0 + __builtin_ctzll(m) : FWD_THREADS;
             m &= m - 1;                                   // (0 & anything) stays 0
-            const int j2 = m ? __builtin_ctzll(m) : j1;
-            const bool have2 = m != 0;
+            const int j2 = m ? c0 + __builtin_ctzll(m) : FWD_THREADS;
             m &= m - 1;
-            jj[u] = c0 + (hh ? j2 : j1);
-            const bool have = hh ? have2 : have1;
+            jj[u] = hh ? j2 : j1;
             const float2 xy = s_xy[jj[u]];
             const float4 co = s_con[jj[u]];
             cc[u] = s_col[jj[u]];
             const float dx = xy.x - pxf, dy = xy.y - pyf;
             const float power = __builtin_fmaf(dx, __builtin_fmaf(co.x, dx, co.y * dy), (co.z * dy) * dy);   // log2 domain
             const float a = fminf(GIP_ALPHA_MAX, co.w * __builtin_amdgcn_exp2f(power));
-            al[u] = (have && power <= 0.0f && a >= GIP_ALPHA_MIN) ? a : 0.f;      // 0 = the reference skips this pair
+            al[u] = (power <= 0.0f && a >= GIP_ALPHA_MIN) ? a : 0.f;              // 0 = the reference skips this pair
           }
           bool any_stop = false;
 #pragma unroll
@@ -183,8 +187,8 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
             a_o = (done || stop1) ? 0.f : a_o;
             const float t2 = T1 * (1.f - a_o);
             const bool stop2 = t2 < GIP_T_MIN;
-            float w = hh ? a_o * T1 : a_e * T;
-            w = (hh ? stop2 : stop1) ? 0.f : w;
+            const float w_e = stop1 ? 0.f : a_e * T, w_o = stop2 ? 0.f : a_o * T1;
+            const float w = hh ? w_o : w_e;
             C0 += cc[u].x * w; C1 += cc[u].y * w; C2 += cc[u].z * w; Wt += w; Dp += cc[u].w * w;
             last_contributor = w > 0.f ? (base - start) + jj[u] + 1 : last_contributor;
             T = stop2 ? T1 : t2;
