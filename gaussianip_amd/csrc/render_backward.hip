@@ -70,7 +70,8 @@ struct BwdAcc { float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9; };
 __device__ __forceinline__ bool bwd_pair(BwdPix& p, BwdAcc& a, float pxf, float pyf, const float2 xy, const float4 co,
                                          const float4 cl, uint32_t i) {
   const float dx = xy.x - pxf, dy = xy.y - pyf;
-  const float power = __builtin_fmaf(dx, __builtin_fmaf(co.x, dx, co.y * dy), (co.z * dy) * dy);   // conic pre-scaled: log2 domain
+  // conic pre-scaled: log2 domain; the forward's operation sequence (render_forward.hip): a dx and c dy first
+  const float power = __builtin_fmaf(dx, __builtin_fmaf(co.y, dy, co.x * dx), (co.z * dy) * dy);
   const float G = __builtin_amdgcn_exp2f(power);
   const float alpha = fminf(GIP_ALPHA_MAX, co.w * G);
   const bool c = i < p.lastc && power <= 0.0f && alpha >= GIP_ALPHA_MIN;

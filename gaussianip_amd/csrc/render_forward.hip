@@ -31,6 +31,8 @@
 #define FWD_PAIRS 4
 #endif
 #define FWD_THREADS 512
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // value held by lane ^ 32 (v_permlane32_swap: a <- [a_lo | b_lo], b <- [a_hi | b_hi]; inline asm, see render_backward.hip)
 __device__ __forceinline__ float xchg32(float x, int hh) {
@@ -61,7 +63,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   const int lx = ((wave & 1) << 3) | (pl & 7), ly = ((wave >> 1) << 2) | (pl >> 3);
   const int px = tx * GIP_TILE + lx, py = ty * GIP_TILE + ly;
   const bool inside = px < kp.W && py < kp.H;
-  const float pxf = (float)px, pyf = (float)py;
+  const v2f pxy = {(float)px, (float)py};
   const float tile_x0 = (float)(tx * GIP_TILE), tile_y0 = (float)(ty * GIP_TILE);
   // slot of this pixel in the checkpoint rows: the backward's layout (8x8 quadrant * 64 + row * 8 + column)
   const int cpix = ((((ly >> 3) << 1) | (lx >> 3)) << 6) | ((ly & 7) << 3) | (lx & 7);
@@ -74,18 +76,22 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
 
   // entry FWD_THREADS of the staged arrays is a NULL entry (opacity 0 => alpha 0 => skipped by the alpha >= 1/255 test):
   // a pair whose second (or first) entry does not exist reads it instead of carrying per-lane "have" flags
-  __shared__ float2 s_xy[FWD_THREADS + 1];
-  __shared__ float4 s_con[FWD_THREADS + 1];   // conic a,b,c (exp2 domain) + opacity
-  __shared__ float4 s_col[FWD_THREADS + 1];   // r,g,b + depth
+  // Field order chosen for PACKED fp32 math inside one (pixel, entry) evaluation — a gfx950 SIMD retires v_pk_mul /
+  // v_pk_add / v_pk_fma (two fp32 per lane) at the rate of one scalar fp32 instruction: (x, y) - (px, py) is one
+  // v_pk_add, (a dx, c dy) one v_pk_mul on the adjacent (a, c) pair, the colour / depth sums two v_pk_fma on (r, g), (b, d)
+  __shared__ v2f s_xy[FWD_THREADS + 1];
+  __shared__ v4f s_con[FWD_THREADS + 1];   // conic a, c, b (exp2 domain) + opacity
+  __shared__ v4f s_col[FWD_THREADS + 1];   // r, g, b + depth
   __shared__ uint32_t s_mask[FWD_THREADS];
   if (threadIdx.x == 0) {
-    s_xy[FWD_THREADS] = make_float2(0.f, 0.f);
-    s_con[FWD_THREADS] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_col[FWD_THREADS] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_xy[FWD_THREADS] = (v2f){0.f, 0.f};
+    s_con[FWD_THREADS] = (v4f){0.f, 0.f, 0.f, 0.f};
+    s_col[FWD_THREADS] = (v4f){0.f, 0.f, 0.f, 0.f};
   }
 
   bool done = !inside;
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, Dp = 0.f;   // C, W, D: this lane half's share of the sums
+  float T = 1.0f, Wt = 0.f;
+  v2f CG = {0.f, 0.f}, BD = {0.f, 0.f};   // (red, green), (blue, depth): this lane half's share of the sums
   uint32_t last_contributor = 0;
 
   // software pipeline over the batches: the key of batch b+2 and the record of batch b+1 are in flight
@@ -104,10 +110,10 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     const uint32_t k = base + threadIdx.x;
     if (k < end) {
       const float4 q0 = r0, q1 = r1, q2 = r2;
-      s_xy[threadIdx.x] = make_float2(q0.x, q0.y);
+      s_xy[threadIdx.x] = (v2f){q0.x, q0.y};
       // conic pre-scaled into the exp2 domain: power * log2(e) = A dx^2 + B dx dy + C dy^2 (sign tests are unchanged)
-      s_con[threadIdx.x] = make_float4(q1.x * -0.72134752044448170f, q1.y * -1.4426950408889634f, q1.z * -0.72134752044448170f, q0.w);
-      s_col[threadIdx.x] = make_float4(q2.x, q2.y, q2.z, q0.z);
+      s_con[threadIdx.x] = (v4f){q1.x * -0.72134752044448170f, q1.z * -0.72134752044448170f, q1.y * -1.4426950408889634f, q0.w};
+      s_col[threadIdx.x] = (v4f){q2.x, q2.y, q2.z, q0.z};
       // extent of { power >= -ln(255 o) }  (conservative: +1% / +0.05 px)
       uint32_t mask = 0xff;
       const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
@@ -142,7 +148,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
         if (rel != 0 && (rel % GIP_SEGMENT) == 0) {
           // blend state at the start of segment rel / GIP_SEGMENT (>= 1): lets the backward treat every segment of
           // this tile as an independent work item (render_backward.hip).  The two lane halves hold partial sums.
-          const float s0 = C0 + xchg32(C0, hh), s1 = C1 + xchg32(C1, hh), s2 = C2 + xchg32(C2, hh), sd = Dp + xchg32(Dp, hh);
+          const float s0 = CG.x + xchg32(CG.x, hh), s1 = CG.y + xchg32(CG.y, hh), s2 = BD.x + xchg32(BD.x, hh), sd = BD.y + xchg32(BD.y, hh);
           const uint32_t slot = ckpt_start[vt] + rel / GIP_SEGMENT - 1;
           if (slot < kp.ckpt_capacity && hh == 0) {
             float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * GIP_BLOCK) + cpix;
@@ -157,7 +163,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
           // FWD_PAIRS pairs of list entries per trip: lanes 0-31 take the first entry of a pair, lanes 32-63 the second
           int jj[FWD_PAIRS];
           float al[FWD_PAIRS];
-          float4 cc[FWD_PAIRS];
+          v4f cc[FWD_PAIRS];
 #pragma unroll
           for (int u = 0; u < FWD_PAIRS; u++) {
             const int j1 = m ? c0 + __builtin_ctzll(m) : FWD_THREADS;
@@ -165,11 +171,12 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
             const int j2 = m ? c0 + __builtin_ctzll(m) : FWD_THREADS;
             m &= m - 1;
             jj[u] = hh ? j2 : j1;
-            const float2 xy = s_xy[jj[u]];
-            const float4 co = s_con[jj[u]];
+            const v2f d = s_xy[jj[u]] - pxy;                               // (dx, dy)
+            const v4f co = s_con[jj[u]];
             cc[u] = s_col[jj[u]];
-            const float dx = xy.x - pxf, dy = xy.y - pyf;
-            const float power = __builtin_fmaf(dx, __builtin_fmaf(co.x, dx, co.y * dy), (co.z * dy) * dy);   // log2 domain
+            const v2f t = co.xy * d;                                       // (a dx, c dy)
+            // log2 domain; same operation sequence as the backward's re-evaluation (render_backward.hip: bwd_pair)
+            const float power = __builtin_fmaf(d.x, __builtin_fmaf(co.z, d.y, t.x), t.y * d.y);
             const float a = fminf(GIP_ALPHA_MAX, co.w * __builtin_amdgcn_exp2f(power));
             al[u] = (power <= 0.0f && a >= GIP_ALPHA_MIN) ? a : 0.f;              // 0 = the reference skips this pair
           }
@@ -189,7 +196,9 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
             const bool stop2 = t2 < GIP_T_MIN;
             const float w_e = stop1 ? 0.f : a_e * T, w_o = stop2 ? 0.f : a_o * T1;
             const float w = hh ? w_o : w_e;
-            C0 += cc[u].x * w; C1 += cc[u].y * w; C2 += cc[u].z * w; Wt += w; Dp += cc[u].w * w;
+            CG = __builtin_elementwise_fma(cc[u].xy, (v2f){w, w}, CG);
+            BD = __builtin_elementwise_fma(cc[u].zw, (v2f){w, w}, BD);
+            Wt += w;
             last_contributor = w > 0.f ? (base - start) + jj[u] + 1 : last_contributor;
             T = stop2 ? T1 : t2;
             done = done || stop1 || stop2;
@@ -205,6 +214,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   }
 
   // the two lane halves hold disjoint shares of the sums and the same T
+  float C0 = CG.x, C1 = CG.y, C2 = BD.x, Dp = BD.y;
   C0 += xchg32(C0, hh); C1 += xchg32(C1, hh); C2 += xchg32(C2, hh); Wt += xchg32(Wt, hh); Dp += xchg32(Dp, hh);
   const uint32_t lc_other = __float_as_uint(xchg32(__uint_as_float(last_contributor), hh));
   last_contributor = max(last_contributor, lc_other);

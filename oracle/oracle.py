@@ -124,11 +124,15 @@ class RasterOracle:
             self.lib.oracle_pixel_margins(self.ctx, _p(ids), ctypes.c_int(ids.shape[0]), _p(out))
         return out
 
-    def knife_edge_gaussians(self, thresh=2e-5):
-        """(bool [P] mask of the Gaussians that are the subject of a knife-edge threshold test, number of such pixels)."""
+    def knife_edge_gaussians(self, thresh=2e-5, downstream=False):
+        """(bool [P] mask of the Gaussians that are the subject of a knife-edge threshold test, number of such pixels);
+        with downstream=True also a [P] mask of the Gaussians blended behind such a subject at some pixel."""
         flags = np.zeros(self.P, np.uint8)
+        down = np.zeros(self.P, np.uint8) if downstream else None
         self.lib.oracle_knife_edge_gaussians.restype = ctypes.c_int
-        n = self.lib.oracle_knife_edge_gaussians(self.ctx, ctypes.c_float(thresh), _p(flags))
+        n = self.lib.oracle_knife_edge_gaussians(self.ctx, ctypes.c_float(thresh), _p(flags), _p(down))
+        if downstream:
+            return flags.astype(bool), int(n), down.astype(bool)
         return flags.astype(bool), int(n)
 
     def geom(self):

@@ -440,7 +440,11 @@ void oracle_pixel_margins(const oracle_ctx* c, const int32_t* pix_ids, int n, fl
  * within `thresh` at its entry): the set of gradient rows that a legitimately different decision changes by one whole
  * pixel contribution.  Entries behind a flipped one see T change by at most 0.4 % at that single pixel (alpha flips)
  * or contribute with T < 1e-4 (termination flips) and are not flagged.  Returns the number of knife-edge pixels. */
-int oracle_knife_edge_gaussians(const oracle_ctx* c, float thresh, uint8_t* flags) {
+int oracle_knife_edge_gaussians(const oracle_ctx* c, float thresh, uint8_t* flags, uint8_t* downstream) {
+  /* downstream[g] (optional) = 1 for every Gaussian that is blended BEHIND a knife-edge subject at some pixel: if the
+   * subject's decision flips, the transmittance of everything behind it at that pixel changes by the factor
+   * (1 - alpha_subject) (0.4 % for an alpha >= 1/255 flip) — a second-order effect that is visible only on gradient
+   * entries that are small sums of cancelling per-view terms. */
   const int H = c->H, W = c->W;
   int count = 0;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : count)
@@ -455,15 +459,22 @@ int oracle_knife_edge_gaussians(const oracle_ctx* c, float thresh, uint8_t* flag
       const float dx = c->means2D[2 * g] - (float)px, dy = c->means2D[2 * g + 1] - (float)py;
       const float* co = c->conic_opacity + 4 * g;
       const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-      if (fabsf(power) < thresh) { flags[g] = 1; hit = 1; } /* benign race: every writer stores 1 */
-      if (power > 0.0f) continue;
-      const float alpha = fminf(0.99f, co[3] * expf(power));
-      if (fabsf(alpha - 1.0f / 255.0f) * 255.0f < thresh) { flags[g] = 1; hit = 1; }
-      if (alpha < 1.0f / 255.0f) continue;
-      const float test_T = T * (1 - alpha);
-      if (fabsf(test_T - 0.0001f) * 10000.0f < thresh) { flags[g] = 1; hit = 1; }
-      if (test_T < 0.0001f) break;
-      T = test_T;
+      int subject = 0;
+      if (fabsf(power) < thresh) subject = 1;
+      if (power <= 0.0f) {
+        const float alpha = fminf(0.99f, co[3] * expf(power));
+        if (fabsf(alpha - 1.0f / 255.0f) * 255.0f < thresh) subject = 1;
+        if (alpha >= 1.0f / 255.0f) {
+          const float test_T = T * (1 - alpha);
+          if (fabsf(test_T - 0.0001f) * 10000.0f < thresh) subject = 1;
+          if (hit && downstream) downstream[g] = 1;
+          if (subject) { flags[g] = 1; hit = 1; } /* benign race: every writer stores 1 */
+          if (test_T < 0.0001f) break;
+          T = test_T;
+          continue;
+        }
+      }
+      if (subject) { flags[g] = 1; hit = 1; }
     }
     count += hit;
   }

@@ -14,7 +14,9 @@ tensor (the six parameter gradients + means2D) within
     Gaussians that walk through a PROVEN knife-edge pixel (a threshold test of the blend within 2e-5 of flipping in
     the oracle: oracle.knife_edge_gaussians) are left out of the element-wise bar only — v_exp_f32 and libm expf may
     decide such a pixel differently, which moves that Gaussian's gradient by one whole pixel contribution; their
-    count is printed and bounded.
+    count is printed and bounded.  Gaussians blended BEHIND such a subject at that pixel see its transmittance change
+    by the factor (1 - alpha) = 0.4 % there; that matters only where a gradient entry is a small sum of cancelling
+    terms, and those rows (oracle: downstream=True) get the looser REL_TOL_DOWNSTREAM.
 The achieved errors are printed (pytest -s) and written to gpurun_out/parity_headline.json when that directory exists.
 Reference call sites: gaussian_renderer/__init__.py:85-93, threestudio/systems/GaussianIP.py:452-457."""
 import json
@@ -34,6 +36,7 @@ P = 100000
 MAX_TOL = 2e-3
 REL_TOL = 1e-2
 FLOOR_FRAC = 1e-3
+REL_TOL_DOWNSTREAM = 5e-2
 _report = {}
 
 
@@ -57,7 +60,7 @@ def _upstream(seed, V=1):
             rng.normal(size=(V, 1, H, W)).astype(np.float32))
 
 
-def _compare(tag, name, ours, ref, floor=0.0, ref_end_to_end=None, skip_rows=None):
+def _compare(tag, name, ours, ref, floor=0.0, ref_end_to_end=None, skip_rows=None, loose_rows=None):
     """`ref`: oracle backward on the alpha image of the HIP forward (element-wise bar + max-normalised bar);
     `ref_end_to_end`: oracle backward on the oracle's own forward (max-normalised bar only);
     `skip_rows` [P] bool: knife-edge Gaussians, excluded from the element-wise bar."""
@@ -69,6 +72,12 @@ def _compare(tag, name, ours, ref, floor=0.0, ref_end_to_end=None, skip_rows=Non
     big = np.abs(ref) > FLOOR_FRAC * top
     if skip_rows is not None:
         big[skip_rows] = False
+    if loose_rows is not None:          # rows behind a knife-edge subject: looser element-wise bar
+        lb = big.copy()
+        lb[~loose_rows] = False
+        e_loose = float((err[lb] / np.abs(ref[lb])).max()) if lb.any() else 0.0
+        assert e_loose < REL_TOL_DOWNSTREAM, "%s %s: per-element relative error %.3e behind a knife-edge subject" % (tag, name, e_loose)
+        big[loose_rows] = False
     e_rel = float((err[big] / np.abs(ref[big])).max()) if big.any() else 0.0
     rec = dict(max_norm=e_max, rel=e_rel, entries_checked=int(big.sum()), top=top)
     line = "%-22s %-11s max-normalised %.2e   per-element relative %.2e on %d entries" % (tag, name, e_max, e_rel, big.sum())
@@ -110,7 +119,7 @@ def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look):
         torch.cuda.synchronize()
         go_e2e = ro.backward(gC[0], gD[0], gA[0])
         go = ro.backward(gC[0], gD[0], gA[0], alpha_out=alpha.detach().cpu().numpy())
-        knife, n_knife_pixels = ro.knife_edge_gaussians()
+        knife, n_knife_pixels, behind = ro.knife_edge_gaussians(downstream=True)
     finally:
         oracle.set_threads(1)
     tag = "1 view / " + look
@@ -120,7 +129,7 @@ def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look):
     for name, ours in (("means3D", t["means3D"].grad), ("means2D", m2.grad), ("opacities", t["opacities"].grad),
                        ("shs", t["shs"].grad), ("scales", t["scales"].grad), ("rotations", t["rotations"].grad)):
         _compare(tag, name, ours, go[name], floor=rot_floor if name == "rotations" else 0.0, ref_end_to_end=go_e2e[name],
-                 skip_rows=knife)
+                 skip_rows=knife, loose_rows=behind)
     _report[tag]["num_rendered"] = Rn
     _report[tag]["knife_edge_pixels"] = n_knife_pixels
     _report[tag]["knife_edge_gaussians"] = int(knife.sum())
@@ -151,16 +160,20 @@ def test_four_view_launch_set_at_100k_1024(oracle):
             imgs.append(out)
             ros.append(ro)
             grads.append(ro.backward(gC[v], gD[v], gA[v], alpha_out=alpha_np[v]))
+        kd = [ro.knife_edge_gaussians(downstream=True) for ro in ros]
+        knife, behind = [k[0] for k in kd], [k[2] for k in kd]     # per view: subjects of a knife-edge test / rows behind one
     finally:
         oracle.set_threads(1)
+    knife_any, behind_any = np.logical_or.reduce(knife), np.logical_or.reduce(behind)
+    assert knife_any.sum() <= 1e-2 * P, int(knife_any.sum())       # ~1e-3 of the Gaussians per view
     for v in range(4):
         o_color, o_radii, o_depth, o_alpha = imgs[v]
         assert np.array_equal(radii[v].cpu().numpy(), o_radii), "radii of view %d" % v
         _assert_images(ros[v], color[v], depth[v], alpha[v], o_color, o_depth, o_alpha)
-        _compare("4 views", "means2D[%d]" % v, m2.grad[v], grads[v]["means2D"])
+        _compare("4 views", "means2D[%d]" % v, m2.grad[v], grads[v]["means2D"], skip_rows=knife[v], loose_rows=behind[v])
     tot = {k: sum(g[k].astype(np.float64) for g in grads) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     rot_floor = float(np.abs(tot["scales"] * sc["scales"]).max())
     for k in ("means3D", "opacities", "shs", "scales"):
-        _compare("4 views", k, t[k].grad, tot[k])
-    _compare("4 views", "rotations", t["rotations"].grad, tot["rotations"], floor=rot_floor)
+        _compare("4 views", k, t[k].grad, tot[k], skip_rows=knife_any, loose_rows=behind_any)
+    _compare("4 views", "rotations", t["rotations"].grad, tot["rotations"], floor=rot_floor, skip_rows=knife_any, loose_rows=behind_any)
     _dump()
