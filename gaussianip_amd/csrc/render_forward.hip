@@ -48,6 +48,13 @@ __device__ __forceinline__ void both32(float x, float& lo, float& hi) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
 }
 
+// index of the lowest set bit of the wave-uniform mask m (-1 when m is empty), cleared from m: s_ff1_i32_b64 + s_bitset0_b64
+__device__ __forceinline__ int ffs_clear(unsigned long long& m) {
+  int j;
+  asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(m));
+  return j;
+}
+
 __global__ void __launch_bounds__(FWD_THREADS)
 gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_order,
                           const uint32_t* __restrict__ tile_start, const unsigned long long* __restrict__ keys,
@@ -74,25 +81,30 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
   if (end < start) end = start;
   const GipRecord* recs = records + (size_t)v * kp.P;
 
-  // entry FWD_THREADS of the staged arrays is a NULL entry (opacity 0 => alpha 0 => skipped by the alpha >= 1/255 test):
-  // a pair whose second (or first) entry does not exist reads it instead of carrying per-lane "have" flags
+  // Every 64-entry chunk of the staged arrays is preceded by a NULL entry (opacity 0 => alpha 0 => skipped by the
+  // alpha >= 1/255 test): chunk c lives at slots c * 65 + 1 .. c * 65 + 64, its NULL entry at c * 65.  The scalar walk
+  // takes j = find-first-one(m) - which is -1 once the mask is empty - and slot (c * 65 + 1 + j) is then the NULL entry:
+  // a pair whose second (or first) entry does not exist needs neither a select nor per-lane "have" flags
   // Field order chosen for PACKED fp32 math inside one (pixel, entry) evaluation — a gfx950 SIMD retires v_pk_mul /
   // v_pk_add / v_pk_fma (two fp32 per lane) at the rate of one scalar fp32 instruction: (x, y) - (px, py) is one
   // v_pk_add, (a dx, c dy) one v_pk_mul on the adjacent (a, c) pair, the colour / depth sums two v_pk_fma on (r, g), (b, d)
-  __shared__ v2f s_xy[FWD_THREADS + 1];
-  __shared__ v4f s_con[FWD_THREADS + 1];   // conic a, c, b (exp2 domain) + opacity
-  __shared__ v4f s_col[FWD_THREADS + 1];   // r, g, b + depth
+  constexpr int FWD_SLOTS = (FWD_THREADS / 64) * 65;
+  __shared__ v2f s_xy[FWD_SLOTS];
+  __shared__ v4f s_con[FWD_SLOTS];   // conic a, c, b (exp2 domain) + opacity
+  __shared__ v4f s_col[FWD_SLOTS];   // r, g, b + depth
   __shared__ uint32_t s_mask[FWD_THREADS];
-  if (threadIdx.x == 0) {
-    s_xy[FWD_THREADS] = (v2f){0.f, 0.f};
-    s_con[FWD_THREADS] = (v4f){0.f, 0.f, 0.f, 0.f};
-    s_col[FWD_THREADS] = (v4f){0.f, 0.f, 0.f, 0.f};
+  if (threadIdx.x < FWD_THREADS / 64) {
+    s_xy[threadIdx.x * 65] = (v2f){0.f, 0.f};
+    s_con[threadIdx.x * 65] = (v4f){0.f, 0.f, 0.f, 0.f};
+    s_col[threadIdx.x * 65] = (v4f){0.f, 0.f, 0.f, 0.f};
   }
+  const int sidx = threadIdx.x + (threadIdx.x >> 6) + 1;      // staging slot of this thread's entry
 
   bool done = !inside;
   float T = 1.0f, Wt = 0.f;
   v2f CG = {0.f, 0.f}, BD = {0.f, 0.f};   // (red, green), (blue, depth): this lane half's share of the sums
   uint32_t last_contributor = 0;
+  int last_off = -1;      // byte offset (x16) of the last contributing entry inside the current batch, -1 = none yet
 
   // software pipeline over the batches: the key of batch b+2 and the record of batch b+1 are in flight
   // while batch b is blended, so the dependent key -> record gather never stalls the blend loop
@@ -110,10 +122,10 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     const uint32_t k = base + threadIdx.x;
     if (k < end) {
       const float4 q0 = r0, q1 = r1, q2 = r2;
-      s_xy[threadIdx.x] = (v2f){q0.x, q0.y};
+      s_xy[sidx] = (v2f){q0.x, q0.y};
       // conic pre-scaled into the exp2 domain: power * log2(e) = A dx^2 + B dx dy + C dy^2 (sign tests are unchanged)
-      s_con[threadIdx.x] = (v4f){q1.x * -0.72134752044448170f, q1.z * -0.72134752044448170f, q1.y * -1.4426950408889634f, q0.w};
-      s_col[threadIdx.x] = (v4f){q2.x, q2.y, q2.z, q0.z};
+      s_con[sidx] = (v4f){q1.x * -0.72134752044448170f, q1.z * -0.72134752044448170f, q1.y * -1.4426950408889634f, q0.w};
+      s_col[sidx] = (v4f){q2.x, q2.y, q2.z, q0.z};
       // extent of { power >= -ln(255 o) }  (conservative: +1% / +0.05 px)
       uint32_t mask = 0xff;
       const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;
@@ -158,58 +170,62 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
         const int e = c0 + lane;
         const uint32_t mk = e < cnt ? s_mask[e] : 0u;
         unsigned long long m = __ballot((mk >> wave) & 1u);
+        const int cbase16 = ((c0 >> 6) * 65 + 1) << 4;
         bool wave_done = false;
         while (m) {
           // FWD_PAIRS pairs of list entries per trip: lanes 0-31 take the first entry of a pair, lanes 32-63 the second
-          int jj[FWD_PAIRS];
+          int ja[FWD_PAIRS];                                  // byte offset (x16) of this lane half's entry in the staged arrays
           float al[FWD_PAIRS];
           v4f cc[FWD_PAIRS];
 #pragma unroll
           for (int u = 0; u < FWD_PAIRS; u++) {
-            const int j1 = m ? c0 + __builtin_ctzll(m) : FWD_THREADS;
-            m &= m - 1;                                   // (0 & anything) stays 0
-            const int j2 = m ? c0 + __builtin_ctzll(m) : FWD_THREADS;
-            m &= m - 1;
-            jj[u] = hh ? j2 : j1;
-            const v2f d = s_xy[jj[u]] - pxy;                               // (dx, dy)
-            const v4f co = s_con[jj[u]];
-            cc[u] = s_col[jj[u]];
+            // scalar side: byte offsets of the pair's two entries; find-first-one of an empty mask is -1 = the NULL slot
+            const int j1 = ffs_clear(m), j2 = ffs_clear(m);
+            const int a1 = cbase16 + (j1 << 4), a2 = cbase16 + (j2 << 4);
+            ja[u] = hh ? a2 : a1;
+            const v2f d = *(const v2f*)((const char*)s_xy + (ja[u] >> 1)) - pxy;        // (dx, dy)
+            const v4f co = *(const v4f*)((const char*)s_con + ja[u]);
+            cc[u] = *(const v4f*)((const char*)s_col + ja[u]);
             const v2f t = co.xy * d;                                       // (a dx, c dy)
             // log2 domain; same operation sequence as the backward's re-evaluation (render_backward.hip: bwd_pair)
             const float power = __builtin_fmaf(d.x, __builtin_fmaf(co.z, d.y, t.x), t.y * d.y);
             const float a = fminf(GIP_ALPHA_MAX, co.w * __builtin_amdgcn_exp2f(power));
             al[u] = (power <= 0.0f && a >= GIP_ALPHA_MIN) ? a : 0.f;              // 0 = the reference skips this pair
           }
-          bool any_stop = false;
+          const unsigned long long done_before = __ballot(done);
 #pragma unroll
           for (int u = 0; u < FWD_PAIRS; u++) {
             float a_e, a_o;                                                      // first / second entry of the pair
             both32(al[u], a_e, a_o);
             // the reference's per-entry rule, applied to both entries in order by both lane halves; a terminated pixel
-            // sees alpha 0, which leaves T and the sums unchanged
+            // sees alpha 0, which leaves T and the sums unchanged.  T (1 - a) is evaluated as fma(-a, T, T).
             a_e = done ? 0.f : a_e;
-            const float t1 = T * (1.f - a_e);
+            const float t1 = __builtin_fmaf(-a_e, T, T);
             const bool stop1 = t1 < GIP_T_MIN;                                   // only reachable with a_e > 0
             const float T1 = stop1 ? T : t1;
             a_o = (done || stop1) ? 0.f : a_o;
-            const float t2 = T1 * (1.f - a_o);
+            const float t2 = __builtin_fmaf(-a_o, T1, T1);
             const bool stop2 = t2 < GIP_T_MIN;
             const float w_e = stop1 ? 0.f : a_e * T, w_o = stop2 ? 0.f : a_o * T1;
             const float w = hh ? w_o : w_e;
             CG = __builtin_elementwise_fma(cc[u].xy, (v2f){w, w}, CG);
             BD = __builtin_elementwise_fma(cc[u].zw, (v2f){w, w}, BD);
             Wt += w;
-            last_contributor = w > 0.f ? (base - start) + jj[u] + 1 : last_contributor;
+            last_off = w > 0.f ? ja[u] : last_off;                               // resolved to a list index once per batch
             T = stop2 ? T1 : t2;
             done = done || stop1 || stop2;
-            any_stop = any_stop || stop1 || stop2;
           }
-          if (__any(any_stop)) {           // wave-uniform; re-test termination only when something changed
+          if (__ballot(done) != done_before) {     // wave-uniform; re-test termination only when something changed
             if (__all(done)) { wave_done = true; break; }
           }
         }
         if (wave_done) break;
       }
+    }
+    if (last_off >= 0) {                                // n_contrib = 1-based list position of the last contributor
+      const uint32_t slot = (uint32_t)last_off >> 4;    // slot = chunk * 65 + 1 + position: list index = slot - chunk - 1
+      last_contributor = (base - start) + slot - slot / 65u;
+      last_off = -1;
     }
   }
 
