@@ -193,7 +193,10 @@ class StableDiffusionGuidance:
             return self.controlnet.embed_condition(cond)
 
     def forward_unet(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet=True,
-                     control_embedding=None, **_unused):
+                     control_embedding=None, replicas=1, **_unused):
+        """`replicas` = r: the batch is r copies of the same (latents, t, pose map) with different prompt embeddings
+        (ANPG: 3, classifier-free guidance: 2); the layers in front of the first cross-attention then run on one copy
+        (networks._Encoder.encode) — identical algebra."""
         dt = self.weights_dtype
         x = noisy_latents.to(dt)
         ctx = encoder_hidden_states.to(dt)
@@ -201,11 +204,11 @@ class StableDiffusionGuidance:
             x = x.contiguous(memory_format=torch.channels_last)
         with torch.autocast("cuda", enabled=False):
             if not use_pose_controlnet:
-                return self.unet(x, t, ctx).to(noisy_latents.dtype)
+                return self.unet(x, t, ctx, replicas=replicas).to(noisy_latents.dtype)
             if control_embedding is None:
                 control_embedding = self.embed_control(control_img)
-            down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=control_embedding)
-            return self.unet(x, t, ctx, down, mid).to(noisy_latents.dtype)
+            down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=control_embedding, replicas=replicas)
+            return self.unet(x, t, ctx, down, mid, replicas=replicas).to(noisy_latents.dtype)
 
     def encode_images(self, imgs, generator=None):
         x = (imgs * 2.0 - 1.0).to(self.weights_dtype)
@@ -238,7 +241,7 @@ class StableDiffusionGuidance:
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
             # the three branches share their pose maps: the ControlNet hint stem runs on the B distinct maps and tiles
             noise_pred = self.forward_unet(torch.cat([latents_noisy] * 3, dim=0), control_img,
-                                           torch.cat([t] * 3), embeds, use_pose_controlnet)
+                                           torch.cat([t] * 3), embeds, use_pose_controlnet, replicas=3)
             direction = sds.anpg_direction(noise_pred, t, self.cfg.guidance_scale)
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
         if self.cfg.grad_clip_pixel:
@@ -252,7 +255,7 @@ class StableDiffusionGuidance:
             noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
             noise_pred = self.forward_unet(torch.cat([latents_noisy] * 2, dim=0), control_img,
-                                           torch.cat([t] * 2), embeds, use_pose_controlnet)
+                                           torch.cat([t] * 2), embeds, use_pose_controlnet, replicas=2)
             direction = sds.cfg_direction(noise_pred, noise, self.cfg.guidance_scale, self.cfg.guidance_rescale)
         # no per-pixel clip here: the reference applies grad_clip_pixel only on the ANPG path (:427-431 vs :513)
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction

@@ -66,6 +66,8 @@ class ResBlock(nn.Module):
         add are one pass.  `self.staged_addend` (set by _Encoder.stage_time_embedding) already holds
         conv1.bias + time_emb_proj(silu(temb)) for this block when the batched projection is in use."""
         addend, self.staged_addend = self.staged_addend, None
+        if addend is not None and addend.shape[0] != x.shape[0]:
+            addend = addend[:x.shape[0]]           # shared prefix of a replicated batch (see _Encoder.encode)
         if addend is None:
             addend = self.conv1.bias
             if self.time_emb_proj is not None:
@@ -214,8 +216,10 @@ class TransformerBlock(nn.Module):
         self.ff_in = nn.Linear(dim, dim * 8)     # GEGLU: value | gate
         self.ff_out = nn.Linear(dim * 4, dim)
 
-    def forward(self, x, ctx):
+    def forward(self, x, ctx, replicas=1):
         x = self.attn1(self.norm1(x), None, x)                 # residual adds ride in the out-projection's epilogue
+        if replicas > 1:                                       # x held one copy of `replicas` identical samples so far
+            x = x.repeat(replicas, 1, 1)
         x = self.attn2(self.norm2(x), ctx, x)
         h = self.norm3(x)
         if h.shape[0] * h.shape[1] >= _GEGLU_FUSE_MIN_ROWS and fused.linear_supported(h, self.ff_in.weight):
@@ -235,16 +239,21 @@ class SpatialTransformer(nn.Module):
         self.block = TransformerBlock(dim, ctx_dim, heads, lora_rank, ip, ip_scale)
         self.proj_out = nn.Conv2d(dim, dim, 1)
 
-    def forward(self, x, ctx):
+    def forward(self, x, ctx, replicas=1):
+        """`replicas` > 1: x holds ONE copy of `replicas` samples that are identical up to the first cross-attention
+        (same latents / timestep / pose map, different prompts); norm, proj_in and the self-attention run on that
+        copy and the result is tiled before attn2 — the same values, 1/replicas of the work."""
         B, C, H, W = x.shape
         if fusable(x):      # NHWC: the 1x1 projections are GEMMs on the token view, no layout change anywhere
             t = F.linear(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
-            t = fused.linear(self.block(t, ctx), self.proj_out.weight.reshape(C, C), self.proj_out.bias,
-                             x.permute(0, 2, 3, 1).reshape(B, H * W, C))         # the block's residual rides in the epilogue
-            return t.reshape(B, H, W, C).permute(0, 3, 1, 2)
+            res = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            if replicas > 1:
+                res = res.repeat(replicas, 1, 1)
+            t = fused.linear(self.block(t, ctx, replicas), self.proj_out.weight.reshape(C, C), self.proj_out.bias, res)   # the block's residual rides in the epilogue
+            return t.reshape(B * replicas, H, W, C).permute(0, 3, 1, 2)
         h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        h = self.block(h, ctx).reshape(B, H, W, C).permute(0, 3, 1, 2)
-        return x + self.proj_out(h)
+        h = self.block(h, ctx, replicas).reshape(B * replicas, H, W, C).permute(0, 3, 1, 2)
+        return (x.repeat(replicas, 1, 1, 1) if replicas > 1 else x) + self.proj_out(h)
 
 
 class Downsample(nn.Module):
@@ -316,13 +325,18 @@ class _Encoder(nn.Module):
         for b, (lo, hi) in zip(blocks, offs):
             b.staged_addend = allp[:, lo:hi]
 
-    def encode(self, h, temb, ctx):
-        skips = [h]
+    def encode(self, h, temb, ctx, replicas=1):
+        """`replicas` > 1: `h` (and the rows of `temb` that matter) hold one copy of `replicas` identical samples — the
+        [neg | pos | null] branches of compute_grad_anpg share latents, timestep and pose map (ipa_guidance.py:397-399)
+        and first differ at the first cross-attention — so conv_in, the first ResnetBlock2D and the first transformer's
+        self-attention half run once per distinct sample; everything from attn2 on sees the full batch."""
+        skips = [h.repeat(replicas, 1, 1, 1) if replicas > 1 else h]
         for i in range(4):
             for j in range(2):
-                h = self.down_res[2 * i + j](h, temb)
+                first = replicas > 1 and i == 0 and j == 0
+                h = self.down_res[2 * i + j](h, temb[:h.shape[0]] if first and temb is not None else temb)
                 if i < 3:
-                    h = self.down_attn[2 * i + j](h, ctx)
+                    h = self.down_attn[2 * i + j](h, ctx, replicas) if first else self.down_attn[2 * i + j](h, ctx)
                 skips.append(h)
             if i < 3:
                 h = self.down_sample[i](h)
@@ -351,9 +365,10 @@ class UNet(_Encoder):
         self.norm_out = GroupNormAct(32, 320, act=True)
         self.conv_out = nn.Conv2d(320, 4, 3, padding=1)
 
-    def forward(self, x, t, ctx, down_residuals: Optional[List[torch.Tensor]] = None, mid_residual=None):
+    def forward(self, x, t, ctx, down_residuals: Optional[List[torch.Tensor]] = None, mid_residual=None, replicas=1):
         temb = self.temb(t, x.dtype)
-        h, skips = self.encode(self.conv_in(x), temb, ctx)
+        b = x.shape[0] // replicas
+        h, skips = self.encode(self.conv_in(x[:b] if replicas > 1 else x), temb, ctx, replicas)
         h = self.mid(h, temb, ctx)
         if down_residuals is not None:
             skips = [s + r for s, r in zip(skips, down_residuals)]
@@ -403,14 +418,17 @@ class ControlNet(_Encoder):
                 c = F.silu(c)
         return c
 
-    def forward(self, x, t, ctx, cond, conditioning_scale=1.0, cond_embedding=None) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    def forward(self, x, t, ctx, cond, conditioning_scale=1.0, cond_embedding=None, replicas=1) -> Tuple[List[torch.Tensor], torch.Tensor]:
         """`cond` may hold fewer samples than x (B / k): the hint stem then runs once per distinct hint and its output
         is tiled k times — the three guidance branches of compute_grad_anpg share their pose maps (ipa_guidance.py:397-399)."""
         temb = self.temb(t, x.dtype)
         c = self.embed_condition(cond) if cond_embedding is None else cond_embedding
-        if c.shape[0] != x.shape[0]:
+        b = x.shape[0] // replicas
+        if replicas > 1:
+            x, c = x[:b], c[:b]
+        elif c.shape[0] != x.shape[0]:
             c = c.repeat(x.shape[0] // c.shape[0], 1, 1, 1)
-        h, skips = self.encode(self.conv_in(x) + c, temb, ctx)
+        h, skips = self.encode(self.conv_in(x) + c, temb, ctx, replicas)
         h = self.mid(h, temb, ctx)
         down = [conv1x1(s, z.weight, z.bias) for z, s in zip(self.zero_convs, skips)]
         mid = conv1x1(h, self.mid_zero.weight, self.mid_zero.bias)

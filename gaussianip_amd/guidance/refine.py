@@ -97,7 +97,7 @@ class ViewConsistentRefiner:
         hint = self.g.embed_control(control_img)      # timestep-independent: once per view, not once per DDIM step
         for t in timesteps:
             tt = t.reshape(1).expand(2)
-            noise_pred = self.g.forward_unet(torch.cat([lat] * 2), None, tt, embeds, True, control_embedding=hint)
+            noise_pred = self.g.forward_unet(torch.cat([lat] * 2), None, tt, embeds, True, control_embedding=hint, replicas=2)
             uncond, text = noise_pred.float().chunk(2)
             noise_pred = uncond + self.guidance_scale * (text - uncond)
             lat = ddim_step(lat, noise_pred, t, self.g.alphas)

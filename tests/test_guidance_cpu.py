@@ -89,6 +89,12 @@ def test_guidance_plugin_token_layout_and_gradient_path():
     assert float(torch.norm(grad, dim=-1).max()) <= cfg.grad_clip_threshold + 1e-5
     grad2, _ = gd.compute_grad_sds(latents, control, t, pu, True, None, el, az, None, None, generator=g)
     assert grad2.shape == latents.shape
+    # the branches of a replicated batch share everything in front of the first cross-attention: same values
+    with torch.no_grad():
+        x3 = torch.cat([latents.detach()] * 3)
+        full = gd.forward_unet(x3, control, torch.cat([t] * 3), emb, True, replicas=1)
+        shared = gd.forward_unet(x3, control, torch.cat([t] * 3), emb, True, replicas=3)
+    assert float((full - shared).abs().max()) < 1e-4 * max(1.0, float(full.abs().max()))
     from gaussianip_amd.guidance import sds
     loss, gfix = sds.sds_loss(latents, grad)
     loss.backward()
@@ -303,7 +309,7 @@ class _TinyControlNet(torch.nn.Module):
     def embed_condition(self, cond):
         return torch.nn.functional.adaptive_avg_pool2d(cond, 64).mean(1, keepdim=True)
 
-    def forward(self, x, t, ctx, cond, scale=1.0, cond_embedding=None):
+    def forward(self, x, t, ctx, cond, scale=1.0, cond_embedding=None, replicas=1):
         c = cond_embedding
         if c.shape[0] != x.shape[0]:
             c = c.repeat(x.shape[0] // c.shape[0], 1, 1, 1)
@@ -314,7 +320,7 @@ class _TinyUNet(torch.nn.Module):
     def fold_lora(self, scale=1.0):
         return self
 
-    def forward(self, x, t, ctx, down=None, mid=None):
+    def forward(self, x, t, ctx, down=None, mid=None, replicas=1):
         out = 0.9 * x + ctx.mean(dim=(1, 2)).view(-1, 1, 1, 1) + 1e-3 * t.view(-1, 1, 1, 1).to(x.dtype)
         return out if mid is None else out + 0.1 * mid
 
