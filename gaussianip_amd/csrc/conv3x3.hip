@@ -47,7 +47,6 @@ __global__ void __launch_bounds__(CV_THREADS, STAGES == 2 ? 2 : 1)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom) {
-  const bool interleave = (geom >> 24) & 1;
   // geom = stride | pad_top << 8 | pad_left << 16; H, W are the OUTPUT dims, Hin, Win the input dims (equal at stride 1)
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -170,37 +169,6 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     }
   };
 
-  // The same math with the NEXT stage's LDS-DMA issues spread between the MFMA groups (one DMA after every four
-  // MFMAs): an MFMA blocks the wave's issue for 8 of its 16 cycles, so the DMA's issue cost (60-180 cycles apiece when
-  // eight of them sit in one block ahead of the math) overlaps with matrix work of the same wave instead of preceding it.
-  auto compute_stage = [&](const unsigned char* sbuf, int tap_n, int cb_n, int buf_n) {
-    const int dy = tap_n / 3, dx = tap_n - dy * 3;
-    const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * Win + dx) * Cin : 0) + cb_n * CV_BK) * 2u;
-    const unsigned wtap_off = (unsigned)(tap_n * Cin + cb_n * CV_BK) * 2u;
-    unsigned char* sa = smem + buf_n * STAGE + wave * 1024;
-    unsigned char* sb = sa + A_BYTES;
-    int d = 0;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const int pc = ((ks * 4 + kq) ^ swz) * 16;
-      f16x8 pix[4], wt[NI];
-#pragma unroll
-      for (int mi = 0; mi < 4; mi++) pix[mi] = *(const f16x8*)(sbuf + pix_base + mi * 2048 + pc);
-#pragma unroll
-      for (int ni = 0; ni < NI; ni++) wt[ni] = *(const f16x8*)(sbuf + ch_base + ni * 2048 + pc);
-#pragma unroll
-      for (int ni = 0; ni < NI; ni++) {
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[ni], pix[mi], acc[ni][mi], 0, 0, 0);
-        if (d < 4) dma16(xr, ((a_mask[d] >> tap_n) & 1u) ? a_off[d] : CV_OOB, tap_off, sa + d * 4096);
-        else if (d < 4 + B_ROUNDS) dma16(wr, b_off[d - 4], wtap_off, sb + (d - 4) * 4096);
-        d++;
-      }
-    }
-    static_assert(2 * NI >= 4 + B_ROUNDS, "one DMA slot per MFMA group");
-  };
-
   int tap = kt_begin / cblocks, cb = kt_begin - (kt_begin / cblocks) * cblocks;     // K step the NEXT stage() call loads
   auto advance = [&]() {
     if (++cb == cblocks) { cb = 0; ++tap; }
@@ -212,17 +180,8 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     __syncthreads();
     for (int kt = 0; kt < KT; kt++) {
       const int buf = kt & 1;
-      if (kt + 1 < KT) {
-        if (interleave) {
-          compute_stage(smem + buf * STAGE, tap, cb, buf ^ 1);
-        } else {
-          stage(tap, cb, buf ^ 1);
-          compute(smem + buf * STAGE);
-        }
-        advance();
-      } else {
-        compute(smem + buf * STAGE);
-      }
+      if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
+      compute(smem + buf * STAGE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -328,7 +287,6 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
                   int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0, int Hin = 0, int Win = 0,
                   int geom = 1 | (1 << 8) | (1 << 16)) {
   if (Hin == 0) { Hin = H; Win = W; }
-  static const int interleave_ok = [] { const char* e = getenv("GIP_CONV_INTERLEAVE"); return e ? (e[0] == '1') : 1; }();
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
@@ -349,9 +307,6 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
     while (ksplit > 1 && (size_t)ksplit * M * Cout * sizeof(float) > workspace_bytes) ksplit--;
     if (ksplit < 2) ksplit = 1;
   }
-  // DMA issues interleaved with the MFMA groups: +3-5 % on the full-K launches (measured same-box A/B, tools/exp_conv4.py),
-  // -7 % on the short split-K launches, which keep the block form
-  if (interleave_ok && ksplit == 1) geom |= 1 << 24;
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
                      N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom);

@@ -21,6 +21,9 @@ from .ahds import AHDSSchedule
 from .networks import IP_TOKENS, TEXT_TOKENS, ControlNet, UNet, VAEEncoder, init_for_benchmark
 
 
+_NO_SHARED_PREFIX = __import__("os").environ.get("GIP_SHARE_PREFIX", "1") == "0"      # A/B switch (tools/)
+
+
 @dataclass
 class GuidanceConfig:
     # the subset of ipa_guidance.py:74-123 that the per-step path reads (values of configs/exp.yaml:78-120 as defaults)
@@ -197,6 +200,8 @@ class StableDiffusionGuidance:
         """`replicas` = r: the batch is r copies of the same (latents, t, pose map) with different prompt embeddings
         (ANPG: 3, classifier-free guidance: 2); the layers in front of the first cross-attention then run on one copy
         (networks._Encoder.encode) — identical algebra."""
+        if _NO_SHARED_PREFIX:
+            replicas = 1
         dt = self.weights_dtype
         x = noisy_latents.to(dt)
         ctx = encoder_hidden_states.to(dt)

@@ -87,6 +87,18 @@ class StageOneStep:
         self.radii = None
         self.visibility_filter = None
 
+    _index_cache = None
+
+    def _take(self, t, ids):
+        """t[ids] along dim 0 without a host synchronisation (index tensors are cached per device)."""
+        if self._index_cache is None:
+            self._index_cache = {}
+        key = (t.device, tuple(ids))
+        idx = self._index_cache.get(key)
+        if idx is None:
+            idx = self._index_cache[key] = torch.as_tensor(list(ids), dtype=torch.long).to(t.device)
+        return t.index_select(0, idx)
+
     # GaussianIP.forward
     def forward(self, batch: Dict, renderbackground=None) -> Dict:
         bg = self.background if renderbackground is None else renderbackground
@@ -115,10 +127,12 @@ class StageOneStep:
                "scale": self.gaussian.get_scaling}
         if self.skeleton is not None and "mvp_mtx" in batch:
             dev = images.device
-            az = torch.as_tensor(batch["azimuth"])[ids].to(dev, non_blocking=True)
-            cent = torch.as_tensor(batch["center"])[ids].to(dev, non_blocking=True)
+            az, cent, mvp = torch.as_tensor(batch["azimuth"]), torch.as_tensor(batch["center"]), batch["mvp_mtx"]
+            if self.sharding is not None:           # (indexing with a Python list would synchronise: cached index tensors)
+                az, cent, mvp = self._take(az, ids), self._take(cent, ids), self._take(mvp, ids)
+            az, cent = az.to(dev, non_blocking=True), cent.to(dev, non_blocking=True)
             head_zoom = (cent == self.head_offset) & (az > 0)        # :176
-            pose, all_vis, _ = self.skeleton.openpose_draw(batch["mvp_mtx"][ids], self.pose_hw[0], self.pose_hw[1], az, head_zoom, True)
+            pose, all_vis, _ = self.skeleton.openpose_draw(mvp, self.pose_hw[0], self.pose_hw[1], az, head_zoom, True)
             out["pose"], out["all_vis_all"] = pose, all_vis
         return out
 
@@ -130,7 +144,7 @@ class StageOneStep:
         per_view = {k: v for k, v in batch.items() if k not in ("height", "width")}
         if self.sharding is not None:       # this rank's views only; the loss below is its share of the batch mean
             ids = list(self.sharding.views)
-            per_view = {k: (v[ids] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == batch["c2w"].shape[0] else v)
+            per_view = {k: (self._take(v, ids) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == batch["c2w"].shape[0] else v)
                         for k, v in per_view.items()}
         guidance_out = guidance(step, out["comp_rgb"], out["pose"], prompt_utils, use_pose_controlnet, out["all_vis_all"], **per_view)
         loss = self.loss(out, guidance_out)
