@@ -217,16 +217,18 @@ def main():
                 pmc = json.load(open(ppath))
                 c = pmc.get(dom, {})
                 traffic = int(c["hbm_fetch_bytes"] + c["hbm_write_bytes"])
-                # vector-issue roofline of the same kernel: one SIMD retires one wave64 vector instruction per
-                # 4 cycles (SQ_ACTIVE_INST_VALU counts those issue quad-cycles), the chip has 256 CUs x 4 SIMDs,
-                # the launch lasted GRBM_GUI_ACTIVE / 8 XCD cycles.  frac = busy SIMD-cycles / available SIMD-cycles.
+                # vector-issue roofline of the same kernel: a gfx950 SIMD retires one wave64 fp32 vector instruction
+                # per 4 cycles (transcendental and packed forms take longer), the chip has 256 CUs x 4 SIMDs, the launch
+                # lasted GRBM_GUI_ACTIVE / 8 XCD cycles: frac = 4 * SQ_INSTS_VALU / (1024 * cycles) is the share of the
+                # launch's SIMD issue cycles that the kernel's vector instructions need at that best-case rate.
                 cycles = c["GRBM_GUI_ACTIVE"] / 8.0
                 valu = {"bound": "valu-issue", "kernel": "gip_%s_kernel" % dom, "wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
-                        "cycles_per_wave_instruction": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 2),
-                        "busy_simd_cycles": int(4.0 * c["SQ_ACTIVE_INST_VALU"]), "available_simd_cycles": int(cycles * 1024),
-                        "frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * 1024), 4),
-                        "launch_cycles": int(cycles), "source": "profiles/pmc.json (rocprofv3 --pmc, this build)",
-                        "formula": "4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"}
+                        "cycles_per_wave_instruction_assumed": 4,
+                        "needed_simd_cycles": int(4.0 * c["SQ_INSTS_VALU"]), "available_simd_cycles": int(cycles * 1024),
+                        "frac": round(4.0 * c["SQ_INSTS_VALU"] / (cycles * 1024), 4),
+                        "busy_quad_cycles_counter": int(c["SQ_ACTIVE_INST_VALU"]), "launch_cycles": int(cycles),
+                        "source": "profiles/pmc.json (rocprofv3 --pmc, this build)",
+                        "formula": "4 * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"}
             except Exception:
                 traffic, valu = None, None
         roofline = {"bound": "hbm", "kernel": "gip_%s_kernel" % dom, "achieved": round(achieved, 2),
