@@ -31,7 +31,7 @@ class GipRasterInputs(ctypes.Structure):
 
 
 class GipRasterOutputs(ctypes.Structure):
-    _fields_ = [(n, _vp) for n in ("color", "radii", "depth", "alpha")]
+    _fields_ = [(n, _vp) for n in ("color", "radii", "depth", "alpha", "host_header")]
 
 
 class GipRasterGradsIn(ctypes.Structure):

@@ -110,6 +110,7 @@ static GipStatePtrs state_ptrs(void* state, const GipRasterStateLayout& L) {
   p.ckpt_start = (uint32_t*)(b + L.ckpt_start);
   p.seg_tile = (uint32_t*)(b + L.seg_tile);
   p.checkpoints = (float*)(b + L.checkpoints);
+  p.host_header = nullptr;
   return p;
 }
 
@@ -170,6 +171,7 @@ static int forward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, c
   GipKernelParams kp;
   fill_params(cfg, L, &kp);
   GipStatePtrs st = state_ptrs(state, L);
+  st.host_header = out->host_header;
   hipStream_t s = (hipStream_t)stream;
   StageTimer tm(s, times);
 

@@ -127,7 +127,7 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
                 uint32_t* __restrict__ tile_start,
                 uint32_t* __restrict__ seg_start, uint32_t* __restrict__ ckpt_start, uint32_t* __restrict__ seg_tile,
                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offset,
-                uint32_t* __restrict__ tile_order, GipRasterHeader* __restrict__ header) {
+                uint32_t* __restrict__ tile_order, GipRasterHeader* __restrict__ header, uint32_t* __restrict__ host_header) {
   __shared__ uint32_t s_wave[3][SCAN_WAVES];
   __shared__ uint32_t s_bucket[ORDER_CLASSES * SCAN_WAVES];
   __shared__ uint32_t s_class[4];
@@ -233,6 +233,11 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
     header->max_tile_count = max_tile;
     header->num_segments = total.b;
     header->num_checkpoints = total.c;
+    if (host_header) {      // pinned host mirror: the caller's capacity check needs no device-to-host copy
+      host_header[0] = GIP_ABI_VERSION; host_header[1] = total.a;
+      host_header[2] = (total.a > kp.capacity) ? 1u : 0u; host_header[3] = max_tile;
+      __threadfence_system();
+    }
   }
 }
 
@@ -243,7 +248,7 @@ void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) 
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr_once;
   hipLaunchKernelGGL(gip_scan_kernel, dim3(3), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
-                     st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header);
+                     st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header, st.host_header);
 }
 
 // ------------------------------------------------------------------------------------------------

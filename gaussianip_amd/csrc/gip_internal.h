@@ -57,6 +57,7 @@ struct GipStatePtrs {
   uint32_t* ckpt_start;     // [V*T+1]
   uint32_t* seg_tile;       // [seg_capacity]
   float* checkpoints;       // [ckpt_capacity][5][256]
+  uint32_t* host_header;    // optional pinned host mirror of the header's first words (GipRasterOutputs::host_header)
 };
 
 // --- launchers implemented in the .hip translation units -----------------------------------------

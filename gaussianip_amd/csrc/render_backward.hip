@@ -235,7 +235,16 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
           const float hx = sqrtf(inv * q1.z) * 1.01f + 0.05f, hy = sqrtf(inv * q1.x) * 1.01f + 0.05f;
           const float rx = q0.x - tile_x0, ry = q0.y - tile_y0;
           const bool xl = rx - hx <= 7.f, xr = rx + hx >= 8.f, yt = ry - hy <= 7.f, yb = ry + hy >= 8.f;
-          mask = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+          // distance bound for the quadrants diagonal to the centre (render_forward.hip): q >= lambda_min |d|^2
+          const float hd = 0.5f * (q1.x - q1.z);
+          const float lmax = 0.5f * (q1.x + q1.z) + sqrtf(__builtin_fmaf(hd, hd, q1.y * q1.y));
+          const float rad = sqrtf(inv * lmax) * 1.01f + 0.05f;
+          const float rad2 = rad * rad;
+          const float ex0 = fmaxf(fmaxf(-rx, rx - 7.f), 0.f), ex1 = fmaxf(fmaxf(8.f - rx, rx - 15.f), 0.f);
+          const float ey0 = fmaxf(fmaxf(-ry, ry - 7.f), 0.f), ey1 = fmaxf(fmaxf(8.f - ry, ry - 15.f), 0.f);
+          const float ex0s = ex0 * ex0, ex1s = ex1 * ex1, ey0s = ey0 * ey0, ey1s = ey1 * ey1;
+          mask = (xl && yt && ex0s + ey0s <= rad2 ? 1u : 0u) | (xr && yt && ex1s + ey0s <= rad2 ? 2u : 0u) |
+                 (xl && yb && ex0s + ey1s <= rad2 ? 4u : 0u) | (xr && yb && ex1s + ey1s <= rad2 ? 8u : 0u);
         }
         s_mask[lane] = mask;
         s_row[lane] = row;

@@ -16,7 +16,7 @@
 //   * the tile's depth-sorted list is consumed in batches of 512: each lane fetches one key, gathers that
 //     Gaussian's 64-byte record with dwordx4 loads, stages the 40 bytes the blend needs into LDS (conic pre-scaled
 //     into the exp2 domain), and computes an 8-bit BLOCK MASK from the tight screen-space extent of the
-//     alpha >= 1/255 ellipse (|dx| <= sqrt(2 ln(255 o) cov_xx), same for y).  A pair outside that ellipse fails the
+//     alpha >= 1/255 ellipse (|dx| <= sqrt(2 ln(255 o) cov_xx), same for y; and distance <= sqrt(t / lambda_min)).  A pair outside that ellipse fails the
 //     reference's alpha < 1/255 test, so skipping it cannot change any output;
 //   * each wave ballots the mask bits of its block and walks only the set bits with scalar find-first-one, two per
 //     step, FWD_PAIRS steps per trip (independent exp / alpha chains), and leaves as soon as all its pixels terminated;
@@ -138,10 +138,23 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
         const float rx = q0.x - tile_x0, ry = q0.y - tile_y0;   // centre relative to the tile origin
         const uint32_t cols = (rx - hx <= 7.f ? 1u : 0u) | (rx + hx >= 8.f ? 2u : 0u);      // columns 0..7 / 8..15
         const float ylo = ry - hy, yhi = ry + hy;
+        // second bound, for the blocks diagonal to the centre (the extent test keeps the whole bounding box of the
+        // ellipse): the quadratic form is >= lambda_min |d|^2, so a block farther from the centre than
+        // sqrt(t / lambda_min) lies outside the ellipse.  lambda_min = det / lambda_max (no cancellation).
+        const float hd = 0.5f * (q1.x - q1.z);
+        const float lmax = 0.5f * (q1.x + q1.z) + sqrtf(__builtin_fmaf(hd, hd, q1.y * q1.y));
+        const float rad = sqrtf(inv * lmax) * 1.01f + 0.05f;
+        const float rad2 = rad * rad;
+        const float ex0 = fmaxf(fmaxf(-rx, rx - 7.f), 0.f), ex1 = fmaxf(fmaxf(8.f - rx, rx - 15.f), 0.f);
+        const float ex0s = ex0 * ex0, ex1s = ex1 * ex1;
         mask = 0;
 #pragma unroll
-        for (int band = 0; band < 4; band++)                                                 // rows 4 band .. 4 band + 3
-          if (ylo <= (float)(4 * band + 3) && yhi >= (float)(4 * band)) mask |= cols << (2 * band);
+        for (int band = 0; band < 4; band++) {                                               // rows 4 band .. 4 band + 3
+          const float ey = fmaxf(fmaxf((float)(4 * band) - ry, ry - (float)(4 * band + 3)), 0.f);
+          const float eys = ey * ey;
+          const uint32_t near = (ex0s + eys <= rad2 ? 1u : 0u) | (ex1s + eys <= rad2 ? 2u : 0u);
+          if (ylo <= (float)(4 * band + 3) && yhi >= (float)(4 * band)) mask |= (cols & near) << (2 * band);
+        }
       }
       s_mask[threadIdx.x] = mask;
     }

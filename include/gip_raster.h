@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIP_ABI_VERSION 1
+#define GIP_ABI_VERSION 2
 #define GIP_TILE 16            /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16 in the reference's rasterizer) */
 #define GIP_MAX_VIEWS 16       /* views per call */
 #define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
@@ -97,6 +97,11 @@ typedef struct GipRasterOutputs {
   int32_t* radii;  /* [V,P]     */
   float*   depth;  /* [V,1,H,W] */
   float*   alpha;  /* [V,1,H,W] */
+  uint32_t* host_header; /* optional (null = unused): 16 x u32 of PINNED, device-mapped HOST memory.  The binning stage
+                            stores {abi_version, num_rendered, overflow, max_tile_count} there as soon as the totals
+                            are known, so the caller learns the capacity verdict from an event on `stream` without
+                            enqueueing a device-to-host copy (the reference instead blocks on a D2H read of
+                            num_rendered inside every forward). */
 } GipRasterOutputs;
 
 /* Upstream gradients (any may be null = zero) and the forward outputs (all three required: the

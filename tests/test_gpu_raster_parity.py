@@ -156,7 +156,7 @@ def _check_backward(oracle, kind, P, H, W, seed, sh_degree, use_precomp=False, b
             full = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
             cov[bad] = full[bad]
     ro, _ = _oracle_forward(oracle, sc, cam, H, W, bg, sh_degree, colors=colors, cov=cov)
-    go = ro.backward(gC, gD, gA)
+    go_e2e = ro.backward(gC, gD, gA)
 
     st = _settings(cam, H, W, bg, sh_degree)
     t = {k: _dev(v).requires_grad_(True) for k, v in sc.items()}
@@ -174,24 +174,31 @@ def _check_backward(oracle, kind, P, H, W, seed, sh_degree, use_precomp=False, b
     loss.backward()
     torch.cuda.synchronize()
 
-    def close(name, ours, ref, floor=0.0):
+    # The fork's backward derives every T_j from T_final := 1 - alpha_out: at a nearly opaque pixel (alpha 0.9999) a
+    # 1-ulp difference of the two forwards' alpha images (fp32 summation order) is a 1e-3 relative difference of T_final.
+    # So the backward is checked in isolation at `tol` (the oracle replays with THIS forward's alpha image, exactly the
+    # input the fork's backward gets) and end to end at the looser bar that conditioning allows.
+    go_iso = ro.backward(gC, gD, gA, alpha_out=alpha.detach().cpu().numpy().reshape(1, H, W))
+
+    def close(name, ours, ref, floor=0.0, bar=tol):
         # `floor`: magnitude below which a gradient is analytically zero (e.g. the rotation of an isotropic Gaussian)
         ours = ours.detach().cpu().numpy().reshape(ref.shape)
         scale = max(float(np.abs(ref).max()), floor) + 1e-20
         err = np.abs(ours - ref).max() / scale
-        assert err < tol, "%s: max error / max |grad| = %.3e" % (name, err)
+        assert err < bar, "%s: max error / max |grad| = %.3e" % (name, err)
 
-    close("means3D", t["means3D"].grad, go["means3D"])
-    close("means2D", means2D.grad, go["means2D"])
-    close("opacities", t["opacities"].grad, go["opacities"])
-    if use_precomp:
-        close("colors_precomp", tc.grad, go["colors_precomp"])
-        close("cov3D_precomp", tv.grad, go["cov3D_precomp"])
-    else:
-        close("shs", t["shs"].grad, go["shs"])
-        close("scales", t["scales"].grad, go["scales"])
-        close("rotations", t["rotations"].grad, go["rotations"],
-              floor=float(np.abs(go["scales"] * sc["scales"]).max()))
+    for go, bar in ((go_iso, tol), (go_e2e, max(tol, 5e-3))):
+        close("means3D", t["means3D"].grad, go["means3D"], bar=bar)
+        close("means2D", means2D.grad, go["means2D"], bar=bar)
+        close("opacities", t["opacities"].grad, go["opacities"], bar=bar)
+        if use_precomp:
+            close("colors_precomp", tc.grad, go["colors_precomp"], bar=bar)
+            close("cov3D_precomp", tv.grad, go["cov3D_precomp"], bar=bar)
+        else:
+            close("shs", t["shs"].grad, go["shs"], bar=bar)
+            close("scales", t["scales"].grad, go["scales"], bar=bar)
+            close("rotations", t["rotations"].grad, go["rotations"],
+                  floor=float(np.abs(go["scales"] * sc["scales"]).max()), bar=bar)
     return t, means2D
 
 
