@@ -41,6 +41,15 @@ def timestep_embedding(t, dim=320, max_period=10000.0):
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
+def _tile_batch(x, n):
+    """x.repeat(n, 1, 1, 1) that keeps an NHWC tensor NHWC (Tensor.repeat returns NCHW-contiguous memory, which sends
+    every consumer of the result — here the last up-block of the U-Net through its skip connection — down the
+    unfused library path)."""
+    if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        return x.permute(0, 2, 3, 1).repeat(n, 1, 1, 1).permute(0, 3, 1, 2)
+    return x.repeat(n, 1, 1, 1)
+
+
 class ResBlock(nn.Module):
     def __init__(self, cin, cout, temb_dim=1280, eps=1e-5):
         super().__init__()
@@ -253,7 +262,7 @@ class SpatialTransformer(nn.Module):
             return t.reshape(B * replicas, H, W, C).permute(0, 3, 1, 2)
         h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.block(h, ctx, replicas).reshape(B * replicas, H, W, C).permute(0, 3, 1, 2)
-        return (x.repeat(replicas, 1, 1, 1) if replicas > 1 else x) + self.proj_out(h)
+        return (_tile_batch(x, replicas) if replicas > 1 else x) + self.proj_out(h)
 
 
 class Downsample(nn.Module):
@@ -330,7 +339,7 @@ class _Encoder(nn.Module):
         [neg | pos | null] branches of compute_grad_anpg share latents, timestep and pose map (ipa_guidance.py:397-399)
         and first differ at the first cross-attention — so conv_in, the first ResnetBlock2D and the first transformer's
         self-attention half run once per distinct sample; everything from attn2 on sees the full batch."""
-        skips = [h.repeat(replicas, 1, 1, 1) if replicas > 1 else h]
+        skips = [_tile_batch(h, replicas) if replicas > 1 else h]
         for i in range(4):
             for j in range(2):
                 first = replicas > 1 and i == 0 and j == 0
@@ -413,9 +422,10 @@ class ControlNet(_Encoder):
         DDIM steps of the refine pass) computes it once and hands it to forward() as `cond_embedding`."""
         c = cond
         for i, conv in enumerate(self.cond_stem):
-            c = conv(c)
             if i < len(self.cond_stem) - 1:
-                c = F.silu(c)
+                c = F.silu(conv(c))
+            else:
+                c = conv3x3(c, conv.weight, conv.bias)       # 256 -> 320 at 1/8 resolution: the MFMA kernel's shape
         return c
 
     def forward(self, x, t, ctx, cond, conditioning_scale=1.0, cond_embedding=None, replicas=1) -> Tuple[List[torch.Tensor], torch.Tensor]:

@@ -59,8 +59,16 @@ def test_three_full_ahds_steps(rig):
     before = dict(_lib.call_counts)
     losses = []
     scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)     # precision: 16-mixed; with the fused Adam its step() stays on the device
+    import torch.nn.functional as F
+    library_convs = []
+    real_conv2d = F.conv2d
+
+    def spy_conv2d(x, w, *a, **k):
+        library_convs.append((tuple(x.shape), tuple(w.shape)))
+        return real_conv2d(x, w, *a, **k)
     for step in range(3):
         batch = scenes.train_batch(cam_rng, B, H, W, device=dev)
+        F.conv2d = spy_conv2d if step == 1 else real_conv2d
         if step > 0:
             # steady state: nothing between the render and the optimizer may wait for the GPU (step 0 sizes the
             # rasterizer's capacity synchronously, once per shape)
@@ -70,6 +78,7 @@ def test_three_full_ahds_steps(rig):
             action = stage.optimizer_step(loss, step, scaler=scaler if step == 2 else None)
         finally:
             torch.cuda.set_sync_debug_mode("default")
+            F.conv2d = real_conv2d
         assert action is None and set(gout) == {"loss_sds", "grad_norm"}
         assert out["comp_rgb"].shape == (B, H, W, 3) and out["pose"].shape == (B, 512, 512, 3) and out["all_vis_all"].shape == (B,)
         losses.append(loss.detach())
@@ -87,6 +96,11 @@ def test_three_full_ahds_steps(rig):
                 "gip_attention_fwd_f16", "gip_gn_silu_forward", "gip_gn_silu_backward", "gip_layernorm_f16"):
         assert ran.get(sym, 0) >= 3, (sym, ran.get(sym, 0))
     assert ran["gip_raster_forward"] <= 4                        # one launch set per step (+ one capacity re-run at most)
+    # no 3x3 convolution the MFMA kernel covers (input channels a multiple of 64, >= 64 output channels, 16^2 and larger)
+    # may fall back to the library: a tensor that silently lost its NHWC layout (Tensor.repeat, an eager add) once sent
+    # a whole ResnetBlock2D there.  What legitimately stays: the 3-channel stems and the 4 / 8-channel output convolutions
+    stray = [(xs, ws) for xs, ws in library_convs if ws[2:] == (3, 3) and ws[1] % 64 == 0 and ws[0] >= 64 and xs[2] >= 16]
+    assert not stray, stray
 
 
 def test_amp_gradscaler_reproduces_the_scaled_densification_statistics(rig):

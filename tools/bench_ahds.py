@@ -96,6 +96,17 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
 
     for i in range(warmup):
         step(i)
+    if os.environ.get("GIP_TORCH_PROFILE"):
+        # op-level table of two steady-state steps (which aten op, with which shapes, from which line launched the glue kernels)
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+            step(warmup)
+            step(warmup + 1)
+            torch.cuda.synchronize()
+        with open(os.environ["GIP_TORCH_PROFILE"], "w") as f:
+            f.write(prof.key_averages(group_by_input_shape=True, group_by_stack_n=6).table(
+                sort_by="self_cuda_time_total", row_limit=120, max_name_column_width=50, max_shapes_column_width=70, max_src_column_width=110))
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
