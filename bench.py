@@ -142,6 +142,21 @@ def main():
     views_total = world * V * args.steps
     mpix_s = views_total * H * W / elapsed / 1e6
 
+    # forward only (SURVEY §8d asks for forward and forward+backward separately): the same 4-view launch set rendered
+    # without a backward to follow.  Grad mode stays on so that the capacity check stays deferred as in training; an
+    # output render under no_grad additionally waits for its header (one host round trip per call)
+    def fwd_step():
+        m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        return rasterize_views(t["means3D"], m2d, t["opacities"], sts, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    for _ in range(3):
+        fwd_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd_step()
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
     # ---- BASELINE.json configs[3] layout of the same raster step (N > 1): the 4 views of ONE optimizer step sharded over
     # the ranks of a seed group (8 GPUs: 2 seed groups with their own process groups), gradients SUM-reduced inside it
     config3 = None
@@ -288,6 +303,7 @@ def main():
                           "num_rendered_per_view": int(Rv), "sh_degree": 0,
                           "parallelism": "view-sharded dp%d" % world},
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
+               "forward_only": {"ms_per_step": round(fwd_ms, 4), "mpix_per_s_per_gpu": round(V * H * W / fwd_ms / 1e3, 1)},
                "config3_layout": config3,
                "roofline": roofline, "roofline_valu": valu, "cpu_baseline": cpu}
     if rank == 0:
