@@ -47,7 +47,9 @@ template <int D, bool TWO>
 __global__ void __launch_bounds__(256, 2)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
-                const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2) {
+                const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2, int ld_kv, int ld_kv2) {
+  // ld_kv / ld_kv2: elements between consecutive key rows of (k, v) / (k2, v2).  H * D for packed projections; larger
+  // when a layer's keys are a column range of one wide matrix holding the key / value projections of MANY layers
   static_assert(D % 8 == 0 && D <= 128, "head dim");
   constexpr int AT_ROW = D <= 64 ? 128 : 256;          // bytes per LDS row
   constexpr int AT_TILE = AT_BKV * AT_ROW;             // one K or V stage
@@ -108,14 +110,14 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #define AT_FETCH(blk_)                                                                   \
   {                                                                                      \
     const int ra_ = min((blk_) * AT_BKV + row0, n_keys - 1), rb_ = min((blk_) * AT_BKV + row1, n_keys - 1);  \
-    kr0 = *(const uint4*)(kp + (size_t)ra_ * C + ch0 * 8);                               \
-    kr1 = *(const uint4*)(kp + (size_t)rb_ * C + ch1 * 8);                               \
-    vr0 = *(const uint4*)(vp + (size_t)ra_ * C + ch0 * 8);                               \
-    vr1 = *(const uint4*)(vp + (size_t)rb_ * C + ch1 * 8);                               \
+    kr0 = *(const uint4*)(kp + (size_t)ra_ * ld + ch0 * 8);                               \
+    kr1 = *(const uint4*)(kp + (size_t)rb_ * ld + ch1 * 8);                               \
+    vr0 = *(const uint4*)(vp + (size_t)ra_ * ld + ch0 * 8);                               \
+    vr1 = *(const uint4*)(vp + (size_t)rb_ * ld + ch1 * 8);                               \
     if constexpr (PER == 3) {                                                            \
       const int rc_ = min((blk_) * AT_BKV + row2, n_keys - 1);                           \
-      kr2 = *(const uint4*)(kp + (size_t)rc_ * C + ch2 * 8);                             \
-      vr2 = *(const uint4*)(vp + (size_t)rc_ * C + ch2 * 8);                             \
+      kr2 = *(const uint4*)(kp + (size_t)rc_ * ld + ch2 * 8);                             \
+      vr2 = *(const uint4*)(vp + (size_t)rc_ * ld + ch2 * 8);                             \
     }                                                                                    \
   }
 #define AT_DEPOSIT(stage_)                                                 \
@@ -146,8 +148,9 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 
   for (int seg = 0; seg < (TWO ? 2 : 1); seg++) {
     const int n_keys = seg == 0 ? Nkv : Nkv2;
-    const _Float16* kp = (seg == 0 ? k : k2) + (size_t)b * n_keys * C + h * D;
-    const _Float16* vp = (seg == 0 ? v : v2) + (size_t)b * n_keys * C + h * D;
+    const size_t ld = (size_t)(seg == 0 ? ld_kv : ld_kv2);
+    const _Float16* kp = (seg == 0 ? k : k2) + (size_t)b * n_keys * ld + h * D;
+    const _Float16* vp = (seg == 0 ? v : v2) + (size_t)b * n_keys * ld + h * D;
 #pragma unroll
     for (int dt = 0; dt < ND; dt++)
 #pragma unroll
@@ -292,28 +295,35 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 
 template <int D>
 static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
-                        float c, const void* k2, const void* v2, int Nkv2, float w2) {
+                        float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2) {
   if (k2)
     hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
-                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2);
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2, ld_kv, ld_kv2);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
-                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f);
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv, ld_kv);
+}
+
+extern "C" int gip_attention_fwd_strided_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
+                                             int32_t Nq, int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2,
+                                             int32_t Nkv2, float weight2, int32_t ld_kv, int32_t ld_kv2, void* stream) {
+  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < AT_BQ || Nq % AT_BQ || Nkv < 1) return 1;
+  if ((k2 != nullptr) != (v2 != nullptr) || (k2 && Nkv2 < 1)) return 1;
+  if (ld_kv < H * D || ld_kv % 8 || (k2 && (ld_kv2 < H * D || ld_kv2 % 8))) return 1;        // 16-byte row loads
+  const float c = scale * 1.4426950408889634f;
+  const dim3 grid(Nq / AT_BQ, B * H);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
+    case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
+    case 80: launch_attn<80>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
+    default: return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 extern "C" int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
                                      int32_t Nq, int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2,
                                      int32_t Nkv2, float weight2, void* stream) {
-  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < AT_BQ || Nq % AT_BQ || Nkv < 1) return 1;
-  if ((k2 != nullptr) != (v2 != nullptr) || (k2 && Nkv2 < 1)) return 1;
-  const float c = scale * 1.4426950408889634f;
-  const dim3 grid(Nq / AT_BQ, B * H);
-  hipStream_t s = (hipStream_t)stream;
-  switch (D) {
-    case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
-    case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
-    case 80: launch_attn<80>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2); break;
-    default: return 1;
-  }
-  return hipGetLastError() == hipSuccess ? 0 : 3;
+  return gip_attention_fwd_strided_f16(q, k, v, o, B, H, Nq, Nkv, D, scale, k2, v2, Nkv2, weight2, H * D, H * D, stream);
 }

@@ -273,27 +273,48 @@ def conv1x1(x, w, bias=None):
     return F.conv2d(x, w, bias)
 
 
+def _kv_rows(t):
+    """Row stride (in halves) of a [B, N, C] key / value tensor the attention kernel can read in place: packed, or a column
+    range of a wider row-major matrix (rows of one sample consecutive).  None when a copy is needed."""
+    B, N, C = t.shape
+    if t.stride(2) != 1 or t.stride(1) % 8 or t.stride(1) < C or (B > 1 and t.stride(0) != N * t.stride(1)) or t.data_ptr() % 16:
+        return None
+    return t.stride(1)
+
+
 def attention_supported(q, k, heads):
     D = q.shape[-1] // heads
     return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64, 80) and q.shape[1] % 128 == 0 and
-            k.shape[1] >= 1 and q.is_contiguous() and k.is_contiguous() and
+            k.shape[1] >= 1 and q.is_contiguous() and _kv_rows(k) is not None and
             not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
 
 
 def attention(q, k, v, heads, k2=None, v2=None, weight2=1.0):
     """softmax(q k^T / sqrt(D)) v [+ weight2 * softmax(q k2^T / sqrt(D)) v2] on [B, N, heads * D] projections; returns
-    [B, Nq, heads * D] (csrc/attention.hip).  Key counts are arbitrary (77 text tokens, 4 image tokens, 2N mutual keys)."""
+    [B, Nq, heads * D] (csrc/attention.hip).  Key counts are arbitrary (77 text tokens, 4 image tokens, 2N mutual keys).
+    k / v (and k2 / v2) may be column ranges of one wide projection matrix (same row stride for the pair)."""
     B, Nq, C = q.shape
     D = C // heads
     o = torch.empty_like(q)
     null = ctypes.c_void_p(None)
     two = k2 is not None
-    rc = _lib.nn_lib().gip_attention_fwd_f16(_p(q), _p(k), _p(v.contiguous()), _p(o), B, heads, Nq, k.shape[1], D,
-                                             float(D) ** -0.5, _p(k2.contiguous()) if two else null,
-                                             _p(v2.contiguous()) if two else null, k2.shape[1] if two else 0, float(weight2),
-                                             ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+
+    def pair(a, b):
+        la, lb = _kv_rows(a), _kv_rows(b)
+        if la is None or la != lb:
+            a, b = a.contiguous(), b.contiguous()
+            la = C
+        return a, b, la
+    k, v, ld = pair(k, v)
+    ld2 = C
+    if two:
+        k2, v2, ld2 = pair(k2, v2)
+    rc = _lib.nn_lib().gip_attention_fwd_strided_f16(_p(q), _p(k), _p(v), _p(o), B, heads, Nq, k.shape[1], D, float(D) ** -0.5,
+                                                     _p(k2) if two else null, _p(v2) if two else null,
+                                                     k2.shape[1] if two else 0, float(weight2), ld, ld2,
+                                                     ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
     if rc != 0:
-        raise RuntimeError("gip_attention_fwd_f16 failed with status %d" % rc)
+        raise RuntimeError("gip_attention_fwd_strided_f16 failed with status %d" % rc)
     return o
 
 

@@ -144,6 +144,7 @@ class Attention(nn.Module):
         return h.transpose(1, 2).reshape(q.shape)
 
     refine = None        # RefineAttentionState when this layer is one of the VCR target self-attentions
+    staged_kv = None     # (k, v, k_ip, v_ip) of the prompt tokens for the next call (_Encoder.stage_context)
 
     def _forward_refine(self, x):
         """Self-attention in the 'refine' state of LoRAAttnProcessor2_0 (attention_processor_faceid.py:291-364):
@@ -193,6 +194,15 @@ class Attention(nn.Module):
             ctx = x
         elif self.ip:
             ctx, ip_ctx = ctx[:, :-IP_TOKENS], ctx[:, -IP_TOKENS:]
+        staged, self.staged_kv = self.staged_kv, None
+        if staged is not None and staged[0].shape[0] == x.shape[0] and not self.lora_rank:
+            # key / value projections of the prompt tokens, made for all layers at once by _Encoder.stage_context
+            q = self.to_q(x)
+            k, v, k_ip, v_ip = staged
+            if fused.attention_supported(q, k, self.heads):
+                if k_ip is None:
+                    return self._out(fused.attention(q, k, v, self.heads), residual)
+                return self._out(fused.attention(q, k, v, self.heads, k_ip, v_ip, self.ip_scale), residual)
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if self.lora_rank:
             q, k, v = q + self.lora_q(x), k + self.lora_k(ctx), v + self.lora_v(ctx)
@@ -324,7 +334,40 @@ class _Encoder(nn.Module):
             offs.append((o, o + b.conv1.out_channels))
             o += b.conv1.out_channels
         self._temb_pack = (blocks, W, bias, offs)
+        # every cross-attention layer projects the SAME prompt tokens: one [sum(2 C), 768] matrix for all their to_k / to_v
+        # (and one for the IP-Adapter's to_k_ip / to_v_ip over the 4 image tokens) turns 4 tiny GEMMs per layer into 2 per
+        # forward.  Only for folded LoRA (a live LoRA branch keeps the per-layer path).
+        cross = [m.attn2 for m in self.modules() if isinstance(m, TransformerBlock)]
+        self._ctx_pack = None
+        if cross and not any(a.lora_rank for a in cross):
+            Wt = torch.cat([torch.cat([a.to_k.weight, a.to_v.weight]) for a in cross]).contiguous()
+            Wi = torch.cat([torch.cat([a.to_k_ip.weight, a.to_v_ip.weight]) for a in cross]).contiguous() if all(a.ip for a in cross) else None
+            offs, o = [], 0
+            for a in cross:
+                c = a.to_k.weight.shape[0]
+                offs.append((o, c))
+                o += 2 * c
+            self._ctx_pack = (cross, Wt, Wi, offs)
         return self
+
+    _ctx_pack = None
+
+    def stage_context(self, ctx):
+        """Projects the prompt tokens `ctx` [B, 77 (+ 4 image tokens), 768] for every cross-attention layer of this
+        network at once; each layer then reads its keys / values as a column range of the result (strided in place)."""
+        if self._ctx_pack is None or not (ctx.is_cuda and ctx.dtype == torch.float16) or fused._DISABLED or \
+                (torch.is_grad_enabled() and ctx.requires_grad):
+            return
+        cross, Wt, Wi, offs = self._ctx_pack
+        B = ctx.shape[0]
+        if Wi is not None:
+            text = F.linear(ctx[:, :-IP_TOKENS].reshape(-1, ctx.shape[-1]), Wt).view(B, -1, Wt.shape[0])
+            ip = F.linear(ctx[:, -IP_TOKENS:].reshape(-1, ctx.shape[-1]), Wi).view(B, IP_TOKENS, Wi.shape[0])
+        else:
+            text, ip = F.linear(ctx.reshape(-1, ctx.shape[-1]), Wt).view(B, -1, Wt.shape[0]), None
+        for a, (o, c) in zip(cross, offs):
+            a.staged_kv = (text[:, :, o:o + c], text[:, :, o + c:o + 2 * c],
+                           None if ip is None else ip[:, :, o:o + c], None if ip is None else ip[:, :, o + c:o + 2 * c])
 
     def stage_time_embedding(self, temb):
         if self._temb_pack is None or not (temb.is_cuda and temb.dtype == torch.float16):
@@ -376,6 +419,7 @@ class UNet(_Encoder):
 
     def forward(self, x, t, ctx, down_residuals: Optional[List[torch.Tensor]] = None, mid_residual=None, replicas=1):
         temb = self.temb(t, x.dtype)
+        self.stage_context(ctx)
         b = x.shape[0] // replicas
         h, skips = self.encode(self.conv_in(x[:b] if replicas > 1 else x), temb, ctx, replicas)
         h = self.mid(h, temb, ctx)
@@ -432,6 +476,7 @@ class ControlNet(_Encoder):
         """`cond` may hold fewer samples than x (B / k): the hint stem then runs once per distinct hint and its output
         is tiled k times — the three guidance branches of compute_grad_anpg share their pose maps (ipa_guidance.py:397-399)."""
         temb = self.temb(t, x.dtype)
+        self.stage_context(ctx)
         c = self.embed_condition(cond) if cond_embedding is None else cond_embedding
         b = x.shape[0] // replicas
         if replicas > 1:

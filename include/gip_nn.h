@@ -101,6 +101,13 @@ int gip_linear_f16(const void* x, const void* w, const void* bias, const void* r
 int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t Nq,
                           int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2, int32_t Nkv2,
                           float weight2, void* stream);
+/* Same, with the key / value rows of a sample `ld_kv` (`ld_kv2` for k2 / v2) halves apart instead of H * D: k and v may
+ * then be column ranges of ONE wide projection matrix that holds the to_k / to_v outputs of every cross-attention layer
+ * of a network (the prompt embeddings are the same input for all 16 layers of attention_processor_faceid.py:433-523, so
+ * the host projects them with one GEMM per forward).  ld % 8 == 0, ld >= H * D; a sample's rows are consecutive. */
+int gip_attention_fwd_strided_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t Nq,
+                                  int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2, int32_t Nkv2,
+                                  float weight2, int32_t ld_kv, int32_t ld_kv2, void* stream);
 #ifdef __cplusplus
 }
 #endif

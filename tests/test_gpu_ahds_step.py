@@ -93,7 +93,7 @@ def test_three_full_ahds_steps(rig):
     # and the hand-written HIP path is what ran
     ran = {k: _lib.call_counts.get(k, 0) - before.get(k, 0) for k in _lib.call_counts}
     for sym in ("gip_raster_forward", "gip_raster_backward", "gip_openpose_draw", "gip_conv3x3_nhwc_f16",
-                "gip_attention_fwd_f16", "gip_gn_silu_forward", "gip_gn_silu_backward", "gip_layernorm_f16"):
+                "gip_attention_fwd_strided_f16", "gip_gn_silu_forward", "gip_gn_silu_backward", "gip_layernorm_f16"):
         assert ran.get(sym, 0) >= 3, (sym, ran.get(sym, 0))
     assert ran["gip_raster_forward"] <= 4                        # one launch set per step (+ one capacity re-run at most)
     # no 3x3 convolution the MFMA kernel covers (input channels a multiple of 64, >= 64 output channels, 16^2 and larger)

@@ -119,3 +119,50 @@ def test_reference_processor_fixtures_through_the_hip_attention(monkeypatch, fol
             assert np.abs(got - want).max() < 1e-2 * np.abs(want).max(), ("cross", n_tok)
             if n_tok == 256:
                 assert calls[before:] == [4, 7], calls[before:]     # one plain call, one two-key-set call of the HIP kernel
+
+
+def test_keys_as_column_ranges_of_a_wide_projection_matrix():
+    """gip_attention_fwd_strided_f16: k / v (and k2 / v2) read in place from one wide row-major matrix == packed copies."""
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B, H, D, N = 3, 8, 40, 1024
+    C = H * D
+    q = torch.randn(B, N, C, device="cuda", generator=g).half()
+    wide = torch.randn(B, 77, 5 * C + 64, device="cuda", generator=g).half()
+    wide2 = torch.randn(B, 4, 3 * C, device="cuda", generator=g).half()
+    k, v = wide[:, :, C:2 * C], wide[:, :, 3 * C + 64:4 * C + 64]
+    k2, v2 = wide2[:, :, :C], wide2[:, :, 2 * C:]
+    assert not k.is_contiguous() and fused.attention_supported(q, k, H)
+    with torch.no_grad():
+        assert torch.equal(fused.attention(q, k, v, H), fused.attention(q, k.contiguous(), v.contiguous(), H))
+        assert torch.equal(fused.attention(q, k, v, H, k2, v2, 0.5),
+                           fused.attention(q, k.contiguous(), v.contiguous(), H, k2.contiguous(), v2.contiguous(), 0.5))
+        # a pair with different row strides, or a misaligned slice, is copied instead of misread
+        odd = wide[:, :, 4:C + 4]
+        assert fused._kv_rows(odd) is None or odd.data_ptr() % 16 == 0
+        assert torch.equal(fused.attention(q, k, wide2[:, :1].expand(B, 77, 3 * C)[:, :, :C], H),
+                           fused.attention(q, k.contiguous(), wide2[:, :1].expand(B, 77, 3 * C)[:, :, :C].contiguous(), H))
+
+
+def test_staged_context_projections_equal_the_per_layer_projections():
+    """_Encoder.stage_context: the prompt tokens projected for all cross-attention layers by one GEMM per network
+    (U-Net: text + image-prompt tokens; ControlNet: all 81 tokens) give the same denoise output as 4 small GEMMs per layer."""
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance
+    from gaussianip_amd.guidance.ahds import AHDSSchedule
+    gd = StableDiffusionGuidance(GuidanceConfig(), schedule=AHDSSchedule(list(range(2400))))
+    assert gd.unet._ctx_pack is not None and gd.controlnet._ctx_pack is not None
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B = 2
+    lat = torch.randn(B, 4, 32, 32, device="cuda", generator=g)
+    ctrl = torch.rand(B, 3, 256, 256, device="cuda", generator=g)
+    emb = (torch.randn(3 * B, 81, 768, device="cuda", generator=g) * 0.1).half()
+    tt = torch.tensor([100, 700], device="cuda")
+    x3, c3, t3 = torch.cat([lat] * 3), torch.cat([ctrl] * 3), torch.cat([tt] * 3)
+    with torch.no_grad():
+        staged = gd.forward_unet(x3, c3, t3, emb, True)
+        packs = gd.unet._ctx_pack, gd.controlnet._ctx_pack
+        gd.unet._ctx_pack = gd.controlnet._ctx_pack = None
+        plain = gd.forward_unet(x3, c3, t3, emb, True)
+        gd.unet._ctx_pack, gd.controlnet._ctx_pack = packs
+    assert float((staged.float() - plain.float()).abs().max()) < 2e-3 * max(1.0, float(plain.float().abs().max()))
+    assert all(m.staged_kv is None for m in gd.unet.modules() if hasattr(m, "staged_kv"))     # every staged entry was consumed
