@@ -65,10 +65,7 @@ def _check_forward_scene(oracle, sc, cam, H, W, sh_degree, bg=(0.0, 0.0, 0.0), n
     # ---- integer buffers: bit-exact ----
     assert np.array_equal(radii[0].cpu().numpy(), o_radii), "radii"
     keys, vals, ranges, tt, nc = ro.binning()
-    rec_u = sv["records_u32"][0].cpu().numpy()
-    assert np.array_equal(rec_u[:, 7].astype(np.uint32), tt), "tiles_touched"
     hdr = sv["header"].cpu().numpy()
-    assert int(hdr[1]) == Rn and int(hdr[2]) == 0, "num_rendered / overflow"
     geom = ro.geom()
     rec_f = sv["records"][0].cpu().numpy()
     vis = o_radii > 0
@@ -76,18 +73,58 @@ def _check_forward_scene(oracle, sc, cam, H, W, sh_degree, bg=(0.0, 0.0, 0.0), n
     assert np.array_equal(rec_f[vis, 2].view(np.uint32), geom["depths"][vis].view(np.uint32)), "depth bits"
     assert np.array_equal(rec_f[vis, 4:7].view(np.uint32), geom["conic_opacity"][vis, :3].view(np.uint32)), "conic bits"
     assert np.array_equal(rec_f[vis, 8:11].view(np.uint32), geom["rgb"][vis].view(np.uint32)), "rgb bits"
-    my_keys = sv["keys"][:Rn].cpu().numpy().view(np.uint64)
-    assert np.array_equal((my_keys & np.uint64(0xffffffff)).astype(np.uint32), vals), "point_list"
-    assert np.array_equal(my_keys >> np.uint64(32), keys & np.uint64(0xffffffff)), "sorted depth keys"
-    ts = sv["tile_start"].cpu().numpy().astype(np.int64)
-    cnt = (ranges[:, 1].astype(np.int64) - ranges[:, 0].astype(np.int64))
-    assert np.array_equal(ts[1:] - ts[:-1], cnt), "per-tile counts"
-    ne = cnt > 0
-    assert np.array_equal(ts[:-1][ne], ranges[ne, 0].astype(np.int64)), "ranges.x"
-    assert np.array_equal(ts[1:][ne], ranges[ne, 1].astype(np.int64)), "ranges.y"
+    nc_expected = compare_tile_lists(sv, hdr, geom, keys, vals, ranges, tt, nc, H, W)
     # ---- images ----
-    _assert_images(ro, color[0], depth[0], alpha[0], o_color, o_depth, o_alpha, sv["n_contrib"][0], nc, nc_mismatch_frac)
+    _assert_images(ro, color[0], depth[0], alpha[0], o_color, o_depth, o_alpha, sv["n_contrib"][0], nc_expected, nc_mismatch_frac)
     return Rn, ro
+
+
+def compare_tile_lists(sv, hdr, geom, keys, vals, ranges, tt, nc, H, W, min_keep=0.5):
+    """The per-tile lists against the oracle's (= the fork's sorted (tile | depth) key / value buffers).  The library makes
+    instances only for the tiles the alpha >= 1/255 region of a Gaussian can reach, so its lists are the oracle's lists
+    WITHOUT some entries; asserted here, bit-exactly:
+      * the kept entries are the oracle's, in the oracle's order (same Gaussian ids, same depth keys, tile by tile);
+      * every dropped entry is dead: at no pixel of its tile does it pass the fork's alpha >= 1/255 test (brute force over
+        the 256 pixels with the oracle's conic / opacity), and the drop rate is plausible (never more than half);
+      * tiles_touched / num_rendered / the ranges are those of the kept lists.
+    Returns the oracle's n_contrib image re-expressed as positions in the kept lists."""
+    P = tt.shape[0]
+    tiles_x = (W + 15) // 16
+    T = ranges.shape[0]
+    ts = sv["tile_start"].cpu().numpy().astype(np.int64)
+    Rg = int(hdr[1])
+    assert int(hdr[2]) == 0 and ts[-1] == Rg, "overflow / num_rendered"
+    my_keys = sv["keys"][:Rg].cpu().numpy().view(np.uint64)
+    g_idx = (my_keys & np.uint64(0xffffffff)).astype(np.int64)
+    g_tile = np.repeat(np.arange(T, dtype=np.int64), ts[1:] - ts[:-1])
+    o_tile = (keys >> np.uint64(32)).astype(np.int64)
+    o_idx = vals.astype(np.int64)
+    o_pair, g_pair = o_tile * P + o_idx, g_tile * P + g_idx
+    kept = np.isin(o_pair, g_pair)
+    assert kept.sum() == Rg and np.array_equal(o_pair[kept], g_pair), "kept entries = the oracle's entries, in its order"
+    assert np.array_equal(my_keys >> np.uint64(32), (keys & np.uint64(0xffffffff))[kept]), "sorted depth keys"
+    assert Rg >= min_keep * max(len(o_pair), 1), "implausible drop rate"
+    rec_u = sv["records_u32"][0].cpu().numpy()
+    assert np.array_equal(rec_u[:, 7].astype(np.int64), np.bincount(g_idx, minlength=P)), "tiles_touched of the kept lists"
+    # dropped entries are dead (float64 evaluation of the fork's test on every pixel of the tile, no margin needed: the
+    # library's bound is conservative by > 1 %)
+    d = np.flatnonzero(~kept)
+    if d.size:
+        co = geom["conic_opacity"][o_idx[d]].astype(np.float64)
+        mx, my = geom["means2D"][o_idx[d], 0].astype(np.float64), geom["means2D"][o_idx[d], 1].astype(np.float64)
+        x0, y0 = (o_tile[d] % tiles_x) * 16.0, (o_tile[d] // tiles_x) * 16.0
+        off = np.arange(16, dtype=np.float64)
+        dx = (mx - x0)[:, None, None] - off[None, None, :]
+        dy = (my - y0)[:, None, None] - off[None, :, None]
+        power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+        a = np.minimum(0.99, co[:, 3, None, None] * np.exp(np.minimum(power, 0.0)))
+        assert not ((power <= 0) & (a >= 1.0 / 255.0)).any(), "a dropped instance would have contributed"
+    # n_contrib: position of the last contributor, counted in the kept list of its tile
+    ck = np.concatenate([[0], np.cumsum(kept)])
+    tile_of_pixel = (np.arange(H)[:, None] // 16) * tiles_x + (np.arange(W)[None, :] // 16)
+    lo = ranges[tile_of_pixel, 0].astype(np.int64)
+    lo = np.where(nc > 0, lo, 0)
+    return (ck[lo + nc.astype(np.int64)] - ck[lo]).astype(np.uint32)
 
 
 KNIFE_EDGE = 2e-5

@@ -96,3 +96,40 @@ count([(0.0, 15.0, 4.0 * by, 4.0 * by + 3) for by in range(4)], "bands 16x4")
 count([(8.0 * bx, 8.0 * bx + 7, 4.0 * by, 4.0 * by + 3) for by in range(4) for bx in range(2)], "blocks 8x4")
 alive = (t2 > 0)
 print("entries with t2 > 0: %.3f" % alive.mean())
+
+# ---- tile-level: instances under the reference rect / the tight extent rect / the exact tile-ellipse test
+P_ = g["means2D"].shape[0]
+mx, my = g["means2D"][:, 0].astype(np.float64), g["means2D"][:, 1].astype(np.float64)
+A_, B_, C_, o_ = (g["conic_opacity"][:, k].astype(np.float64) for k in range(4))
+vis = tt > 0
+t2_ = 2.0 * np.log(np.maximum(255.0 * o_, 1e-30)) + 0.02
+det_ = A_ * C_ - B_ * B_
+hx_ = np.sqrt(np.maximum(t2_ / det_ * C_, 0)) * 1.01 + 0.05
+hy_ = np.sqrt(np.maximum(t2_ / det_ * A_, 0)) * 1.01 + 0.05
+# the reference radius from the conic's inverse (cov2D = inverse of the conic matrix)
+ca, cb, cc = C_ / det_, -B_ / det_, A_ / det_
+mid = 0.5 * (ca + cc)
+lam1 = mid + np.sqrt(np.maximum(0.1, mid * mid - (ca * cc - cb * cb)))
+rad = np.ceil(3.0 * np.sqrt(lam1))
+def rect(rx, ry):
+    x0 = np.clip(((mx - rx) / 16).astype(np.int64), 0, tiles_x); y0 = np.clip(((my - ry) / 16).astype(np.int64), 0, H // 16)
+    x1 = np.clip(((mx + rx + 15) / 16).astype(np.int64), 0, tiles_x); y1 = np.clip(((my + ry + 15) / 16).astype(np.int64), 0, H // 16)
+    return x0, y0, x1, y1
+x0, y0, x1, y1 = rect(rad, rad)
+ref_n = ((x1 - x0) * (y1 - y0))[vis].sum()
+# tight: tiles whose pixel range [16 t, 16 t + 15] meets [m - h, m + h], inside the reference rect
+tx0 = np.maximum(x0, np.floor((mx - hx_) / 16).astype(np.int64)); tx1 = np.minimum(x1, np.floor((mx + hx_) / 16).astype(np.int64) + 1)
+ty0 = np.maximum(y0, np.floor((my - hy_) / 16).astype(np.int64)); ty1 = np.minimum(y1, np.floor((my + hy_) / 16).astype(np.int64) + 1)
+tight_n = (np.maximum(tx1 - tx0, 0) * np.maximum(ty1 - ty0, 0))[vis & (t2_ > 0)].sum()
+print("instances: reference rect %d (oracle %d), tight extent rect %d (%.3f)" % (ref_n, R, tight_n, tight_n / ref_n))
+# exact: per instance of the oracle list, min of q over the tile's pixel rectangle
+X0, X1, Y0, Y1 = 0.0 - cx, 15.0 - cx, 0.0 - cy, 15.0 - cy
+q = lambda x, y: A * x * x + 2 * B * x * y + C * y * y
+inside = (X0 <= 0) & (X1 >= 0) & (Y0 <= 0) & (Y1 >= 0)
+cand = []
+for xe in (X0, X1):
+    ys = np.clip(-B * xe / C, Y0, Y1); cand.append(q(xe, ys))
+for ye in (Y0, Y1):
+    xs = np.clip(-B * ye / A, X0, X1); cand.append(q(xs, ye))
+qmin = np.where(inside, 0.0, np.minimum.reduce(cand))
+print("           exact tile / ellipse test %d (%.3f)" % (int(((t2 > 0) & (qmin <= t2)).sum()), ((t2 > 0) & (qmin <= t2)).sum() / R))
