@@ -131,7 +131,8 @@ typedef struct GipRasterGradsOut {
 /* Status header written by forward at the start of the state buffer (16 x u32). */
 typedef struct GipRasterHeader {
   uint32_t abi_version;
-  uint32_t num_rendered;   /* total (tile, Gaussian) instances required, over all views */
+  uint32_t num_rendered;   /* total (tile, Gaussian) instances required, over all views (of the rectangles described
+                              at the record layout below: <= the fork's num_rendered) */
   uint32_t overflow;       /* 1 if num_rendered > capacity: outputs are invalid, re-run with more */
   uint32_t max_tile_count; /* longest per-tile list */
   uint32_t num_visible;    /* Gaussians with radii > 0, over all views */
@@ -173,9 +174,12 @@ typedef struct GipRasterStateLayout {
  *   float  depth       view-space z
  *   float  opacity
  *   float  conic_a, conic_b, conic_c
- *   uint32 tiles_touched
+ *   uint32 tiles_touched   instances made for this Gaussian = area of the rectangle below.  NOT the fork's count: the
+ *                          fork's 3-sigma rectangle is intersected with the extent of the alpha >= 1/255 region
+ *                          (|dx| <= sqrt(2 ln(255 opacity) cov_xx), same for y): tiles outside it cannot pass the
+ *                          fork's alpha test at any pixel, so no output depends on them
  *   float  r, g, b     colour after SH / clamp
- *   int32  radius
+ *   int32  radius          the fork's ceil(3 sigma_max) (the `radii` output / visibility), independent of the above
  *   uint32 rect_min    (x | y << 16) in tiles
  *   uint32 rect_max    (x | y << 16) in tiles, exclusive
  *   uint32 clamped     bit0..2 = colour channel clamped at 0
