@@ -139,21 +139,29 @@ static int after_launch(const GipRasterConfig* c, hipStream_t s) {
 
 namespace {
 struct StageTimer {
-  hipStream_t s; float* out; hipEvent_t ev[2 * GIP_NUM_STAGES]; bool used[GIP_NUM_STAGES]; bool ok;
-  StageTimer(hipStream_t s_, float* out_) : s(s_), out(out_), ok(true) {
+  hipStream_t s; float* out; hipEvent_t ev[2 * GIP_NUM_STAGES]; bool used[GIP_NUM_STAGES]; bool ok; int created;
+  StageTimer(hipStream_t s_, float* out_) : s(s_), out(out_), ok(true), created(0) {
     for (int i = 0; i < GIP_NUM_STAGES; i++) used[i] = false;
-    if (out) for (int i = 0; i < 2 * GIP_NUM_STAGES; i++) ok = ok && hipEventCreate(&ev[i]) == hipSuccess;
+    if (out)
+      for (int i = 0; i < 2 * GIP_NUM_STAGES && ok; i++) {
+        ok = hipEventCreate(&ev[i]) == hipSuccess;
+        if (ok) created++;
+      }
   }
-  void begin(int st) { if (out && ok) { hipEventRecord(ev[2 * st], s); used[st] = true; } }
-  void end(int st) { if (out && ok) hipEventRecord(ev[2 * st + 1], s); }
+  void begin(int st) { if (out && ok) { ok = hipEventRecord(ev[2 * st], s) == hipSuccess; used[st] = true; } }
+  void end(int st) { if (out && ok) ok = hipEventRecord(ev[2 * st + 1], s) == hipSuccess; }
   int finish() {
     if (!out) return GIP_OK;
     int rc = GIP_OK;
     if (!ok || hipStreamSynchronize(s) != hipSuccess) rc = GIP_ERR_HIP;
     for (int i = 0; i < GIP_NUM_STAGES; i++) {
-      if (rc == GIP_OK && used[i]) { float ms = 0.f; hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]); out[i] = ms; }
+      if (rc == GIP_OK && used[i]) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = GIP_ERR_HIP;
+        out[i] = ms;
+      }
     }
-    if (ok) for (int i = 0; i < 2 * GIP_NUM_STAGES; i++) hipEventDestroy(ev[i]);
+    for (int i = 0; i < created; i++) (void)hipEventDestroy(ev[i]);
     return rc;
   }
 };
