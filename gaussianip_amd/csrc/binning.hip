@@ -261,11 +261,11 @@ gip_scatter_kernel(GipKernelParams kp, const GipRecord* __restrict__ records, co
                    uint32_t* __restrict__ inst_offset, unsigned long long* __restrict__ keys) {
   const int v = blockIdx.y;
   const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
-  uint32_t tiles = 0, rmin = 0, rmax = 0, dbits = 0;
+  uint32_t tiles = 0, rmin = 0, rmax = 0, dbits = 0, tmask = 0;
   if (idx < kp.P) {
     const uint4* rp = reinterpret_cast<const uint4*>(records + (size_t)v * kp.P + idx);
     const uint4 q0 = rp[0], q1 = rp[1], q3 = rp[3];
-    dbits = q0.z; tiles = q1.w; rmin = q3.x; rmax = q3.y;
+    dbits = q0.z; tiles = q1.w; rmin = q3.x; rmax = q3.y; tmask = q3.w;
   }
   // exclusive prefix of tiles_touched inside the workgroup
   __shared__ uint32_t s_wave[4];
@@ -286,9 +286,12 @@ gip_scatter_kernel(GipKernelParams kp, const GipRecord* __restrict__ records, co
   uint4 s1 = make_uint4(0, 0, 0, 0);
   if (tiles > 4) s1 = sp[1];
   const uint32_t slots[GIP_SLOTS] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-  int k = 0;
+  const int area = (rmaxx - rminx) * (rmaxy - rminy);
+  int k = -1, kt = 0;                                  // k: instance number, kt: tile of the rectangle
   for (int ty = rminy; ty < rmaxy; ty++)
-    for (int tx = rminx; tx < rmaxx; tx++, k++) {
+    for (int tx = rminx; tx < rmaxx; tx++, kt++) {
+      if (!gip_rect_has(tmask, area, kt)) continue;
+      k++;
       const size_t t = tbase + ty * kp.tiles_x + tx;
       uint32_t slot;
       if (k < GIP_SLOTS) {

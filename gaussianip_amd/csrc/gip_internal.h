@@ -18,8 +18,18 @@ struct __attribute__((aligned(16))) GipRecord {
   float x, y, depth, opacity;           // q0
   float ca, cb, cc; uint32_t tiles;     // q1
   float r, g, b; int32_t radius;        // q2
-  uint32_t rmin, rmax, clamped, pad;    // q3  (rect in tiles: x | y << 16; max exclusive)
+  uint32_t rmin, rmax, clamped, tmask;  // q3  (rect in tiles: x | y << 16; max exclusive; tmask: see gip_rect_has)
 };
+
+// Instances of a Gaussian: the tiles of its rectangle whose bit is set in `tmask` (bit k = tile k of the rectangle in
+// row-major order) when the rectangle has at most GIP_MASK_TILES tiles; every tile of a larger rectangle.
+#define GIP_MASK_TILES 32
+__host__ __device__ inline bool gip_rect_has(uint32_t tmask, int area, int k) { return area > GIP_MASK_TILES || ((tmask >> k) & 1u); }
+// index of tile k among the Gaussian's instances (its row / slot number)
+__host__ __device__ inline int gip_rect_rank(uint32_t tmask, int area, int k) {
+  return area > GIP_MASK_TILES ? k : __builtin_popcount(tmask & ((1u << k) - 1u));
+}
+
 static_assert(sizeof(GipRecord) == GIP_RECORD_BYTES, "record size");
 
 struct GipViewConst {           // per-view host scalars, passed by value in kernel args

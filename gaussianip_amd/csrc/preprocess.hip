@@ -72,7 +72,7 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
   rec.x = rec.y = rec.depth = rec.opacity = 0.f;
   rec.ca = rec.cb = rec.cc = 0.f; rec.tiles = 0;
   rec.r = rec.g = rec.b = 0.f; rec.radius = 0;
-  rec.rmin = rec.rmax = rec.clamped = rec.pad = 0;
+  rec.rmin = rec.rmax = rec.clamped = 0; rec.tmask = 0xffffffffu;
 
   if (idx < kp.P) {
     const float p0 = means3D[3 * idx], p1 = means3D[3 * idx + 1], p2 = means3D[3 * idx + 2];
@@ -185,10 +185,52 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
         }
       }
     }
-    radii[(size_t)v * kp.P + idx] = rec.radius;
+    // ... and, for rectangles of up to GIP_MASK_TILES tiles, only the tiles the ellipse itself reaches (the rectangle's
+    // corners usually lie outside): the minimum of q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 over the tile's pixel box (0 when
+    // the centre is inside, else on an edge, at the clamped 1-D minimiser) against t2, with the box grown by 0.05 px and
+    // t2 by 2 %.  (Bench scene: another 12 % fewer instances.)  Done last, from the record alone, so that nothing else is
+    // live across the loop (the kernel must stay under 64 VGPRs: two 1024-thread workgroups per CU).
     float4* dst = reinterpret_cast<float4*>(records + (size_t)v * kp.P + idx);
-    const float4* src = reinterpret_cast<const float4*>(&rec);
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    {
+      const float4* src = reinterpret_cast<const float4*>(&rec);
+      dst[0] = src[0]; dst[2] = src[2];                        // position / depth / opacity and colour / radius are final
+      radii[(size_t)v * kp.P + idx] = rec.radius;
+    }
+    if (rec.tiles > 1u && rec.tiles <= (uint32_t)GIP_MASK_TILES) {
+      const int rminx = (int)(rec.rmin & 0xffffu), rminy = (int)(rec.rmin >> 16);
+      const int rmaxx = (int)(rec.rmax & 0xffffu), rmaxy = (int)(rec.rmax >> 16);
+      const float qa = rec.ca, qb = rec.cb, qc = rec.cc, tq = (2.0f * __logf(255.0f * rec.opacity) + 0.02f) * 1.02f;
+      // x* = ia y on a horizontal edge, y* = ic x on a vertical one (v_rcp_f32: the position of a minimum needs no more)
+      const float ia = -qb * __builtin_amdgcn_rcpf(qa), ic = -qb * __builtin_amdgcn_rcpf(qc), qb2 = 2.f * qb;
+      uint32_t m = 0;
+      int k = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+      for (int ty = rminy; ty < rmaxy; ty++) {
+        const float Y0 = (float)(ty * GIP_TILE) - 0.05f - rec.y, Y1 = Y0 + (float)(GIP_TILE - 1) + 0.1f;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int tx = rminx; tx < rmaxx; tx++, k++) {
+          const float X0 = (float)(tx * GIP_TILE) - 0.05f - rec.x, X1 = X0 + (float)(GIP_TILE - 1) + 0.1f;
+          float qmin = 0.f;
+          if (!(X0 <= 0.f && X1 >= 0.f && Y0 <= 0.f && Y1 >= 0.f)) {
+            float y = fminf(fmaxf(ic * X0, Y0), Y1);
+            qmin = (qa * X0 + qb2 * y) * X0 + qc * y * y;
+            y = fminf(fmaxf(ic * X1, Y0), Y1);
+            qmin = fminf(qmin, (qa * X1 + qb2 * y) * X1 + qc * y * y);
+            float x = fminf(fmaxf(ia * Y0, X0), X1);
+            qmin = fminf(qmin, (qa * x + qb2 * Y0) * x + qc * Y0 * Y0);
+            x = fminf(fmaxf(ia * Y1, X0), X1);
+            qmin = fminf(qmin, (qa * x + qb2 * Y1) * x + qc * Y1 * Y1);
+          }
+          if (qmin <= tq) m |= 1u << k;
+        }
+      }
+      rec.tmask = m;
+      rec.tiles = (uint32_t)__builtin_popcount(m);
+    }
+    {
+      const float4* src = reinterpret_cast<const float4*>(&rec);
+      dst[1] = src[1]; dst[3] = src[3];                        // conic + tiles_touched, rectangle + tile mask
+    }
   }
 
   // ---- per-tile histogram, aggregated per workgroup ----
@@ -215,11 +257,14 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
 #pragma unroll
     for (int k = 0; k < GIP_SLOTS; k++) slots[k] = 0;
     if (ntiles > 0) {
-      int k = 0;
+      const int area = (rmaxx - rminx) * (rmaxy - rminy);
+      int k = 0, kt = 0;                                            // k: instance number, kt: tile of the rectangle
       for (int ty = rminy; ty < rmaxy; ty++)
-        for (int tx = rminx; tx < rmaxx; tx++, k++) {
+        for (int tx = rminx; tx < rmaxx; tx++, kt++) {
+          if (!gip_rect_has(rec.tmask, area, kt)) continue;
+          const int k_cur = k++;
           const uint32_t tile = (uint32_t)(ty * gx + tx);
-          if (k < GIP_SLOTS) {
+          if (k_cur < GIP_SLOTS) {
             uint32_t h = (tile * 2654435761u) >> 19;                 // 13 bits
             for (;;) {
               const uint32_t prev = atomicCAS(&s_key[h], 0u, tile + 1u);
@@ -228,7 +273,7 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
             }
             const uint32_t packed = (h << 16) | atomicAdd(&s_cnt[h], 1u);   // rank < 8192
 #pragma unroll
-            for (int kk = 0; kk < GIP_SLOTS; kk++) if (kk == k) slots[kk] = packed;
+            for (int kk = 0; kk < GIP_SLOTS; kk++) if (kk == k_cur) slots[kk] = packed;
           } else {
             atomicAdd(&tcb[tile], 1u);
           }

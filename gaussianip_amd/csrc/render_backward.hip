@@ -222,8 +222,9 @@ gip_render_backward_kernel(GipKernelParams kp, const GipRasterHeader* __restrict
         s_xy[lane] = make_float2(q0.x, q0.y);
         s_con[lane] = make_float4(q1.x * -0.72134752044448170f, q1.y * -1.4426950408889634f, q1.z * -0.72134752044448170f, q0.w);
         s_col[lane] = make_float4(q2.x, q2.y, q2.z, q0.z);
-        const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff;
-        row = rio + (ty - rminy) * (rmaxx - rminx) + (tx - rminx);
+        const uint32_t rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff, rmaxy = q3.y >> 16;
+        row = rio + (uint32_t)gip_rect_rank(q3.w, (int)((rmaxx - rminx) * (rmaxy - rminy)),
+                                            (int)((ty - rminy) * (rmaxx - rminx) + (tx - rminx)));
         if (row >= kp.capacity) row = 0xffffffffu;
         mask = 0xf;
         const float t2 = 2.0f * __logf(255.0f * q0.w) + 0.02f;

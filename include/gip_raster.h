@@ -174,7 +174,7 @@ typedef struct GipRasterStateLayout {
  *   float  depth       view-space z
  *   float  opacity
  *   float  conic_a, conic_b, conic_c
- *   uint32 tiles_touched   instances made for this Gaussian = area of the rectangle below.  NOT the fork's count: the
+ *   uint32 tiles_touched   instances made for this Gaussian = tiles of the rectangle below that are set in tile_mask.  NOT the fork's count: the
  *                          fork's 3-sigma rectangle is intersected with the extent of the alpha >= 1/255 region
  *                          (|dx| <= sqrt(2 ln(255 opacity) cov_xx), same for y): tiles outside it cannot pass the
  *                          fork's alpha test at any pixel, so no output depends on them
@@ -183,7 +183,8 @@ typedef struct GipRasterStateLayout {
  *   uint32 rect_min    (x | y << 16) in tiles
  *   uint32 rect_max    (x | y << 16) in tiles, exclusive
  *   uint32 clamped     bit0..2 = colour channel clamped at 0
- *   uint32 pad
+ *   uint32 tile_mask   rectangles of at most 32 tiles: bit k set = tile k of the rectangle (row-major) is an instance
+ *                      (the others cannot pass the alpha test either: the ellipse misses them); larger rectangles: all
  */
 
 int gip_abi_version(void);
