@@ -43,7 +43,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
 // (nn.Linear / 1x1 convolution on the NHWC token view; H = 1, W = M).  GEGLU (TAPS = 1 only): w has 2 * Cout rows
 // [value | gate]; a workgroup computes 64 value and the matching 64 gate columns and writes value * gelu(gate).
 template <int BN, int STAGES, int TAPS, bool GEGLU>
-__global__ void __launch_bounds__(CV_THREADS, STAGES == 2 ? 2 : 1)
+__global__ void __launch_bounds__(CV_THREADS, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom) {
@@ -173,36 +173,20 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   auto advance = [&]() {
     if (++cb == cblocks) { cb = 0; ++tap; }
   };
-  if constexpr (STAGES == 2) {
-    stage(tap, cb, 0);
-    advance();
+  // two LDS stages: the DMA of step t + 1 is in flight while the MFMAs of step t run; one wait + barrier per step.  (A
+  // three-stage single-workgroup-per-CU variant and BK = 32 variants with 3 / 4 stages and counted vmcnt were measured
+  // slower: tools/experiments/conv3x3_bk32_multistage.hip.txt holds both.)
+  static_assert(STAGES == 2, "one pipeline depth is built");
+  stage(tap, cb, 0);
+  advance();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
+    compute(smem + buf * STAGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < KT; kt++) {
-      const int buf = kt & 1;
-      if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
-      compute(smem + buf * STAGE);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else {
-    // three stages, one workgroup per CU: the DMA of step t+2 is issued before the math of step t, the wait at the top
-    // of a step is COUNTED (the newest tile stays in flight across the barrier), one raw s_barrier per step
-    constexpr int NDMA = 4 + B_ROUNDS;
-    stage(tap, cb, 0);
-    advance();
-    if (KT > 1) { stage(tap, cb, 1); advance(); }
-    int buf = 0, fill = 2;
-    for (int kt = 0; kt < KT; kt++) {
-      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 2 < KT) { stage(tap, cb, fill); advance(); }
-      compute(smem + buf * STAGE);
-      buf = buf == 2 ? 0 : buf + 1;
-      fill = fill == 2 ? 0 : fill + 1;
-    }
   }
 
   // ---- epilogue: lane holds out[pixel = lane & 15][co = (lane >> 4) * 4 + 0..3] of each 16x16 tile ----
@@ -300,7 +284,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   // split-K when the output tiles cannot fill the chip and a workspace was handed in: aim at ~2 workgroups per CU
   int ksplit = 1;
   const int tiles = m_tiles * n_tiles, KT = TAPS * (Cin / CV_BK);
-  if (!GEGLU && STAGES == 2 && workspace && tiles < 256) {
+  if (!GEGLU && workspace && tiles < 256) {
     ksplit = (512 + tiles - 1) / tiles;
     if (ksplit > KT / 8) ksplit = KT / 8;
     if (ksplit > 16) ksplit = 16;
@@ -328,11 +312,7 @@ extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
   if (!x || !w || !out || N < 1 || H < 1 || W < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 4 || (Cout & 3)) return 1;
   if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;   // 32-bit byte offsets
   hipStream_t s = (hipStream_t)stream;
-  static const int stages = [] { const char* e = getenv("GIP_CONV_STAGES"); return e && e[0] == '3' ? 3 : 2; }();
   const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
-  if (stages == 3)
-    return wide ? launch<160, 3, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s)
-                : launch<128, 3, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s);
   return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes)
               : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes);
 }
