@@ -18,9 +18,13 @@ _ws = {}
 
 
 def _workspace(dev, nbytes):
-    w = _ws.get(dev)
+    """Scratch of the split-K / GroupNorm kernels, one per (device, stream): work enqueued on different streams (the
+    ControlNet runs beside the U-Net encoder) must not share it."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    w = _ws.get(key)
     if w is None or w.numel() < nbytes:
-        w = _ws[dev] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(torch.cuda.current_stream(dev)):
+            w = _ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
     return w
 
 

@@ -22,6 +22,7 @@ from .networks import IP_TOKENS, TEXT_TOKENS, ControlNet, UNet, VAEEncoder, init
 
 
 _NO_SHARED_PREFIX = __import__("os").environ.get("GIP_SHARE_PREFIX", "1") == "0"      # A/B switch (tools/)
+_TWO_STREAMS = __import__("os").environ.get("GIP_GUIDANCE_STREAMS", "2") != "1"    # A/B switch: ControlNet beside the U-Net encoder
 
 
 @dataclass
@@ -210,10 +211,38 @@ class StableDiffusionGuidance:
         with torch.autocast("cuda", enabled=False):
             if not use_pose_controlnet:
                 return self.unet(x, t, ctx, replicas=replicas).to(noisy_latents.dtype)
-            if control_embedding is None:
-                control_embedding = self.embed_control(control_img)
-            down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=control_embedding, replicas=replicas)
-            return self.unet(x, t, ctx, down, mid, replicas=replicas).to(noisy_latents.dtype)
+            if not (x.is_cuda and _TWO_STREAMS):
+                if control_embedding is None:
+                    control_embedding = self.embed_control(control_img)
+                down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=control_embedding, replicas=replicas)
+                return self.unet(x, t, ctx, down, mid, replicas=replicas).to(noisy_latents.dtype)
+            # The ControlNet and the U-Net's encoder + mid block are independent (the 13 residuals enter the U-Net after its
+            # mid block, ipa_guidance.py:331-352): the ControlNet is enqueued on a second HIP stream and the U-Net joins it
+            # where it needs the residuals.  Many layers of both have too few tiles to fill 256 CUs on their own (0.47-0.94
+            # of a round at 16^2 / 32^2), so the two kernel sequences fill each other's idle CUs.  Same kernels, same values.
+            main = torch.cuda.current_stream(x.device)
+            side = self._side_stream(x.device)
+            side.wait_stream(main)                     # x, ctx, the pose maps were produced on the main stream
+            with torch.cuda.stream(side):
+                emb = self.embed_control(control_img) if control_embedding is None else control_embedding
+                down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=emb, replicas=replicas)
+
+            def join():
+                main.wait_stream(side)
+                for r in list(down) + [mid]:
+                    r.record_stream(main)              # allocated on the side stream, consumed (and freed) on the main one
+                return down, mid
+            return self.unet(x, t, ctx, join, None, replicas=replicas).to(noisy_latents.dtype)
+
+    _side = None
+
+    def _side_stream(self, dev):
+        if self._side is None:
+            self._side = {}
+        st = self._side.get(dev)
+        if st is None:
+            st = self._side[dev] = torch.cuda.Stream(device=dev)
+        return st
 
     def encode_images(self, imgs, generator=None):
         x = (imgs * 2.0 - 1.0).to(self.weights_dtype)

@@ -423,6 +423,8 @@ class UNet(_Encoder):
         b = x.shape[0] // replicas
         h, skips = self.encode(self.conv_in(x[:b] if replicas > 1 else x), temb, ctx, replicas)
         h = self.mid(h, temb, ctx)
+        if callable(down_residuals):          # the ControlNet ran on another stream beside the encoder: join here
+            down_residuals, mid_residual = down_residuals()
         if down_residuals is not None:
             skips = [s + r for s, r in zip(skips, down_residuals)]
             h = h + mid_residual
