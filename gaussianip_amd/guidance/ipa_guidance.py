@@ -266,7 +266,7 @@ class StableDiffusionGuidance:
         return torch.cat([neg, pos, null], dim=0)
 
     def compute_grad_anpg(self, latents, control_img, t, prompt_utils, use_pose_controlnet, all_vis_all, elevation,
-                          azimuth, center, camera_distances, generator=None):
+                          azimuth, center, camera_distances, generator=None, control_embedding=None):
         B = elevation.shape[0]
         embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 3)
         assert embeds.shape[1] == TEXT_TOKENS + IP_TOKENS
@@ -275,7 +275,8 @@ class StableDiffusionGuidance:
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
             # the three branches share their pose maps: the ControlNet hint stem runs on the B distinct maps and tiles
             noise_pred = self.forward_unet(torch.cat([latents_noisy] * 3, dim=0), control_img,
-                                           torch.cat([t] * 3), embeds, use_pose_controlnet, replicas=3)
+                                           torch.cat([t] * 3), embeds, use_pose_controlnet, replicas=3,
+                                           control_embedding=control_embedding)
             direction = sds.anpg_direction(noise_pred, t, self.cfg.guidance_scale)
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
         if self.cfg.grad_clip_pixel:
@@ -283,13 +284,14 @@ class StableDiffusionGuidance:
         return grad, {"t_orig": t, "latents_noisy": latents_noisy, "noise_pred": noise_pred, "neg_guidance_weights": None}
 
     def compute_grad_sds(self, latents, control_img, t, prompt_utils, use_pose_controlnet, all_vis_all, elevation,
-                         azimuth, center, camera_distances, generator=None):
+                         azimuth, center, camera_distances, generator=None, control_embedding=None):
         embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 2)
         with torch.no_grad():
             noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
             noise_pred = self.forward_unet(torch.cat([latents_noisy] * 2, dim=0), control_img,
-                                           torch.cat([t] * 2), embeds, use_pose_controlnet, replicas=2)
+                                           torch.cat([t] * 2), embeds, use_pose_controlnet, replicas=2,
+                                           control_embedding=control_embedding)
             direction = sds.cfg_direction(noise_pred, noise, self.cfg.guidance_scale, self.cfg.guidance_rescale)
         # no per-pixel clip here: the reference applies grad_clip_pixel only on the ANPG path (:427-431 vs :513)
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
@@ -302,11 +304,18 @@ class StableDiffusionGuidance:
         B = rgb.shape[0]
         rgb_512 = F.interpolate(rgb.permute(0, 3, 1, 2), (512, 512), mode="bilinear", align_corners=False)
         control = control_img.permute(0, 3, 1, 2)
+        hint = None
+        if use_pose_controlnet and control.is_cuda and _TWO_STREAMS:
+            # the ControlNet's hint stem depends on the pose maps only: it runs on the side stream beside the VAE encoder
+            main, side = torch.cuda.current_stream(control.device), self._side_stream(control.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                hint = self.embed_control(control)       # consumed on the side stream (forward_unet)
         latents = self.encode_images(rgb_512.to(self.weights_dtype), generator)
         t = self.schedule.sample(step, B, self.device, generator)
         fn = self.compute_grad_anpg if self.cfg.use_anpg else self.compute_grad_sds
         grad, _ = fn(latents, control, t, prompt_utils, use_pose_controlnet, all_vis_all, elevation, azimuth, center,
-                     camera_distances, generator)
+                     camera_distances, generator, control_embedding=hint)
         loss_sds, grad = sds.sds_loss(latents, grad)
         return {"loss_sds": loss_sds, "grad_norm": grad.norm()}
 
