@@ -28,3 +28,33 @@ for f, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print("%-18s %9.3f ms %6.1f%% %7d" % (f, ns / nstep / 1e6, 100 * ns / tot, c // nstep))
 for n, c, ns in sorted(rows, key=lambda r: -r[2])[:top]:
     print("%8.3f ms %5d  %s" % (ns / nstep / 1e6, c // nstep, n[:130]))
+
+# ---- idle time: union of the kernel intervals over the steps against the wall time (what stream overlap could still fill)
+iv = db.execute("select start, end from kernels where start>=? and start<? order by start", (lo, hi)).fetchall()
+busy, cur_s, cur_e = 0, None, None
+gaps = []
+for s_, e_ in iv:
+    if cur_e is None or s_ > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_s
+            gaps.append(s_ - cur_e)
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+if cur_e is not None:
+    busy += cur_e - cur_s
+gaps.sort()
+ng = len(gaps)
+print("union of kernel intervals %.2f ms per step; idle %.2f ms per step in %d gaps (median %.1f us, p90 %.1f us, > 20 us: %.2f ms)" % (
+    busy / nstep / 1e6, sum(gaps) / nstep / 1e6, ng // nstep, gaps[ng // 2] / 1e3 if ng else 0, gaps[int(ng * 0.9)] / 1e3 if ng else 0,
+    sum(g_ for g_ in gaps if g_ > 20000) / nstep / 1e6))
+# the largest gaps and the kernels on either side (host-bound stretches show up here)
+named = db.execute("select start, end, name from kernels where start>=? and start<? order by start", (lo, hi)).fetchall()
+big, cur_e, prev = [], None, None
+for s_, e_, n_ in named:
+    if cur_e is not None and s_ > cur_e:
+        big.append((s_ - cur_e, prev, n_))
+    if cur_e is None or e_ > cur_e:
+        cur_e, prev = e_, n_
+for g_, a_, b_ in sorted(big, reverse=True)[:16]:
+    print("  gap %7.1f us   after %-60s before %s" % (g_ / 1e3, a_[:60], b_[:60]))

@@ -12,15 +12,16 @@ emb = torch.randn(3 * B, 81, 768, device=dev, dtype=torch.float16) * 0.1
 tt = torch.randint(20, 800, (3 * B,), device=dev)
 def run():
     with torch.no_grad():
-        return g.forward_unet(lat, ctrl, tt, emb, True)
+        return g.forward_unet(lat, ctrl, tt, emb, True, replicas=3)
 for _ in range(4):
     ref = run()
 torch.cuda.synchronize()
 def wall(fn, n=10):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-print("eager  %.2f ms" % wall(run))
+    h = time.perf_counter() - t0
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, h / n * 1e3
+print("eager  %.2f ms (host enqueue %.2f ms)" % wall(run))
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
@@ -30,4 +31,4 @@ graph = torch.cuda.CUDAGraph()
 with torch.cuda.graph(graph):
     out = run()
 graph.replay(); torch.cuda.synchronize()
-print("graph  %.2f ms" % wall(graph.replay), " max diff vs eager", float((out - ref).abs().max()))
+print("graph  %.2f ms (host enqueue %.2f ms)" % wall(graph.replay), " max diff vs eager", float((out - ref).abs().max()))
