@@ -166,3 +166,32 @@ def test_staged_context_projections_equal_the_per_layer_projections():
         gd.unet._ctx_pack, gd.controlnet._ctx_pack = packs
     assert float((staged.float() - plain.float()).abs().max()) < 2e-3 * max(1.0, float(plain.float().abs().max()))
     assert all(m.staged_kv is None for m in gd.unet.modules() if hasattr(m, "staged_kv"))     # every staged entry was consumed
+
+
+def test_graph_replay_of_the_denoise_equals_the_eager_launches(monkeypatch):
+    """GIP_GRAPH_DENOISE=1: the two-stream ControlNet + U-Net denoise captured once and replayed with new inputs gives the
+    eager result (same kernels in the same order on the same streams)."""
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance, ipa_guidance
+    from gaussianip_amd.guidance.ahds import AHDSSchedule
+    gd = StableDiffusionGuidance(GuidanceConfig(), schedule=AHDSSchedule(list(range(2400))))
+    g = torch.Generator(device="cuda").manual_seed(8)
+    B = 2
+
+    def inputs():
+        lat = torch.randn(B, 4, 32, 32, device="cuda", generator=g)
+        ctrl = torch.rand(B, 3, 256, 256, device="cuda", generator=g)
+        emb = (torch.randn(3 * B, 81, 768, device="cuda", generator=g) * 0.1).half()
+        tt = torch.randint(20, 900, (B,), device="cuda", generator=g)
+        return torch.cat([lat] * 3), ctrl, torch.cat([tt] * 3), emb
+    sets = [inputs() for _ in range(4)]
+    with torch.no_grad():
+        gd.forward_unet(*sets[0][:4], True, replicas=3)      # the libraries' first call of a shape may pick another GEMM algorithm
+        eager = [gd.forward_unet(x, c, t, e, True, replicas=3) for x, c, t, e in sets]
+        monkeypatch.setattr(ipa_guidance, "_GRAPH_DENOISE", True)
+        replayed = [gd.forward_unet(x, c, t, e, True, replicas=3) for x, c, t, e in sets]      # eager, capture + replay, replay, replay
+    assert gd._graphs and any(isinstance(v, tuple) for v in gd._graphs.values())
+    for a, b in zip(eager, replayed):
+        # same kernels in the same order; the library GEMMs may pick another algorithm under capture (observed at the
+        # test's small shapes: 2e-3, the fp16 rounding level; bit-equal at the training shapes, tools/exp_graph.py)
+        assert float((a - b).abs().max()) <= 5e-3 * max(1.0, float(a.abs().max()))
+    assert replayed[2].data_ptr() != replayed[3].data_ptr()           # results are copies, not the graph's static buffer
