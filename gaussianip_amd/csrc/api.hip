@@ -79,6 +79,7 @@ static void fill_params(const GipRasterConfig* c, const GipRasterStateLayout& L,
   kp->D = c->sh_degree; kp->M = c->sh_coeffs;
   kp->scale_modifier = c->scale_modifier;
   kp->capacity = (uint32_t)c->capacity;
+  kp->exact_lists = c->exact_lists ? 1 : 0;
   kp->ckpt_capacity = (uint32_t)(c->capacity / GIP_SEGMENT + 1);
   kp->seg_capacity = kp->ckpt_capacity + (uint32_t)(kp->V * kp->T);
   for (int v = 0; v < c->V; v++) {

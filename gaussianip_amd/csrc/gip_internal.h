@@ -45,6 +45,7 @@ struct GipKernelParams {
   uint32_t capacity;
   uint32_t seg_capacity;    // capacity / GIP_SEGMENT + V*T
   uint32_t ckpt_capacity;   // capacity / GIP_SEGMENT
+  int exact_lists;          // GipRasterConfig::exact_lists
   GipViewConst view[GIP_MAX_VIEWS];
 };
 

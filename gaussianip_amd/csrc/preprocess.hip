@@ -147,7 +147,7 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
         // render kernels' block masks).  A pair outside fails the fork's alpha test, so the dropped instances change no
         // output; radii / visibility keep the fork's 3-sigma definition.  (Bench scene: 14 % fewer instances.)
         int ntiles = ntiles_ref;
-        if (ntiles_ref != 0) {
+        if (ntiles_ref != 0 && !kp.exact_lists) {
           const float t2 = 2.0f * logf(255.0f * opacities[idx]) + 0.02f;
           if (t2 <= 0.f) {
             ntiles = 0;
@@ -196,7 +196,7 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
       dst[0] = src[0]; dst[2] = src[2];                        // position / depth / opacity and colour / radius are final
       radii[(size_t)v * kp.P + idx] = rec.radius;
     }
-    if (rec.tiles > 1u && rec.tiles <= (uint32_t)GIP_MASK_TILES) {
+    if (rec.tiles > 1u && rec.tiles <= (uint32_t)GIP_MASK_TILES && !kp.exact_lists) {
       const int rminx = (int)(rec.rmin & 0xffffu), rminy = (int)(rec.rmin >> 16);
       const int rmaxx = (int)(rec.rmax & 0xffffu), rmaxy = (int)(rec.rmax >> 16);
       const float qa = rec.ca, qb = rec.cb, qc = rec.cc, tq = (2.0f * __logf(255.0f * rec.opacity) + 0.02f) * 1.02f;

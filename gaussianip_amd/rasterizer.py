@@ -58,6 +58,12 @@ def _on_overflow():
     return os.environ.get("GIP_RASTER_ON_OVERFLOW", "zero")
 
 
+def _exact_lists():
+    """GIP_RASTER_EXACT_LISTS=1: every tile of the fork's 3-sigma rectangle gets its instance (tile / index buffers
+    bit-for-bit the fork's); default: only the tiles the alpha >= 1/255 region reaches (same outputs, 25 % fewer instances)."""
+    return os.environ.get("GIP_RASTER_EXACT_LISTS", "0") == "1"
+
+
 def _strict():
     return os.environ.get("GIP_RASTER_SYNC", "0") == "1"
 
@@ -114,6 +120,7 @@ def _make_config(P, V, H, W, sh_degree, M, scale_modifier, tanfovx, tanfovy, cap
         cfg.tanfovx[v] = float(tanfovx[v])
         cfg.tanfovy[v] = float(tanfovy[v])
     cfg.capacity = int(capacity)
+    cfg.exact_lists = 1 if _exact_lists() else 0
     return cfg
 
 

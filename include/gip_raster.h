@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIP_ABI_VERSION 2
+#define GIP_ABI_VERSION 3
 #define GIP_TILE 16            /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16 in the reference's rasterizer) */
 #define GIP_MAX_VIEWS 16       /* views per call */
 #define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
@@ -74,6 +74,12 @@ typedef struct GipRasterConfig {
   float tanfovy[GIP_MAX_VIEWS]; /* [host] per view */
   uint64_t capacity;      /* max number of (tile, Gaussian) instances (= num_rendered summed over views)
                              the state buffers can hold; overflow is flagged in the header */
+  int32_t exact_lists;    /* 0 (default): instances are made only for the tiles a Gaussian's alpha >= 1/255 region can
+                             reach (see the record layout below) — the tile / index buffers are then the fork's MINUS
+                             entries that cannot contribute, every output is unchanged.  1: every tile of the fork's
+                             3-sigma rectangle gets its instance: tiles_touched, num_rendered, the sorted key / value
+                             lists and the tile ranges are bit-for-bit the fork's (parity tests run both). */
+  int32_t reserved;
 } GipRasterConfig;
 
 /* Device inputs.  Exactly one of (shs, colors_precomp) and one of (scales+rotations, cov3D_precomp)

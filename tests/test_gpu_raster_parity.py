@@ -2,6 +2,8 @@
 
 Bars: tile / index buffers bit-exact; RGB / depth / alpha within 1e-4; gradients within 2e-3 of the
 largest gradient magnitude per tensor (the CUDA reference itself sums float atomics in arbitrary order)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -73,10 +75,32 @@ def _check_forward_scene(oracle, sc, cam, H, W, sh_degree, bg=(0.0, 0.0, 0.0), n
     assert np.array_equal(rec_f[vis, 2].view(np.uint32), geom["depths"][vis].view(np.uint32)), "depth bits"
     assert np.array_equal(rec_f[vis, 4:7].view(np.uint32), geom["conic_opacity"][vis, :3].view(np.uint32)), "conic bits"
     assert np.array_equal(rec_f[vis, 8:11].view(np.uint32), geom["rgb"][vis].view(np.uint32)), "rgb bits"
-    nc_expected = compare_tile_lists(sv, hdr, geom, keys, vals, ranges, tt, nc, H, W)
+    if os.environ.get("GIP_RASTER_EXACT_LISTS", "0") == "1":
+        exact_tile_lists(sv, hdr, keys, vals, ranges, tt)
+        nc_expected = nc
+    else:
+        nc_expected = compare_tile_lists(sv, hdr, geom, keys, vals, ranges, tt, nc, H, W)
     # ---- images ----
     _assert_images(ro, color[0], depth[0], alpha[0], o_color, o_depth, o_alpha, sv["n_contrib"][0], nc_expected, nc_mismatch_frac)
     return Rn, ro
+
+
+def exact_tile_lists(sv, hdr, keys, vals, ranges, tt):
+    """GIP_RASTER_EXACT_LISTS=1: tiles_touched, num_rendered, the sorted key / value lists and the tile ranges are the
+    oracle's (= the fork's buffers) bit for bit."""
+    Rn = len(vals)
+    rec_u = sv["records_u32"][0].cpu().numpy()
+    assert np.array_equal(rec_u[:, 7].astype(np.uint32), tt), "tiles_touched"
+    assert int(hdr[1]) == Rn and int(hdr[2]) == 0, "num_rendered / overflow"
+    my_keys = sv["keys"][:Rn].cpu().numpy().view(np.uint64)
+    assert np.array_equal((my_keys & np.uint64(0xffffffff)).astype(np.uint32), vals), "point_list"
+    assert np.array_equal(my_keys >> np.uint64(32), keys & np.uint64(0xffffffff)), "sorted depth keys"
+    ts = sv["tile_start"].cpu().numpy().astype(np.int64)
+    cnt = (ranges[:, 1].astype(np.int64) - ranges[:, 0].astype(np.int64))
+    assert np.array_equal(ts[1:] - ts[:-1], cnt), "per-tile counts"
+    ne = cnt > 0
+    assert np.array_equal(ts[:-1][ne], ranges[ne, 0].astype(np.int64)), "ranges.x"
+    assert np.array_equal(ts[1:][ne], ranges[ne, 1].astype(np.int64)), "ranges.y"
 
 
 def compare_tile_lists(sv, hdr, geom, keys, vals, ranges, tt, nc, H, W, min_keep=0.5):
@@ -166,6 +190,27 @@ def test_forward_parity(oracle, kind, P, H, W, seed, deg):
     assert R > 0
 
 
+@pytest.mark.parametrize("kind,P,H,W,seed,deg", [("stress", 3000, 80, 112, 2, 1), ("ball", 10000, 256, 256, 42, 0)])
+def test_forward_parity_exact_lists(oracle, monkeypatch, kind, P, H, W, seed, deg):
+    """GipRasterConfig::exact_lists (GIP_RASTER_EXACT_LISTS=1): every tile of the fork's 3-sigma rectangle gets its instance —
+    tiles_touched, num_rendered, the sorted (depth, index) lists, the ranges and n_contrib equal the oracle's bit for bit,
+    and the images are those of the default (culled) mode."""
+    from gaussianip_amd import rasterizer as R
+    monkeypatch.setenv("GIP_RASTER_EXACT_LISTS", "1")
+    Rn = _check_forward(oracle, kind, P, H, W, seed, deg, (5.0, 90.0, 1.8, 70.0), bg=(0.1, 0.2, 0.3))
+    sc = scenes.make_scene(kind, P, seed=seed, sh_degree=deg)
+    cam = scenes.camera(5.0, 90.0, 1.8, 70.0, H, W)
+    st = _settings(cam, H, W, (0.1, 0.2, 0.3), deg)
+    args = (_dev(sc["means3D"]), _dev(sc["opacities"]), [st])
+    kw = dict(shs=_dev(sc["shs"]), scales=_dev(sc["scales"]), rotations=_dev(sc["rotations"]))
+    (c1, r1, d1, a1), p1 = R.forward_with_state(*args, **kw)
+    monkeypatch.setenv("GIP_RASTER_EXACT_LISTS", "0")
+    (c0, r0, d0, a0), p0 = R.forward_with_state(*args, **kw)
+    torch.cuda.synchronize()
+    assert int(R.state_views(p1)["header"][1]) == Rn > int(R.state_views(p0)["header"][1])
+    assert torch.equal(r0, r1) and float((c0 - c1).abs().max()) < 2e-6 and float((a0 - a1).abs().max()) < 2e-6
+
+
 def test_forward_parity_close_camera_big_tiles(oracle):
     # camera inside the cloud: huge splats, near-plane culling, long per-tile lists (exercises the 8192 sort class)
     _check_forward(oracle, "stress", 6000, 96, 96, 7, 0, (10.0, 30.0, 0.35, 80.0))
@@ -237,6 +282,11 @@ def _check_backward(oracle, kind, P, H, W, seed, sh_degree, use_precomp=False, b
             close("rotations", t["rotations"].grad, go["rotations"],
                   floor=float(np.abs(go["scales"] * sc["scales"]).max()), bar=bar)
     return t, means2D
+
+
+def test_backward_parity_exact_lists(oracle, monkeypatch):
+    monkeypatch.setenv("GIP_RASTER_EXACT_LISTS", "1")
+    _check_backward(oracle, "stress", 2500, 96, 80, 12, 1)
 
 
 @pytest.mark.parametrize("kind,P,H,W,seed,deg", [("stress", 1500, 64, 64, 11, 0), ("stress", 2500, 96, 80, 12, 1),
