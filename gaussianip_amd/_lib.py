@@ -11,7 +11,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 
 GIP_MAX_VIEWS = 16
 GIP_RECORD_BYTES = 64
-GIP_PARTIAL_FLOATS = 16
+GIP_PARTIAL_FLOATS = 12
 GIP_OK = 0
 
 _vp = ctypes.c_void_p

@@ -42,7 +42,7 @@ extern "C" {
 #define GIP_TILE 16            /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16 in the reference's rasterizer) */
 #define GIP_MAX_VIEWS 16       /* views per call */
 #define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
-#define GIP_PARTIAL_FLOATS 16  /* per-(tile, Gaussian) gradient partial row, 64 bytes */
+#define GIP_PARTIAL_FLOATS 12  /* per-(tile, Gaussian) gradient partial row, 48 bytes (10 used) */
 #ifndef GIP_SEGMENT
 #define GIP_SEGMENT 64
 #endif

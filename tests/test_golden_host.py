@@ -262,7 +262,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     cfg = _lib.GipRasterConfig()
     cfg.P, cfg.V, cfg.H, cfg.W, cfg.sh_degree, cfg.sh_coeffs, cfg.capacity = 1000, 2, 64, 48, 0, 1, 1 << 16
     import ctypes
-    assert lib.gip_raster_state_bytes(ctypes.byref(cfg)) > 0 and lib.gip_raster_scratch_bytes(ctypes.byref(cfg)) == (1 << 16) * 64
+    assert lib.gip_raster_state_bytes(ctypes.byref(cfg)) > 0 and lib.gip_raster_scratch_bytes(ctypes.byref(cfg)) == (1 << 16) * 48
     cfg.V = 99
     assert lib.gip_raster_state_bytes(ctypes.byref(cfg)) == 0
     for header, loader in (("gip_knn.h", _lib.knn_lib), ("gip_nn.h", _lib.nn_lib), ("gip_model.h", _lib.model_lib), ("gip_pose.h", _lib.model_lib)):
