@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=10)
     ap.add_argument("--no-ahds", action="store_true", help="skip the full AHDS training-step measurement (configs[2])")
     ap.add_argument("--ahds-steps", type=int, default=10)
+    ap.add_argument("--no-trained", action="store_true", help="skip the secondary raster measurement on a trained-looking state")
     args = ap.parse_args()
 
     import numpy as np
@@ -156,6 +157,30 @@ def main():
         fwd_step()
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
+    # ---- the same step on a TRAINED-looking state (secondary: the headline config is the init state SURVEY §8d prescribes)
+    trained = None
+    if rank == 0 and not args.no_trained:
+        sct = scenes.trained_look(scenes.make_scene("human", P, seed=42, sh_degree=0), seed=7)
+        tt_ = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in sct.items()}
+        pl_ = [tt_[n] for n in names]
+
+        def step_t():
+            m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+            color, radii, depth, alpha = rasterize_views(tt_["means3D"], m2d, tt_["opacities"], sts, shs=tt_["shs"],
+                                                         scales=tt_["scales"], rotations=tt_["rotations"])
+            torch.autograd.grad([color, depth], pl_ + [m2d], [gC, gD])
+        for _ in range(max(args.warmup, 3)):
+            step_t()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_t()
+        torch.cuda.synchronize()
+        dtt = (time.perf_counter() - t0) / args.steps
+        trained = {"ms_per_step": round(dtt * 1e3, 4), "mpix_per_s": round(V * H * W / dtt / 1e6, 1),
+                   "state": "opacity 0.6, scales x U(1,3) per axis, random rotations / colours (tests/scenes.trained_look)"}
+        del tt_, pl_
 
     # ---- BASELINE.json configs[3] layout of the same raster step (N > 1): the 4 views of ONE optimizer step sharded over
     # the ranks of a seed group (8 GPUs: 2 seed groups with their own process groups), gradients SUM-reduced inside it
@@ -304,6 +329,7 @@ def main():
                           "parallelism": "view-sharded dp%d" % world},
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
                "forward_only": {"ms_per_step": round(fwd_ms, 4), "mpix_per_s_per_gpu": round(V * H * W / fwd_ms / 1e3, 1)},
+               "trained_state": trained,
                "config3_layout": config3,
                "roofline": roofline, "roofline_valu": valu, "cpu_baseline": cpu}
     if rank == 0:

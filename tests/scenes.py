@@ -105,6 +105,21 @@ def camera(elev_deg, azim_deg, dist, fovy_deg, H, W):
                 campos=campos.numpy().astype(np.float32), tanfovx=float(tanx), tanfovy=float(tany))
 
 
+def trained_look(sc, seed=7):
+    """A densified / optimised look of a scene made by make_scene (in place, returned): opaque (0.6), larger anisotropic
+    splats (1-3x per axis) with arbitrary orientation and colour.  Exercises early termination (T < 1e-4), the 0.99 alpha
+    cap and long occupied tile lists — the state a training run spends most of its time in, next to the init state §8d
+    prescribes for the headline number."""
+    rng = np.random.default_rng(seed)
+    P = sc["means3D"].shape[0]
+    sc["scales"] = (sc["scales"] * rng.uniform(1.0, 3.0, (P, 3))).astype(np.float32)
+    sc["opacities"][:] = 0.6
+    q = rng.normal(size=(P, 4))
+    sc["rotations"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    sc["shs"][:, 0, :] = ((rng.uniform(0, 1, (P, 3)) - 0.5) / 0.28209479177387814).astype(np.float32)
+    return sc
+
+
 def train_cameras(n, seed, H, W):
     """n cameras from the training ranges (configs/exp.yaml:6-45; camera_data.py:336-363): elevation +-30,
     batch-uniform azimuth, distance 1.3-1.7, fovy 40-70."""

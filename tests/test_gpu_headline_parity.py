@@ -43,14 +43,7 @@ _report = {}
 def _look(kind):
     sc = scenes.make_scene("human", P, seed=42)
     if kind == "trained":
-        # densified / optimised look: opaque, larger anisotropic splats with arbitrary orientation and colour;
-        # exercises early termination (T < 1e-4), the 0.99 alpha cap and long occupied tile lists
-        rng = np.random.default_rng(7)
-        sc["scales"] = (sc["scales"] * rng.uniform(1.0, 3.0, (P, 3))).astype(np.float32)
-        sc["opacities"][:] = 0.6
-        q = rng.normal(size=(P, 4))
-        sc["rotations"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
-        sc["shs"][:, 0, :] = ((rng.uniform(0, 1, (P, 3)) - 0.5) / 0.28209479177387814).astype(np.float32)
+        scenes.trained_look(sc, seed=7)
     return sc
 
 

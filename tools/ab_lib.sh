@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 for lib in "$@"; do
   for rep in 1 2; do
-  GIP_RASTER_LIB=$lib python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-ahds 2>/dev/null | python -c "
+  GIP_RASTER_LIB=$lib python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-ahds --no-trained 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.readline()); print('$lib', d['ms_per_step'], d['roofline']['stage_ms'])"
   done
