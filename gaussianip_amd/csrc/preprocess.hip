@@ -271,11 +271,24 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
               if (prev == 0u || prev == tile + 1u) break;
               h = (h + 1u) & (HT - 1);
             }
-            const uint32_t packed = (h << 16) | atomicAdd(&s_cnt[h], 1u);   // rank < 8192
+            const uint32_t packed = (h << 16) | (atomicAdd(&s_cnt[h], 1u) & 0xffffu);   // rank < 8192
 #pragma unroll
             for (int kk = 0; kk < GIP_SLOTS; kk++) if (kk == k_cur) slots[kk] = packed;
           } else {
-            atomicAdd(&tcb[tile], 1u);
+            // instances beyond the remembered slots only count.  When their tile is already in the table (a neighbour's
+            // — or this Gaussian's own — remembered instance put it there) they count in the HIGH half of its word (a
+            // workgroup adds at most 1024 to a tile) and ride in that tile's flush; else one global atomic.  They never
+            // claim a table slot: the table is sized for the remembered instances alone (8 x 1024 insertions).
+            uint32_t h = (tile * 2654435761u) >> 19;
+            bool joined = false;
+#pragma unroll 1
+            for (int probe = 0; probe < 8; probe++) {
+              const uint32_t key = reinterpret_cast<volatile uint32_t*>(s_key)[h];
+              if (key == tile + 1u) { atomicAdd(&s_cnt[h], 1u << 16); joined = true; break; }
+              if (key == 0u) break;
+              h = (h + 1u) & (HT - 1);
+            }
+            if (!joined) atomicAdd(&tcb[tile], 1u);
           }
         }
     }
@@ -291,7 +304,10 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
       }
 #pragma unroll
       for (int k = 0; k < HT / PRE_THREADS; k++)
-        if (keyv[k]) val[k] = atomicAdd(&tc[keyv[k] - 1u], val[k]);
+        if (keyv[k]) {
+          if (val[k] >> 16) atomicAdd(&tcb[keyv[k] - 1u], val[k] >> 16);
+          val[k] = (val[k] & 0xffffu) ? atomicAdd(&tc[keyv[k] - 1u], val[k] & 0xffffu) : 0u;
+        }
 #pragma unroll
       for (int k = 0; k < HT / PRE_THREADS; k++)
         if (keyv[k]) s_cnt[threadIdx.x + k * PRE_THREADS] = val[k];

@@ -8,4 +8,5 @@ import sys,json
 d=json.loads(sys.stdin.readline()); print('$lib', d['ms_per_step'], d['roofline']['stage_ms'])"
   done
 done
+for lib in "$@"; do echo "$lib"; GIP_RASTER_LIB=$lib python tools/diag/trained_stages.py 2>/dev/null | grep num_rendered; done
 GIP_RASTER_LIB=${@: -1} python -m pytest tests/test_gpu_raster_parity.py tests/test_gpu_headline_parity.py tests/test_gpu_scale.py -x -q -m gpu 2>&1 | tail -2
