@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=10)
     ap.add_argument("--no-ahds", action="store_true", help="skip the full AHDS training-step measurement (configs[2])")
     ap.add_argument("--ahds-steps", type=int, default=10)
+    ap.add_argument("--prewarm", type=int, default=60, help="untimed steps in front of the warmup steps (GPU clock ramp)")
     ap.add_argument("--no-trained", action="store_true", help="skip the secondary raster measurement on a trained-looking state")
     args = ap.parse_args()
 
@@ -122,6 +123,12 @@ def main():
             pending.wait()
         return color
 
+    # Clock pre-warm (reported as config.prewarm_steps): a process starts on an idle GPU and the first ~30 ms of work run at
+    # ramping clocks (measured: 0.67 -> 0.60 ms per synchronised step over the first 40 steps, tools/diag/step_settling.py);
+    # with a short --warmup that ramp would sit inside the timed region.  These steps are the same step, untimed, in front
+    # of the W warmup steps of the contract; the same count on every rank (the step has collectives at N > 1).
+    for _ in range(args.prewarm):
+        step()
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -324,7 +331,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[1]: %d Gaussians (synthetic human surface, SMPL-X-style "
                                       "init), %dx%d, %d views/step per GPU, raster forward+backward" % (P, H, W, V),
-                          "gaussians": P, "height": H, "width": W, "views_per_step_per_gpu": V,
+                          "gaussians": P, "height": H, "width": W, "views_per_step_per_gpu": V, "prewarm_steps": args.prewarm,
                           "num_rendered_per_view": int(Rv), "sh_degree": 0,
                           "parallelism": "view-sharded dp%d" % world},
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
