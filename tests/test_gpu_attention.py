@@ -60,7 +60,7 @@ def test_single_wide_head_attention_as_dense_gemms():
     xh = x.half().requires_grad_(True)
     got = h(xh)
     (gg,) = torch.autograd.grad(got, xh, torch.ones_like(got))
-    assert float((got.float() - want).abs().max()) < 1e-2 * max(1.0, float(want.abs().max()))
+    assert float((got.detach().float() - want.detach()).abs().max()) < 1e-2 * max(1.0, float(want.detach().abs().max()))
     assert float((gg.float() - gw).abs().max()) < 2e-2 * max(1.0, float(gw.abs().max()))
 
 
