@@ -373,3 +373,38 @@ def test_exchange_bucket_pack_and_unpack_kernels():
     r2, d2 = parallel.exchange_forward_stats(radii, depth).wait()            # single process: the same numbers, no collective
     assert torch.equal(r2, radii.amax(0)) and float(d2) == float(depth.max())
 
+
+
+def test_the_binding_printed_in_integration_md_works():
+    """INTEGRATION.md §3 shows the ctypes binding a maintainer of the reference would write in place of
+    `_C.rasterize_gaussians`: the printed code is executed as it stands (only the library path is made absolute) and must
+    give the shipped wrapper's images."""
+    import os
+    import re
+    from gaussianip_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def rasterize_gaussians" in b]
+    assert len(blocks) == 1
+    code = blocks[0].replace('ctypes.CDLL("libgip_raster.so")', 'ctypes.CDLL(%r)' % os.path.join(_lib.LIB_DIR, "libgip_raster.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    P, H, W = 3000, 96, 128
+    sc = scenes.make_scene("stress", P, seed=4, sh_degree=0)
+    cam = scenes.camera(10.0, 20.0, 1.6, 60.0, H, W)
+    dev = "cuda"
+    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items()}
+    vm, pm, cp = (torch.from_numpy(cam[k]).to(dev) for k in ("viewmatrix", "projmatrix", "campos"))
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    color, radii, depth, alpha, state = ns["rasterize_gaussians"](
+        bg, t["means3D"], None, t["opacities"], t["scales"], t["rotations"], 1.0, None, vm, pm, cam["tanfovx"], cam["tanfovy"], H, W,
+        t["shs"], 0, cp, False, False)
+    torch.cuda.synchronize()
+    st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg,
+                                       scale_modifier=1.0, viewmatrix=vm, projmatrix=pm, sh_degree=0, campos=cp, prefiltered=False,
+                                       debug=False)
+    with torch.no_grad():
+        c2, r2, d2, a2 = GaussianRasterizer(st)(means3D=t["means3D"], means2D=None, opacities=t["opacities"], shs=t["shs"],
+                                                 scales=t["scales"], rotations=t["rotations"])
+    assert torch.equal(color, c2) and torch.equal(radii, r2) and torch.equal(depth, d2) and torch.equal(alpha, a2)
+    assert int(state[:64].view(torch.int32)[0]) == _lib.raster_lib().gip_abi_version()
