@@ -319,3 +319,34 @@ def test_ply_file_matches_the_reference_vertex_table(tmp_path):
         back.load_ply(path)
         for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
             assert torch.equal(getattr(back, k).detach(), torch.from_numpy(d["deg%d%s" % (deg, k)])), k
+
+
+def test_ctypes_structures_match_the_c_headers(tmp_path):
+    """sizeof / offsetof of every C-ABI structure, taken from include/gip_raster.h by the C compiler, equal what the ctypes
+    mirror in gaussianip_amd/_lib.py declares (a field added on one side only would shift every later argument silently)."""
+    import ctypes
+    import subprocess
+    from gaussianip_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"GipRasterConfig": _lib.GipRasterConfig, "GipRasterInputs": _lib.GipRasterInputs, "GipRasterOutputs": _lib.GipRasterOutputs,
+               "GipRasterGradsIn": _lib.GipRasterGradsIn, "GipRasterGradsOut": _lib.GipRasterGradsOut}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gip_raster.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, fname, name, fname))
+    lines.append('  printf("GipRasterHeader %zu\\n", sizeof(GipRasterHeader));')
+    lines.append('  printf("GIP_MAX_VIEWS %d\\nGIP_PARTIAL_FLOATS %d\\nGIP_ABI_VERSION %d\\n", GIP_MAX_VIEWS, GIP_PARTIAL_FLOATS, GIP_ABI_VERSION);')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (name, fname)]) == getattr(cls, fname).offset, (name, fname)
+    assert int(got["GipRasterHeader"]) == 64
+    assert int(got["GIP_MAX_VIEWS"]) == _lib.GIP_MAX_VIEWS and int(got["GIP_PARTIAL_FLOATS"]) == _lib.GIP_PARTIAL_FLOATS
+    assert int(got["GIP_ABI_VERSION"]) == _lib.raster_lib().gip_abi_version()
