@@ -329,7 +329,8 @@ def test_ctypes_structures_match_the_c_headers(tmp_path):
     from gaussianip_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     structs = {"GipRasterConfig": _lib.GipRasterConfig, "GipRasterInputs": _lib.GipRasterInputs, "GipRasterOutputs": _lib.GipRasterOutputs,
-               "GipRasterGradsIn": _lib.GipRasterGradsIn, "GipRasterGradsOut": _lib.GipRasterGradsOut}
+               "GipRasterGradsIn": _lib.GipRasterGradsIn, "GipRasterGradsOut": _lib.GipRasterGradsOut,
+               "GipRasterStateLayout": _lib.GipRasterStateLayout}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gip_raster.h"', 'int main(void) {']
     for name, cls in structs.items():
         lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (name, name))
