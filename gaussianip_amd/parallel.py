@@ -204,23 +204,30 @@ def shard_views(n_views: int, rank: int, world_size: int):
 
 
 class _GroupMax(torch.autograd.Function):
-    """max over the ranks of a group of a 0-d tensor, differentiable like torch.max over the concatenated data: the
-    gradient of everything that used the maximum (on EVERY rank) flows to the rank that holds it."""
+    """max over the ranks of a group of a non-negative 0-d float32 tensor, differentiable like torch.max over the
+    concatenated data: the gradient of everything that used the maximum (on EVERY rank) flows to ONE element — the one on
+    the rank that holds the maximum; when several ranks tie (identical views, a saturated depth) the lowest rank of the
+    group wins, as torch.max picks a single element.  One collective: the ranks MAX-reduce the int64 key
+    (float bits << 32) | (world - rank); non-negative IEEE floats order like their bit patterns, so the winning key
+    carries the maximum in its high word and the winner's rank in its low word."""
 
     @staticmethod
     def forward(ctx, local_max, group):
-        gmax = local_max.detach().clone()
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        bits = local_max.detach().to(torch.float32).reshape(1).view(torch.int32).to(torch.int64)
+        key = (bits << 32) | (world - rank)
+        dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
+        gmax = (key >> 32).to(torch.int32).view(torch.float32).reshape(local_max.shape).to(local_max.dtype)
         ctx.group = group
-        ctx.save_for_backward(local_max.detach() == gmax)
+        ctx.save_for_backward((key & 0xFFFFFFFF) == (world - rank))
         return gmax
 
     @staticmethod
     def backward(ctx, g):
-        (holds,) = ctx.saved_tensors
+        (wins,) = ctx.saved_tensors
         total = g.clone()
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
-        return total * holds.to(total.dtype), None
+        return total * wins.reshape(total.shape).to(total.dtype), None
 
 
 class ViewSharding:
@@ -243,6 +250,9 @@ class ViewSharding:
         self.world = world if world is not None else (dist.get_world_size() if on else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if on else 0)
         self.n_views = n_views
+        if self.world > n_views and self.world % n_views != 0:
+            # e.g. 6 ranks x 4 views: ranks 4 and 5 would re-render views 0 and 1 inside the one group and count twice
+            raise ValueError("ViewSharding: world size %d is neither <= n_views nor a multiple of n_views = %d" % (self.world, n_views))
         self.group_size = min(self.world, n_views)
         self.n_seed_groups = max(1, self.world // self.group_size)
         self.seed_id = self.rank // self.group_size
@@ -275,4 +285,5 @@ class ViewSharding:
             exchange_max(stage.radii, None, self.group)
             exchange_sum(params, vs, self.group, average=False)
         stage.viewspace_grad_sum = vs
-        stage.visibility_filter = stage.radii > 0
+        # the mask of StageOneStep.forward (hand-region exclusion included), from the group-wide radii
+        stage.visibility_filter = stage.visibility(stage.radii) if hasattr(stage, "visibility") else stage.radii > 0

@@ -99,6 +99,16 @@ class StageOneStep:
             idx = self._index_cache[key] = torch.as_tensor(list(ids), dtype=torch.long).to(t.device)
         return t.index_select(0, idx)
 
+    def visibility(self, radii: torch.Tensor) -> torch.Tensor:
+        """The densification mask of GaussianIP.forward (:212-216): radii > 0, minus the Gaussians within `hand_radius` of a
+        hand centre when `disable_hand_densification` is set.  One definition for the single-GPU step and for the
+        multi-GPU exchange, which re-derives the mask from the group-wide radii maximum."""
+        vis = radii > 0
+        if self.cfg.disable_hand_densification and self.hand_centers is not None:
+            dist = torch.norm(self.gaussian.get_xyz[:, None, :] - self.hand_centers[None, :, :], dim=-1)
+            vis = vis & ~(dist.min(dim=-1).values < self.cfg.hand_radius)
+        return vis
+
     # GaussianIP.forward
     def forward(self, batch: Dict, renderbackground=None) -> Dict:
         bg = self.background if renderbackground is None else renderbackground
@@ -110,10 +120,7 @@ class StageOneStep:
         self.viewspace_points = pkg["viewspace_points"]              # [B,P,3]; .grad after backward
         self.viewspace_grad_sum = None
         self.radii = pkg["radii"].max(dim=0).values                  # running max over the views (:165-168)
-        self.visibility_filter = self.radii > 0.0
-        if self.cfg.disable_hand_densification and self.hand_centers is not None:
-            dist = torch.norm(self.gaussian.get_xyz[:, None, :] - self.hand_centers[None, :, :], dim=-1)
-            self.visibility_filter = self.visibility_filter & ~(dist.min(dim=-1).values < self.cfg.hand_radius)
+        self.visibility_filter = self.visibility(self.radii)
         images = pkg["render"].permute(0, 2, 3, 1)                   # [B,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)               # [B,H,W,1]
         dmax = depths.max()                                          # batch-global maximum (:225)
@@ -160,16 +167,21 @@ class StageOneStep:
         but `viewspace_points.grad` is a retained non-leaf gradient that the scaler never sees, so the densification
         statistics (and the `max_grad` = 0.0002 threshold, GaussianIP.py:452-462) see gradients that are still
         multiplied by the scale (65536 at the start).  Reference behaviour, reproduced rather than fixed (SURVEY §7);
-        with scaler=None the statistics are unscaled.  `exchange(self)`: multi-GPU gradient / statistics exchange."""
+        with scaler=None the statistics are unscaled.  `exchange(self)`: multi-GPU gradient / statistics exchange.  It
+        runs on the still-SCALED gradients, before `unscale_`: the scaler's inf / NaN check then sees the group-wide sums,
+        so every rank of a seed group reaches the same `found_inf` verdict, skips (or takes) the same Adam step and
+        keeps the same scale (an overflow on one rank's local gradients would otherwise poison the other ranks' step
+        through the SUM while only that rank skips it)."""
         opt = self.gaussian.optimizer
         opt.zero_grad(set_to_none=True)
         if scaler is not None:
             scaler.scale(loss).backward()
-            scaler.unscale_(opt)
         else:
             loss.backward()
         if exchange is not None:
             exchange(self)
+        if scaler is not None:
+            scaler.unscale_(opt)
         action = self.on_before_optimizer_step(step)
         if scaler is not None:
             scaler.step(opt)

@@ -91,3 +91,90 @@ def test_single_process_is_a_no_op():
     p.grad = torch.ones(3)
     parallel.exchange_step([p], torch.ones(3), torch.ones(3, dtype=torch.int32), torch.tensor(2.0))
     assert torch.equal(p.grad, torch.ones(3))
+
+
+# ---- round 3: scaler / exchange order, tie-breaking of the group maximum, the hand mask under sharding ----
+class _FakeGaussian:
+    def __init__(self, p, lr=0.1):
+        self.optimizer = torch.optim.Adam([{"params": [p], "name": "xyz"}], lr=lr)
+        self.get_xyz = p.detach()
+
+
+def _scaler_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussianip_amd import parallel
+    from gaussianip_amd.system import StageOneConfig, StageOneStep
+    p = torch.nn.Parameter(torch.ones(4, 3))
+    stage = StageOneStep(_FakeGaussian(p), None, torch.zeros(3), StageOneConfig(refine_start_step=0))   # hook returns at once
+    scaler = torch.amp.GradScaler("cpu", init_scale=65536.0)
+
+    def exchange(st):
+        parallel.allreduce_gradients([p])
+
+    # step 0: rank 1's LOCAL gradient overflows (3e34 * 65536 = inf in fp32); rank 0's is finite
+    coef = 3e34 if rank == 1 else 1.0
+    stage.optimizer_step((p * coef).sum(), 0, scaler=scaler, exchange=exchange)
+    skipped = bool(torch.equal(p.detach(), torch.ones(4, 3)))
+    scale0 = float(scaler.get_scale())
+    # step 1: finite everywhere -> both ranks take the same Adam step from the same summed gradient
+    stage.optimizer_step((p * (1.0 + rank)).sum(), 1, scaler=scaler, exchange=exchange)
+    res = [None] * world
+    dist.all_gather_object(res, dict(skipped=skipped, scale0=scale0, p=p.detach().tolist(), scale1=float(scaler.get_scale())))
+    # group maximum with a TIE: both ranks hold 2.0; torch.max over the concatenated data gives the gradient to ONE element
+    x = torch.tensor(2.0, requires_grad=True)
+    y = parallel._GroupMax.apply(x * 1.0, None)
+    (y * (3.0 + rank)).backward()                 # total gradient 3 + 4 = 7 goes to the lowest rank only
+    tie = [None] * world
+    dist.all_gather_object(tie, (float(y.detach()), float(x.grad)))
+    # and without a tie the holder gets it, whichever rank it is
+    x2 = torch.tensor(1.0 + rank, requires_grad=True)
+    y2 = parallel._GroupMax.apply(x2 * 1.0, None)
+    y2.backward()
+    notie = [None] * world
+    dist.all_gather_object(notie, (float(y2.detach()), float(x2.grad)))
+    if rank == 0:
+        out.put(dict(res=res, tie=tie, notie=notie))
+    dist.destroy_process_group()
+
+
+def test_scaler_sees_the_exchanged_gradients_and_group_max_breaks_ties():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scaler_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    r = q.get(timeout=5)
+    a, b = r["res"]
+    # an overflow on ONE rank's local gradients: BOTH ranks skip the step and halve their scale (system.py:168)
+    assert a["skipped"] and b["skipped"]
+    assert a["scale0"] == b["scale0"] == 32768.0
+    assert a["p"] == b["p"] and a["p"] != torch.ones(4, 3).tolist()
+    assert a["scale1"] == b["scale1"]
+    assert r["tie"] == [(2.0, 7.0), (2.0, 0.0)]
+    assert r["notie"] == [(2.0, 0.0), (2.0, 2.0)]
+
+
+def test_view_sharding_rejects_uneven_replication_and_keeps_the_hand_mask():
+    import pytest
+    from gaussianip_amd import parallel
+    from gaussianip_amd.system import StageOneConfig, StageOneStep
+    with pytest.raises(ValueError):
+        parallel.ViewSharding(4, rank=5, world=6, make_groups=False)
+    assert parallel.ViewSharding(4, rank=5, world=8, make_groups=False).views == [1]
+    assert parallel.ViewSharding(4, rank=1, world=3, make_groups=False).views == [1]
+    # the exchange re-derives the visibility filter from the group-wide radii WITH the hand exclusion (GaussianIP.py:212-216)
+    p = torch.nn.Parameter(torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [2.0, 0.0, 0.0]]))
+    stage = StageOneStep(_FakeGaussian(p), None, torch.zeros(3), StageOneConfig(disable_hand_densification=True, hand_radius=0.05),
+                         hand_centers=torch.tensor([[1.0, 0.0, 0.01]]))
+    stage.radii = torch.tensor([3, 5, 0], dtype=torch.int32)
+    stage.viewspace_points = torch.zeros(1, 3, 3, requires_grad=True)
+    stage.viewspace_points.grad = torch.ones(1, 3, 3)
+    parallel.ViewSharding(4, rank=0, world=1, make_groups=False).exchange(stage)
+    assert stage.visibility_filter.tolist() == [True, False, False]
+    assert stage.visibility(stage.radii).tolist() == [True, False, False]

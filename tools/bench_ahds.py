@@ -86,7 +86,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         vs = st.viewspace_points.grad.sum(0)
         parallel.exchange_step([g_["params"][0] for g_ in gm.optimizer.param_groups], vs, st.radii, None, average=True)
         st.viewspace_grad_sum = vs
-        st.visibility_filter = st.radii > 0
+        st.visibility_filter = st.visibility(st.radii)
 
     def step(i):
         batch = scenes.train_batch(cam_rng, B, H, W, device=dev)
