@@ -46,7 +46,8 @@ template <int BN, int STAGES, int TAPS, bool GEGLU>
 __global__ void __launch_bounds__(CV_THREADS, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
-               int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom) {
+               int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom,
+               float* __restrict__ chan_stats) {
   // geom = stride | pad_top << 8 | pad_left << 16; H, W are the OUTPUT dims, Hin, Win the input dims (equal at stride 1)
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -64,7 +65,12 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   const int total = m_tiles * n_tiles, id = (int)(blockIdx.x % (unsigned)total), split = (int)(blockIdx.x / (unsigned)total);
   const int q = total >> 3, r = total & 7, xcd = id & 7;
   const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  // tile order inside an XCD's contiguous chunk (geom bit 24): m-major keeps the tiles that share a PIXEL block together
+  // (the activations are the big operand: VAE, 64^2 / 32^2 levels), n-major the tiles that share a WEIGHT block (16^2 /
+  // 8^2 levels: 30-60 MB of weights against a few MB of activations) — whichever operand is larger is then fetched into
+  // each XCD's L2 once instead of eight times
+  const bool nmajor = (geom >> 24) & 1;
+  const int mt = nmajor ? t % m_tiles : t / n_tiles, nt = nmajor ? t / m_tiles : t - (t / n_tiles) * n_tiles;
   const unsigned M = (unsigned)N * H * W;          // < 2^31 (checked on the host): 32-bit index arithmetic throughout
   const unsigned m0 = (unsigned)mt * CV_BM;
   const int co0 = nt * (GEGLU ? BN / 2 : BN);      // first OUTPUT channel of the tile
@@ -210,6 +216,79 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     }
     return;
   }
+  if constexpr (!GEGLU) {
+    if (((geom >> 25) & 1) && !(Cout & 7)) {
+      // ---- coalesced epilogue through LDS (the stage buffers are free: every wave has passed the loop's last barrier).
+      // The accumulator layout gives a lane 4 channels of one pixel = 8-byte stores 32 contiguous bytes apiece (and the
+      // same shape for the residual loads): the memory pipe sees eight times the instructions a full-row access needs.
+      // Here the tile is rounded to half once (+ bias), laid out [128 pixels][BN channels] in LDS, and written with
+      // 16 bytes per lane, 16 (20) lanes per 256 (320)-byte row; the residual is read the same way and added to the
+      // half-rounded convolution output — fp16(fp16(conv + bias) + residual), diffusers' own arithmetic for
+      // `input_tensor + hidden_states` in ResnetBlock2D.
+      constexpr int ROWB = BN * 2 + 16;                 // padded row: 16-byte aligned, 8-byte writes at most 2-way conflicted
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) {
+        const int cl = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias && co0 + cl < Cout) add4(b4, bias + co0 + cl);
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+          const int p = wm * 64 + mi * 16 + (lane & 15);
+          const f32x4 v = acc[ni][mi];
+          f16x4 o;
+          o[0] = (_Float16)(v[0] + b4[0]); o[1] = (_Float16)(v[1] + b4[1]); o[2] = (_Float16)(v[2] + b4[2]); o[3] = (_Float16)(v[3] + b4[3]);
+          *(f16x4*)(smem + p * ROWB + cl * 2) = o;
+        }
+      }
+      __syncthreads();
+      constexpr int CH = BN / 8, RPP = CV_THREADS / CH;     // 16-byte chunks per row, rows per pass
+      const int chunk = tid % CH, r0 = tid / CH;
+      const int co = co0 + chunk * 8;
+      const bool mine = tid < RPP * CH && co < Cout;
+      // per-channel sum / sum of squares of the FINAL half-rounded outputs of this tile (chan_stats != NULL): the
+      // statistics pass of the GroupNorm that consumes this tensor (gip_gn_finalize_stats) — it never re-reads the tensor
+      float s8[8], q8[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { s8[j] = 0.f; q8[j] = 0.f; }
+      if (mine) {
+#pragma unroll 4
+        for (int row = r0; row < CV_BM; row += RPP) {
+          const unsigned m = m0 + row;
+          if (m >= M) break;
+          f16x8 v = *(const f16x8*)(smem + row * ROWB + chunk * 16);
+          if (residual) {
+            const f16x8 rr = *(const f16x8*)(residual + (size_t)m * Cout + co);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
+          }
+          *(f16x8*)(out + (size_t)m * Cout + co) = v;
+          if (chan_stats) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float f = (float)v[j]; s8[j] += f; q8[j] = fmaf(f, f, q8[j]); }
+          }
+        }
+      }
+      if (chan_stats) {                                      // kernel argument: uniform over the workgroup
+        float* part = (float*)(smem + CV_BM * ROWB);         // [RPP][BN][2] behind the tile image (fits: see launch())
+        if (tid < RPP * CH) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            part[((r0 * BN) + chunk * 8 + j) * 2] = s8[j];
+            part[((r0 * BN) + chunk * 8 + j) * 2 + 1] = q8[j];
+          }
+        }
+        __syncthreads();
+        if (tid < BN && co0 + tid < Cout) {
+          float S = 0.f, Q = 0.f;
+#pragma unroll
+          for (int r = 0; r < RPP; r++) { S += part[(r * BN + tid) * 2]; Q += part[(r * BN + tid) * 2 + 1]; }   // fixed order
+          float* o = chan_stats + ((size_t)mt * Cout + co0 + tid) * 2;
+          o[0] = S; o[1] = Q;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < 4; mi++) {
     const unsigned m = m0 + wm * 64 + mi * 16 + (lane & 15);
@@ -266,14 +345,19 @@ conv_splitk_reduce_kernel(const float* __restrict__ partial, const _Float16* __r
   *(f16x4*)(out + (size_t)i * 4) = o;
 }
 
+// Debug / A-B knobs (tools/exp_conv*.py set them through ctypes; -1 = the shape heuristic below decides)
+extern "C" { int gip_dbg_conv_order = -1; int gip_dbg_conv_epilogue = -1; int gip_dbg_conv_ksplit = 0; }
+
 template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
                   int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0, int Hin = 0, int Win = 0,
-                  int geom = 1 | (1 << 8) | (1 << 16)) {
+                  int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr) {
   if (Hin == 0) { Hin = H; Win = W; }
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
+  static_assert((size_t)CV_BM * (BN * 2 + 16) + (size_t)(CV_THREADS / (BN / 8)) * BN * 8 <= STAGES * (size_t)(CV_BM + BN) * 128,
+                "epilogue tile image + statistics partials must fit in the stage buffers");
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN, STAGES, TAPS, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -281,19 +365,37 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
       return 3;
     attr_set = true;
   }
-  // split-K when the output tiles cannot fill the chip and a workspace was handed in: aim at ~2 workgroups per CU
+  // split-K when the output tiles cannot fill the chip and a workspace was handed in: the largest factor that still
+  // fits ONE round of 2 workgroups per CU (240 tiles: 2 -> 480 workgroups; 3 -> 720 = 1.4 rounds measured 16 % slower;
+  // 60 tiles: 8; tools/exp_conv5.py)
   int ksplit = 1;
   const int tiles = m_tiles * n_tiles, KT = TAPS * (Cin / CV_BK);
   if (!GEGLU && workspace && tiles < 256) {
-    ksplit = (512 + tiles - 1) / tiles;
+    ksplit = 512 / tiles;
     if (ksplit > KT / 8) ksplit = KT / 8;
     if (ksplit > 16) ksplit = 16;
     while (ksplit > 1 && (size_t)ksplit * M * Cout * sizeof(float) > workspace_bytes) ksplit--;
     if (ksplit < 2) ksplit = 1;
   }
+  if (gip_dbg_conv_ksplit > 0 && !GEGLU && workspace) {
+    ksplit = gip_dbg_conv_ksplit;
+    while (ksplit > 1 && ((size_t)ksplit * M * Cout * sizeof(float) > workspace_bytes || ksplit > KT)) ksplit--;
+  }
+  // tile order: n-major only where the pixel count is tiny against the weights (the 8x8 level: 6 pixel blocks, 30-60 MB
+  // of weights: 55 -> 50 us); measured slower everywhere else, also at 16x16 (tools/exp_conv5.py)
+  int nmajor = m_tiles <= 8 && n_tiles > 1 ? 1 : 0;
+  if (gip_dbg_conv_order >= 0) nmajor = gip_dbg_conv_order;
+  int lds_epi = 1;
+  if (gip_dbg_conv_epilogue >= 0) lds_epi = gip_dbg_conv_epilogue;
+  if (chan_stats) {            // statistics come out of the LDS epilogue of whole-K tiles
+    if (GEGLU || (Cout & 7)) return 1;
+    ksplit = 1;
+    lds_epi = 1;
+  }
+  geom |= (nmajor << 24) | (lds_epi << 25);
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
-                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom);
+                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats);
   if (ksplit > 1) {
     const unsigned n4 = (unsigned)(M * Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
@@ -315,6 +417,29 @@ extern "C" int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
   const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
   return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes)
               : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes);
+}
+
+extern "C" int gip_conv3x3_stats_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                                          int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* chan_stats,
+                                          void* stream) {
+  if (!x || !w || !out || !chan_stats || N < 1 || H < 1 || W < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 8 || (Cout & 7)) return 1;
+  if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_stats)
+              : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_stats);
+}
+
+extern "C" int gip_linear_stats_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                                    int32_t K, int32_t Nout, float* chan_stats, void* stream) {
+  if (!x || !w || !out || !chan_stats || M < 1 || M >= (1ll << 31) || K < CV_BK || K % CV_BK || Nout < 8 || (Nout & 7)) return 1;
+  if (!fits32(M, K, Nout, Nout, 1)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  return wide ? launch<160, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, chan_stats)
+              : launch<128, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, chan_stats);
 }
 
 extern "C" int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin,

@@ -131,8 +131,10 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
   const int cg = C / G;
   const float inv_m = 1.f / ((float)HW * (float)cg);
   // per-group totals from the per-split partials: all 256 threads take part (group = t % G, split slice = t / G),
-  // fixed summation order
-  {
+  // fixed summation order.  splits == 0 (forward): mean / rstd were made by gn_finalize_stats_kernel, nothing to reduce
+  if (MODE == 0 && splits == 0) {
+    for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) { s_g[2 * gg] = mean[n * G + gg]; s_g[2 * gg + 1] = rstd[n * G + gg]; }
+  } else {
     float* s_part = s_g + 2 * G;                      // [slices][G][2]
     const int slices = GN_BLOCK / G > 0 ? GN_BLOCK / G : 1;
     const int g = threadIdx.x % G, sl = threadIdx.x / G;
@@ -207,6 +209,45 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
   }
 }
 
+// GroupNorm statistics from the per-(128-row block, channel) sums the producing convolution / linear kernel wrote in its
+// epilogue (csrc/conv3x3.hip, chan_stats [blocks][C][2]): one workgroup per (sample, group), fixed summation order.
+// With an addend a_c (added to x on load by the apply pass): sum(x + a) = S_c + P a_c, sum((x + a)^2) = Q_c + 2 a_c S_c + P a_c^2.
+__global__ void __launch_bounds__(GN_BLOCK)
+gn_finalize_stats_kernel(const float* __restrict__ chan_stats, int blocks_per_sample, long long HW, int C, int G, float eps,
+                         const __half* __restrict__ addend, int addend_stride, float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ float s_part[GN_BLOCK * 2];
+  __shared__ float s_ch[GN_BLOCK * 2];
+  const int n = blockIdx.y, g = blockIdx.x, cg = C / G;         // cg <= GN_BLOCK (checked on the host)
+  const int j = threadIdx.x % cg, k = threadIdx.x / cg, K = GN_BLOCK / cg;
+  float S = 0.f, Q = 0.f;
+  if (k < K) {
+    const float* p = chan_stats + ((size_t)n * blocks_per_sample * C + (size_t)g * cg + j) * 2;
+    for (int b = k; b < blocks_per_sample; b += K) { S += p[(size_t)b * C * 2]; Q += p[(size_t)b * C * 2 + 1]; }
+  }
+  s_part[2 * threadIdx.x] = S; s_part[2 * threadIdx.x + 1] = Q;
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    S = 0.f; Q = 0.f;
+    for (int kk = 0; kk < K; kk++) { S += s_part[2 * (kk * cg + threadIdx.x)]; Q += s_part[2 * (kk * cg + threadIdx.x) + 1]; }
+    if (addend) {
+      const float a = __half2float(addend[(long long)n * addend_stride + g * cg + threadIdx.x]);
+      Q += 2.f * a * S + (float)HW * a * a;
+      S += (float)HW * a;
+    }
+    s_ch[2 * threadIdx.x] = S; s_ch[2 * threadIdx.x + 1] = Q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S = 0.f; Q = 0.f;
+    for (int c = 0; c < cg; c++) { S += s_ch[2 * c]; Q += s_ch[2 * c + 1]; }
+    const float inv_m = 1.f / ((float)HW * (float)cg);
+    const float mu = S * inv_m;
+    const float var = fmaxf(Q * inv_m - mu * mu, 0.f);
+    mean[n * G + g] = mu;
+    rstd[n * G + g] = rsqrtf(var + eps);
+  }
+}
+
 static size_t reduce_lds_bytes(int C) {
   const int tpr = C >> 3, cpt = (tpr + GN_BLOCK - 1) / GN_BLOCK, lanes_x = (tpr + cpt - 1) / cpt;
   const int rpi = GN_BLOCK / lanes_x > 0 ? GN_BLOCK / lanes_x : 1;
@@ -251,6 +292,24 @@ extern "C" int gip_gn_silu_forward(const void* x, const void* gamma, const void*
   hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
                      (const float*)partial, (half8*)y, (long long)HW, C, G, rsplits, splits, eps, apply_silu,
+                     (const __half*)addend, addend_stride);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_gn_silu_forward_stats(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                                         int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t apply_silu,
+                                         const void* addend, int32_t addend_stride, const float* chan_stats,
+                                         int32_t blocks_per_sample, void* stream) {
+  int rc = check(x, y, N, HW, C, G, (size_t)-1);
+  if (rc) return rc;
+  if (!gamma || !beta || !mean || !rstd || !chan_stats || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(G, N), dim3(GN_BLOCK), 0, s, chan_stats, blocks_per_sample, (long long)HW, C, G,
+                     eps, (const __half*)addend, addend_stride, mean, rstd);
+  const int splits = pick_splits(N, HW, C);
+  hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
+                     (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
+                     (const float*)nullptr, (half8*)y, (long long)HW, C, G, 0, splits, eps, apply_silu,
                      (const __half*)addend, addend_stride);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -7,6 +7,7 @@ dL/dx only — the guidance networks are frozen).  `add_bias_residual` (shortcut
 pointwise companions.  Any other input (CPU tests, fp32) takes the plain PyTorch ops with identical semantics.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -34,7 +35,7 @@ def _p(t):
 
 class _FusedGN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, act, addend):
+    def forward(ctx, x, weight, bias, groups, eps, act, addend, chan_stats=None):
         N, C, H, W = x.shape
         ad_ptr, ad_stride = ctypes.c_void_p(None), 0
         if addend is not None:
@@ -43,11 +44,16 @@ class _FusedGN(torch.autograd.Function):
         y = torch.empty_like(x, memory_format=torch.channels_last)
         mean = torch.empty((N, groups), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        nb = lib.gip_gn_workspace_bytes(N, groups)
-        ws = _workspace(x.device, nb)
-        rc = lib.gip_gn_silu_forward(_p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), N, H * W, C, groups,
-                                     float(eps), int(act), ad_ptr, ad_stride, _p(ws), ws.numel(),
-                                     ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        if chan_stats is not None:
+            # the producer of x (MFMA convolution / linear epilogue) already summed x per 128-row block and channel
+            rc = lib.gip_gn_silu_forward_stats(_p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), N, H * W, C, groups,
+                                               float(eps), int(act), ad_ptr, ad_stride, _p(chan_stats), (H * W) // 128, stream)
+        else:
+            nb = lib.gip_gn_workspace_bytes(N, groups)
+            ws = _workspace(x.device, nb)
+            rc = lib.gip_gn_silu_forward(_p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), N, H * W, C, groups,
+                                         float(eps), int(act), ad_ptr, ad_stride, _p(ws), ws.numel(), stream)
         if rc != 0:
             raise RuntimeError("gip_gn_silu_forward failed with status %d" % rc)
         ctx.save_for_backward(x, weight, bias, mean, rstd, addend)
@@ -69,7 +75,7 @@ class _FusedGN(torch.autograd.Function):
                                       ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("gip_gn_silu_backward failed with status %d" % rc)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class GroupNormAct(nn.GroupNorm):
@@ -81,7 +87,7 @@ class GroupNormAct(nn.GroupNorm):
         """`addend` ([N, C], [1, C] or [C], unit stride on C) is added to x before the normalisation."""
         if fusable(x) and self.weight.dtype == torch.float16 and not self.weight.requires_grad and \
                 (addend is None or (addend.dtype == torch.float16 and addend.stride(-1) == 1 and not addend.requires_grad)):
-            return _FusedGN.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.act, addend)
+            return _FusedGN.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.act, addend, producer_stats(x))
         if addend is not None:
             x = x + addend.reshape(-1 if addend.dim() == 2 and addend.shape[0] > 1 else 1, x.shape[1], 1, 1)
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
@@ -89,6 +95,33 @@ class GroupNormAct(nn.GroupNorm):
 
 
 _DISABLED = False
+_STATS_ATTR = "_gip_chan_stats"
+
+
+def producer_stats(x):
+    """chan_stats [N * HW / 128, C, 2] float32 that the kernel which produced `x` wrote in its epilogue (attached to the
+    tensor OBJECT by conv3x3 / linear below; any view / copy of x drops it and the GroupNorm takes its own statistics
+    pass), or None."""
+    st = getattr(x, _STATS_ATTR, None)
+    if st is None or x.dim() != 4:
+        return None
+    N, C, H, W = x.shape
+    if st.shape != (N * H * W // 128, C, 2) or (H * W) % 128 or C // 32 > 256 or os.environ.get("GIP_GN_STATS", "1") == "0":
+        return None
+    return st
+
+
+def attach_stats(x, st):
+    if st is not None:
+        setattr(x, _STATS_ATTR, st)
+    return x
+
+
+def stats_wanted(N, H, W, cout):
+    """The producer takes the next GroupNorm's statistics when a 128-pixel block never straddles two samples and the
+    problem has enough tiles to run without split-K (the split-K reduce kernel does not make them)."""
+    return (not _DISABLED and (H * W) % 128 == 0 and cout % 8 == 0 and _conv_tiles(N, H, W, cout) >= 256 and
+            os.environ.get("GIP_GN_STATS", "1") != "0")
 
 
 class disabled:
@@ -213,10 +246,20 @@ def _conv_tiles(N, H, W, cout):
     return ((N * H * W + 127) // 128) * ((cout + bn - 1) // bn)
 
 
-def _conv_call(x, w, cout, bias=None, residual=None):
+def _conv_call(x, w, cout, bias=None, residual=None, stats=None):
+    """`stats`: a list that receives the output's chan_stats tensor (see producer_stats) when the shape qualifies."""
     N, C, H, W = x.shape
     out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     null = ctypes.c_void_p(None)
+    if stats is not None and stats_wanted(N, H, W, cout):
+        st = torch.empty((N * H * W // 128, cout, 2), dtype=torch.float32, device=x.device)
+        rc = _lib.nn_lib().gip_conv3x3_stats_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias),
+                                                      null if residual is None else _p(residual), _p(out), N, H, W, C, cout,
+                                                      _p(st), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_conv3x3_stats_nhwc_f16 failed with status %d" % rc)
+        stats.append(st)
+        return out
     ws = _workspace(x.device, _SPLITK_WS_BYTES) if _conv_tiles(N, H, W, cout) < 256 else None
     rc = _lib.nn_lib().gip_conv3x3_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias),
                                             null if residual is None else _p(residual), _p(out), N, H, W, C, cout,
@@ -234,10 +277,10 @@ def _transposed_weight(w):
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, residual):
+    def forward(ctx, x, w, bias, residual, stats=None):
         ctx.save_for_backward(w)
         ctx.x_shape, ctx.has_res = tuple(x.shape), residual is not None
-        return _conv_call(x, w, w.shape[0], bias, residual)
+        return _conv_call(x, w, w.shape[0], bias, residual, stats)
 
     @staticmethod
     def backward(ctx, dy):
@@ -248,19 +291,24 @@ class _Conv3x3(torch.autograd.Function):
             dx = _conv_call(dy, _transposed_weight(w), w.shape[1])
         else:
             dx = torch.nn.grad.conv2d_input(ctx.x_shape, w, dy, padding=1)
-        return dx, None, None, (dy if ctx.has_res else None)
+        return dx, None, None, (dy if ctx.has_res else None), None
 
 
-def conv3x3(x, w, bias=None, residual=None):
+def conv3x3(x, w, bias=None, residual=None, gn_next=False):
     """F.conv2d(x, w, bias, padding=1) (+ residual) for a 3x3 kernel.  fp16 NHWC activations with Cin % 64 == 0 and
     enough output tiles to fill the chip run on the hand-written MFMA implicit GEMM with bias / residual in its
-    epilogue; everything else goes to MIOpen."""
+    epilogue; everything else goes to MIOpen.  `gn_next`: the result feeds a GroupNorm — the kernel's epilogue then also
+    takes that GroupNorm's per-channel sums (attached to the returned tensor, see producer_stats)."""
     if (fusable(x) and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0 and w.dtype == torch.float16 and
             not w.requires_grad and w.is_contiguous(memory_format=torch.channels_last) and
             (bias is None or not bias.requires_grad) and (residual is None or fusable(residual)) and
             _conv_tiles(x.shape[0], x.shape[2], x.shape[3], w.shape[0]) >= _MIN_CONV_TILES and
             x.numel() * 2 < (1 << 31) and x.shape[0] * x.shape[2] * x.shape[3] * w.shape[0] * 2 < (1 << 31)):
-        return _Conv3x3.apply(x, w, bias, residual)
+        if not gn_next:
+            return _Conv3x3.apply(x, w, bias, residual)
+        holder = []
+        out = _Conv3x3.apply(x, w, bias, residual, holder)
+        return attach_stats(out, holder[0] if holder else None)
     out = F.conv2d(x, w, None, padding=1)
     if residual is not None:
         return add_bias_residual(residual, out, bias)
@@ -329,7 +377,7 @@ def linear_supported(x, w):
             x.numel() * 2 < (1 << 31) and (x.numel() // x.shape[-1]) * w.shape[0] * 2 < (1 << 31))
 
 
-def linear(x, w, bias=None, residual=None, geglu_act=False):
+def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None):
     """F.linear(x, w, bias) (+ residual) or, with geglu_act, GEGLU(F.linear(x, w, bias)) — one MFMA kernel with the bias /
     residual / activation in its epilogue (csrc/conv3x3.hip, TAPS = 1).  Inference only (frozen denoiser under no_grad);
     anything else goes to hipBLASLt through F.linear."""
@@ -338,6 +386,15 @@ def linear(x, w, bias=None, residual=None, geglu_act=False):
         M = x.numel() // x.shape[-1]
         out = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
         null = ctypes.c_void_p(None)
+        if stats is not None and not geglu_act and M % 128 == 0 and n_out % 8 == 0 and os.environ.get("GIP_GN_STATS", "1") != "0":
+            st = torch.empty((M // 128, n_out, 2), dtype=torch.float32, device=x.device)
+            rc = _lib.nn_lib().gip_linear_stats_f16(_p(x), _p(w), null if bias is None else _p(bias),
+                                                    null if residual is None else _p(residual), _p(out), M, x.shape[-1], n_out, _p(st),
+                                                    ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("gip_linear_stats_f16 failed with status %d" % rc)
+            stats.append(st)
+            return out
         rc = _lib.nn_lib().gip_linear_f16(_p(x), _p(w), null if bias is None else _p(bias), null if residual is None else _p(residual),
                                           _p(out), M, x.shape[-1], n_out, int(geglu_act),
                                           ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))

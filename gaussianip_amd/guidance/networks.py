@@ -81,11 +81,13 @@ class ResBlock(nn.Module):
             addend = self.conv1.bias
             if self.time_emb_proj is not None:
                 addend = F.linear(F.silu(temb), self.time_emb_proj.weight, self.time_emb_proj.bias + addend)
-        h = conv3x3(self.norm1(x), self.conv1.weight)
+        # both convolutions feed a GroupNorm (conv1 -> norm2; conv2 -> the next block's norm1 / a transformer's norm /
+        # norm_out): their epilogues take its statistics, so that GroupNorm reads its input once (apply) instead of twice
+        h = conv3x3(self.norm1(x), self.conv1.weight, gn_next=True)
         if self.conv_shortcut is None:
-            return conv3x3(self.norm2(h, addend), self.conv2.weight, self.conv2.bias, x)
+            return conv3x3(self.norm2(h, addend), self.conv2.weight, self.conv2.bias, x, gn_next=True)
         return conv3x3(self.norm2(h, addend), self.conv2.weight, self.conv2.bias,
-                       conv1x1(x, self.conv_shortcut.weight, self.conv_shortcut.bias))
+                       conv1x1(x, self.conv_shortcut.weight, self.conv_shortcut.bias), gn_next=True)
 
     staged_addend = None
 
@@ -268,8 +270,10 @@ class SpatialTransformer(nn.Module):
             res = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
             if replicas > 1:
                 res = res.repeat(replicas, 1, 1)
-            t = fused.linear(self.block(t, ctx, replicas), self.proj_out.weight.reshape(C, C), self.proj_out.bias, res)   # the block's residual rides in the epilogue
-            return t.reshape(B * replicas, H, W, C).permute(0, 3, 1, 2)
+            holder = []
+            t = fused.linear(self.block(t, ctx, replicas), self.proj_out.weight.reshape(C, C), self.proj_out.bias, res, stats=holder)   # the block's residual rides in the epilogue
+            # the next ResnetBlock2D's norm1 reads this tensor: its statistics came out of the projection's epilogue
+            return fused.attach_stats(t.reshape(B * replicas, H, W, C).permute(0, 3, 1, 2), holder[0] if holder else None)
         h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.block(h, ctx, replicas).reshape(B * replicas, H, W, C).permute(0, 3, 1, 2)
         return (_tile_batch(x, replicas) if replicas > 1 else x) + self.proj_out(h)

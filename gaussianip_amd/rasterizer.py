@@ -224,6 +224,16 @@ def _drain_pending(block=False):
             i += 1
 
 
+def settle_pending():
+    """Blocks until every deferred capacity check has been read and reported.  The check of a training forward runs when
+    its backward has been enqueued, and the check of a grad-enabled forward that is never back-propagated runs at the
+    next rasterizer call — so the LAST forward of a run is only reported by calling this (end of training, before a
+    checkpoint).  An overflowed training step is not a no-op: its images were truncated, its rasterizer gradients are
+    zero, Adam still moves by its momentum and `add_densification_stats` counts the step with zero gradients; it is
+    rare by construction (the capacity is 3x the previous call's requirement) and `overflow_events` counts it."""
+    _drain_pending(block=True)
+
+
 def _forward_with_policy(plan, need_backward):
     _drain_pending()
     key = _hint_key(plan.means3D.device, plan.P, plan.V, plan.H, plan.W)

@@ -38,6 +38,15 @@ int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const
                          const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu,
                          const void* addend, int32_t addend_stride,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Forward with the statistics pass taken out: `chan_stats` [N * blocks_per_sample][C][2] float holds, per 128-row block of
+ * x and channel, the sum and the sum of squares of x's elements — written by the epilogue of the kernel that PRODUCED x
+ * (gip_conv3x3_stats_nhwc_f16 / gip_linear_stats_f16; HW % 128 == 0 so that a block never straddles two samples).  One
+ * small launch folds them into mean / rstd (the addend enters algebraically), then the same apply pass runs: x is read
+ * once instead of twice.  No workspace. */
+int gip_gn_silu_forward_stats(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                              int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t apply_silu,
+                              const void* addend, int32_t addend_stride, const float* chan_stats,
+                              int32_t blocks_per_sample, void* stream);
 int gip_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t M, int32_t C, void* stream);
 int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
 
@@ -75,6 +84,15 @@ int gip_lpips_layer_backward(const void* feat, const void* target_unit, const fl
 int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* workspace, size_t workspace_bytes,
                          void* stream);
+
+/* gip_conv3x3_nhwc_f16 that also writes `chan_stats` [ceil(N*H*W / 128)][Cout][2] float: per 128-pixel block and output
+ * channel the sum and the sum of squares of the final (half-rounded, bias and residual included) outputs — the
+ * statistics pass of the GroupNorm that reads `out` next (gip_gn_silu_forward_stats).  Never split-K.  Cout % 8 == 0. */
+int gip_conv3x3_stats_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
+                               int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* chan_stats, void* stream);
+/* gip_linear_f16 (no GEGLU) with the same per-(128-row block, column) statistics of its output. */
+int gip_linear_stats_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                         int32_t K, int32_t Nout, float* chan_stats, void* stream);
 
 /* The same kernel at stride 2 (diffusers Downsample2D): out [N, Hin/2, Win/2, Cout]; pad_top / pad_left = 1 with the
  * symmetric padding of the U-Net / ControlNet (padding=1), 0 for the VAE's F.pad(x, (0, 1, 0, 1)) + padding=0 form (the

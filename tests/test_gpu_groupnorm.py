@@ -163,3 +163,72 @@ def test_layernorm_rows_match_torch_fp32(rows, C):
     xg = x.clone().requires_grad_(True)
     ln(xg).sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+# ---- round 3: the statistics pass taken by the producing kernel's epilogue (gip_conv3x3_stats_nhwc_f16 /
+# gip_linear_stats_f16 -> gip_gn_silu_forward_stats) ----
+STAT_SHAPES = [(4, 128, 128, 64, 64), (2, 64, 320, 64, 64), (3, 128, 256, 32, 48), (2, 192, 640, 16, 24)]     # N, Cin, Cout, H, W
+
+
+@pytest.mark.parametrize("shape", STAT_SHAPES)
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv_epilogue_statistics_and_the_groupnorm_that_uses_them(shape, residual, monkeypatch):
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setattr(fused, "_MIN_CONV_TILES", 0)
+    monkeypatch.setattr(fused, "stats_wanted", lambda N, H, W, c: (H * W) % 128 == 0 and c % 8 == 0)   # also for small tile counts
+    N, ci, co, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(ci + co + H)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, ci, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(co, ci, 3, 3, device="cuda", generator=g) / (3 * ci ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(co, device="cuda", generator=g).half()
+    r = torch.randn(N, co, H, W, device="cuda", generator=g).half().contiguous(**cl) if residual else None
+    out = fused.conv3x3(x, w, b, r, gn_next=True)
+    st = fused.producer_stats(out)
+    assert st is not None and st.shape == (N * H * W // 128, co, 2), "the epilogue statistics are missing"
+    # 1. they are the per-(128-pixel block, channel) sums of the tensor the kernel wrote
+    rows = out.permute(0, 2, 3, 1).reshape(-1, 128, co).double()
+    want = torch.stack([rows.sum(1), (rows * rows).sum(1)], dim=-1)
+    assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # 2. the same output as the convolution without statistics (which may run split-K at these tile counts: another
+    #    summation order, so one half-precision ulp of slack)
+    plain = fused.conv3x3(x, w, b, r)
+    assert float((out.float() - plain.float()).abs().max()) <= 2e-3 * max(1.0, float(plain.float().abs().max()))
+    # 3. GroupNorm fed by them == GroupNorm with its own statistics pass (mean / rstd differ by summation order only)
+    gn = fused.GroupNormAct(32, co, eps=1e-5, act=True).cuda().half().requires_grad_(False)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(co, device="cuda", generator=g) * 0.5 + 1.0)
+        gn.bias.copy_(torch.randn(co, device="cuda", generator=g) * 0.2)
+    addend = (torch.randn(N, co, device="cuda", generator=g) * 0.5).half()
+    for ad in (None, addend, addend[0]):
+        seen = []
+        orig = fused._FusedGN.apply
+        monkeypatch.setattr(fused._FusedGN, "apply", staticmethod(lambda *a: (seen.append(a[-1]), orig(*a))[1]))
+        y_fused = gn(out, ad)
+        monkeypatch.setattr(fused._FusedGN, "apply", orig)
+        assert seen and seen[0] is st, "the GroupNorm did not take the producer's statistics"
+        y_plain = gn(out.clone(memory_format=torch.channels_last), ad)      # a copy carries no statistics
+        assert float((y_fused.float() - y_plain.float()).abs().max()) <= 2e-3 * max(1.0, float(y_plain.float().abs().max()))
+        xa = out.float() if ad is None else out.float() + ad.float().reshape(-1 if ad.dim() == 2 else 1, co, 1, 1)
+        ref = F.silu(F.group_norm(xa, 32, gn.weight.float(), gn.bias.float(), 1e-5))
+        assert float((y_fused.float() - ref).abs().max()) < 4e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_linear_epilogue_statistics_feed_the_next_groupnorm():
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, H, W, C = 2, 32, 32, 320
+    t = torch.randn(B, H * W, C, device="cuda", generator=g).half()
+    wt = (torch.randn(C, C, device="cuda", generator=g) / C ** 0.5).half()
+    bias = torch.randn(C, device="cuda", generator=g).half()
+    res = torch.randn(B, H * W, C, device="cuda", generator=g).half()
+    holder = []
+    with torch.no_grad():
+        o = fused.linear(t, wt, bias, res, stats=holder)
+    assert holder, "gip_linear_stats_f16 did not run"
+    assert torch.equal(o, fused.linear(t, wt, bias, res))
+    x = fused.attach_stats(o.reshape(B, H, W, C).permute(0, 3, 1, 2), holder[0])
+    assert fused.producer_stats(x) is holder[0]
+    gn = fused.GroupNormAct(32, C, act=True).cuda().half().requires_grad_(False)
+    ref = F.silu(F.group_norm(x.float(), 32, gn.weight.float(), gn.bias.float(), 1e-5))
+    assert float((gn(x).float() - ref).abs().max()) < 4e-3 * max(1.0, float(ref.abs().max()))
