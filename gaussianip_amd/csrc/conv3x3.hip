@@ -140,11 +140,15 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * Win + dx) * Cin : 0) + cb * CV_BK) * 2u;   // relative to the shifted base
     const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
     unsigned char* sa = smem + buf * STAGE + wave * 1024;
+    if (!((geom >> 26) & 1)) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 4096);
+      for (int i = 0; i < 4; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 4096);
+    }
     unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * 1024;
+    if (!((geom >> 27) & 1)) {
 #pragma unroll
-    for (int i = 0; i < B_ROUNDS; i++) dma16(wr, b_off[i], wtap_off, sb + i * 4096);
+      for (int i = 0; i < B_ROUNDS; i++) dma16(wr, b_off[i], wtap_off, sb + i * 4096);
+    }
   };
 
   f32x4 acc[NI][4];
@@ -190,7 +194,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   for (int kt = 0; kt < KT; kt++) {
     const int buf = kt & 1;
     if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
-    compute(smem + buf * STAGE);
+    if (!((geom >> 28) & 1)) compute(smem + buf * STAGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -321,6 +325,281 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   }
 }
 
+
+// -----------------------------------------------------------------------------------------------------------------------
+// conv_big_kernel — the same implicit GEMM with a 256-pixel x BN-channel tile (BN = 256 or 128) owned by ONE 8-wave
+// workgroup per CU instead of two (four) independent 128 x 128 workgroups.
+//
+// Why (tools/exp_conv_ablate.py, round 3): in the 128 x 128 kernel the LDS-DMA stream alone takes as long as the LDS-read +
+// MFMA stream alone (each ~70 % of the full kernel; 23 TB/s of L2 -> LDS traffic at 512 -> 512 @ 128^2, two thirds of the
+// aggregate L2 peak), so the two overlap imperfectly and neither can shrink.  A 256 x 256 tile moves HALF the operand
+// bytes per MFMA (64 KB per K step for 64 MFMAs per wave instead of 2 x 32 KB for 2 x 32), and a wave's 128 x 64 output
+// needs 24 fragment reads per 64 MFMAs instead of 16 per 32.  Structure otherwise as above: two LDS stages of a full K
+// step (2 x 64 KB), the DMA of step t + 1 issued before the MFMAs of step t, ONE barrier per K step (64 MFMAs per wave
+// between barriers), weights as the MFMA A operand, XOR chunk swizzle on the source address, XCD-aware tile order,
+// coalesced epilogue through LDS (in two 128-row halves for BN = 256) with the optional per-channel statistics.
+// Used where the 256-row tiles still fill the chip (launch_big below); no split-K, no GEGLU.
+// -----------------------------------------------------------------------------------------------------------------------
+#define CVB_BM 256
+#define CVB_THREADS 512
+
+template <int BN, int TAPS>
+__global__ void __launch_bounds__(CVB_THREADS, 2)
+conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
+                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
+                int m_tiles, int n_tiles, int Hin, int Win, int geom, float* __restrict__ chan_stats) {
+  const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int WN = BN == 256 ? 4 : 2, WM = 8 / WN;      // wave grid: WM (pixel direction) x WN (channel direction)
+  constexpr int MI = CVB_BM / WM / 16;                     // 16-pixel MFMA tiles per wave: 8 (BN = 256) or 4
+  constexpr int NI = BN / WN / 16;                         // 16-channel MFMA tiles per wave: 4
+  constexpr int A_BYTES = CVB_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_ROUNDS = CVB_BM / 64, B_ROUNDS = BN / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WN, wc = wave % WN;
+
+  const int total = m_tiles * n_tiles, id = (int)blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = id & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  const int mt = t / n_tiles, nt = t - mt * n_tiles;
+  const unsigned M = (unsigned)N * H * W;
+  const unsigned m0 = (unsigned)mt * CVB_BM;
+  const int co0 = nt * BN;
+  const int HW = H * W;
+
+  // ---- per-thread DMA descriptors: a round is 64 rows (8 waves x 8 rows), a lane fills one 16-byte chunk ----
+  const int sub_row = wave * 8 + (lane >> 3);
+  const int pchunk = lane & 7;
+  unsigned a_off[A_ROUNDS], a_mask[A_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < A_ROUNDS; i++) {
+    const int row = i * 64 + sub_row;
+    const unsigned m = m0 + row;
+    const int lchunk = pchunk ^ ((row >> 1) & 7);
+    unsigned mask = 0, off = 0;
+    if (m < M) {
+      if constexpr (TAPS == 9) {
+        const unsigned n = m / (unsigned)HW, rem = m - n * (unsigned)HW;
+        const int y = (int)(rem / (unsigned)W), xx = (int)(rem - (unsigned)y * W);
+        const int iy0 = y * cstride - pad_t, ix0 = xx * cstride - pad_l;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++)
+            if ((unsigned)(iy0 + dy) < (unsigned)Hin && (unsigned)(ix0 + dx) < (unsigned)Win) mask |= 1u << (dy * 3 + dx);
+        off = (((n * (unsigned)Hin + (unsigned)(y * cstride)) * (unsigned)Win + (unsigned)(xx * cstride)) * (unsigned)Cin + lchunk * 8) * 2u;
+      } else {
+        mask = 1u;
+        off = (m * (unsigned)Cin + lchunk * 8) * 2u;
+      }
+    }
+    a_off[i] = off;
+    a_mask[i] = mask;
+  }
+  unsigned b_off[B_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; i++) {
+    const int row = i * 64 + sub_row;
+    const int lchunk = pchunk ^ ((row >> 1) & 7);
+    const int wrow = co0 + row;
+    b_off[i] = wrow < Cout ? (unsigned)(wrow * TAPS * Cin + lchunk * 8) * 2u : CV_OOB;
+  }
+  const unsigned shift = TAPS == 9 ? (unsigned)(pad_t * Win + pad_l) * Cin * 2u : 0u;
+  const unsigned Min = TAPS == 9 ? (unsigned)N * Hin * Win : M;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)x - shift), 0, (int)(Min * (unsigned)Cin * 2u + (unsigned)(2 * Win + 2) * Cin * 2u + shift), CV_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * TAPS * Cin * 2u), CV_RSRC_FLAGS);
+
+  const int cblocks = Cin / CV_BK;
+  const int KT = TAPS * cblocks;
+
+  auto stage = [&](int tap, int cb, int buf) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * Win + dx) * Cin : 0) + cb * CV_BK) * 2u;
+    const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
+    unsigned char* sa = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 8192);
+    unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; i++) dma16(wrs, b_off[i], wtap_off, sb + i * 8192);
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; a++)
+#pragma unroll
+    for (int b = 0; b < MI; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frag_row = lane & 15, swz = (lane >> 1) & 7, kq = lane >> 4;
+  const int pix_base = (wr * (CVB_BM / WM) + frag_row) * 128;
+  const int ch_base = A_BYTES + (wc * (BN / WN) + frag_row) * 128;
+
+  // A K step = 2 k-halves x (MI / 4) groups of 4 pixel fragments = 16 MFMAs per group.  The fragments of group g + 1 are
+  // read while the MFMAs of group g run (two register sets, order pinned with sched_barrier: left alone the compiler
+  // serialises "2 reads, wait, 8 MFMAs" with the LDS latency exposed every 8 MFMAs).
+  constexpr int GROUPS = 2 * (MI / 4);
+  auto ldw = [&](f16x8* wt, const unsigned char* sbuf, int ks) {
+    const int pc = ((ks * 4 + kq) ^ swz) * 16;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) wt[ni] = *(const f16x8*)(sbuf + ch_base + ni * 2048 + pc);
+  };
+  auto ldp = [&](f16x8* px, const unsigned char* sbuf, int g) {
+    const int ks = g / (MI / 4), mg = (g % (MI / 4)) * 4;
+    const int pc = ((ks * 4 + kq) ^ swz) * 16;
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++) px[mi] = *(const f16x8*)(sbuf + pix_base + (mg + mi) * 2048 + pc);
+  };
+  auto mma = [&](const f16x8* wt, const f16x8* px, int g) {
+    const int mg = (g % (MI / 4)) * 4;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+        acc[ni][mg + mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[ni], px[mi], acc[ni][mg + mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  f16x8 w0[NI], w1[NI], pa[4], pb[4];
+  // first half of a K step (k 0..31): reads everything it needs, and the second half's first fragments while its MFMAs run
+  auto half1 = [&](const unsigned char* sbuf) {
+    ldw(w0, sbuf, 0);
+    ldp(pa, sbuf, 0);
+    if constexpr (GROUPS == 4) {
+      ldp(pb, sbuf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(w0, pa, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldw(w1, sbuf, 1);
+      ldp(pa, sbuf, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(w0, pb, 1);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      ldw(w1, sbuf, 1);
+      ldp(pb, sbuf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(w0, pa, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // second half (k 32..63): starts on fragments that are already in registers
+  auto half2 = [&](const unsigned char* sbuf) {
+    if constexpr (GROUPS == 4) {
+      ldp(pb, sbuf, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(w1, pa, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(w1, pb, 3);
+    } else {
+      mma(w1, pb, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int tap = 0, cb = 0;
+  auto advance = [&]() {
+    if (++cb == cblocks) { cb = 0; ++tap; }
+  };
+  stage(tap, cb, 0);
+  advance();
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt++) {
+      const int buf = kt & 1;
+      if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
+      half1(smem + buf * STAGE);
+      half2(smem + buf * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: half-rounded tile image [rows][BN] in LDS, 16-byte row accesses (see conv3x3_kernel) ----
+  auto add4 = [](f32x4& v, const _Float16* p) {
+    const f16x4 b = *(const f16x4*)p;
+    v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+  };
+  constexpr int ROWB = BN * 2 + 16;
+  constexpr int PASSES = BN == 256 ? 2 : 1;               // image rows per pass: 128 (BN = 256) or 256
+  constexpr int PROWS = CVB_BM / PASSES;
+  constexpr int CH = BN / 8, RPP = CVB_THREADS / CH;      // 32 chunks x 16 row lanes, or 16 x 32
+  const int chunk = tid % CH, r0 = tid / CH;
+  const int co = co0 + chunk * 8;
+  const bool mine = co < Cout;
+  float s8[2][8], q8[2][8];                               // statistics of the tile's two 128-row blocks
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) { s8[b][j] = 0.f; q8[b][j] = 0.f; }
+#pragma unroll
+  for (int pass = 0; pass < PASSES; pass++) {
+    if (PASSES == 1 || wr == pass) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) {
+        const int cl = wc * (BN / WN) + ni * 16 + (lane >> 4) * 4;
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias && co0 + cl < Cout) add4(b4, bias + co0 + cl);
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+          const int p = (PASSES == 1 ? wr * (CVB_BM / WM) : 0) + mi * 16 + (lane & 15);
+          const f32x4 v = acc[ni][mi];
+          f16x4 o;
+          o[0] = (_Float16)(v[0] + b4[0]); o[1] = (_Float16)(v[1] + b4[1]); o[2] = (_Float16)(v[2] + b4[2]); o[3] = (_Float16)(v[3] + b4[3]);
+          *(f16x4*)(smem + p * ROWB + cl * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    if (mine) {
+#pragma unroll 4
+      for (int row = r0; row < PROWS; row += RPP) {
+        const unsigned m = m0 + pass * PROWS + row;
+        if (m >= M) break;
+        f16x8 v = *(const f16x8*)(smem + row * ROWB + chunk * 16);
+        if (residual) {
+          const f16x8 rr = *(const f16x8*)(residual + (size_t)m * Cout + co);
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
+        }
+        *(f16x8*)(out + (size_t)m * Cout + co) = v;
+        if (chan_stats) {
+          const int blk = PASSES == 2 ? pass : (row >= 128 ? 1 : 0);
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float f = (float)v[j];
+            if (blk == 0) { s8[0][j] += f; q8[0][j] = fmaf(f, f, q8[0][j]); }
+            else { s8[1][j] += f; q8[1][j] = fmaf(f, f, q8[1][j]); }
+          }
+        }
+      }
+    }
+    __syncthreads();                                      // the image is rewritten by the next pass / the partials below
+  }
+  if (chan_stats) {
+    float* part = (float*)smem;                           // [RPP][BN][2]
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      if ((size_t)(mt * 2 + b) * 128 >= M) break;         // uniform
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        part[((r0 * BN) + chunk * 8 + j) * 2] = s8[b][j];
+        part[((r0 * BN) + chunk * 8 + j) * 2 + 1] = q8[b][j];
+      }
+      __syncthreads();
+      if (tid < BN && co0 + tid < Cout) {
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RPP; rr++) { S += part[(rr * BN + tid) * 2]; Q += part[(rr * BN + tid) * 2 + 1]; }
+        float* o = chan_stats + ((size_t)(mt * 2 + b) * Cout + co0 + tid) * 2;
+        o[0] = S; o[1] = Q;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // out[m][co] = sum_s slab[s][m][co] + bias[co] + residual[m][co], 4 channels per lane, fixed summation order
 __global__ void __launch_bounds__(256)
 conv_splitk_reduce_kernel(const float* __restrict__ partial, const _Float16* __restrict__ bias, const _Float16* __restrict__ residual,
@@ -346,7 +625,47 @@ conv_splitk_reduce_kernel(const float* __restrict__ partial, const _Float16* __r
 }
 
 // Debug / A-B knobs (tools/exp_conv*.py set them through ctypes; -1 = the shape heuristic below decides)
-extern "C" { int gip_dbg_conv_order = -1; int gip_dbg_conv_epilogue = -1; int gip_dbg_conv_ksplit = 0; }
+extern "C" { int gip_dbg_conv_order = -1; int gip_dbg_conv_epilogue = -1; int gip_dbg_conv_ksplit = 0; int gip_dbg_conv_ablate = 0;
+             int gip_dbg_conv_big = -1; }
+// same-box A/B of a whole training step (tools/ab_ahds.sh): GIP_CONV_EPILOGUE=0 restores the per-lane 8-byte epilogue,
+// GIP_CONV_KSPLIT_R2=1 the round-2 split-K factor; read once
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+template <int BN, int TAPS>
+static int launch_big(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W, int Cin,
+                      int Cout, hipStream_t s, int Hin, int Win, int geom, float* chan_stats) {
+  const long long M = (long long)N * H * W;
+  const int m_tiles = (int)((M + CVB_BM - 1) / CVB_BM), n_tiles = (Cout + BN - 1) / BN;
+  const size_t lds = 2 * (size_t)(CVB_BM + BN) * 128;
+  static_assert((size_t)(CVB_BM / (BN == 256 ? 2 : 1)) * (BN * 2 + 16) <= 2 * (size_t)(CVB_BM + BN) * 128 &&
+                (size_t)(CVB_THREADS / (BN / 8)) * BN * 8 <= 2 * (size_t)(CVB_BM + BN) * 128, "epilogue image / partials must fit");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_big_kernel<BN, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return 3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_big_kernel<BN, TAPS>), dim3(m_tiles * n_tiles), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
+                     (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin, Cout,
+                     m_tiles, n_tiles, Hin, Win, geom, chan_stats);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// The 256-row tile is used where its tiles still fill the chip at ONE workgroup per CU (>= 7/8 of a round of 256) and
+// Cout is a multiple of its channel width; everything else stays on the 128-row kernel (two workgroups per CU, split-K).
+static int big_tile_width(long long M, int Cout) {
+  static const int env_big = env_int("GIP_CONV_BIG", 1);
+  int use = env_big;
+  if (gip_dbg_conv_big >= 0) use = gip_dbg_conv_big;
+  if (!use || (Cout & 127)) return 0;
+  const long long m_tiles = (M + CVB_BM - 1) / CVB_BM;
+  if (!(Cout & 255) && m_tiles * (Cout / 256) >= 224) return 256;
+  // a 256 x 128 tile (Cout = 128, 640) measured equal or slower than two 128 x 128 workgroups per CU: not dispatched
+  return 0;
+}
 
 template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
@@ -354,6 +673,12 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
                   int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr) {
   if (Hin == 0) { Hin = H; Win = W; }
   const long long M = (long long)N * H * W;
+  if constexpr (!GEGLU) {
+    if (!(Cout & 7)) {
+      const int bw = big_tile_width(M, Cout);
+      if (bw == 256) return launch_big<256, TAPS>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, Hin, Win, geom, chan_stats);
+    }
+  }
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
   static_assert((size_t)CV_BM * (BN * 2 + 16) + (size_t)(CV_THREADS / (BN / 8)) * BN * 8 <= STAGES * (size_t)(CV_BM + BN) * 128,
@@ -371,7 +696,8 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   int ksplit = 1;
   const int tiles = m_tiles * n_tiles, KT = TAPS * (Cin / CV_BK);
   if (!GEGLU && workspace && tiles < 256) {
-    ksplit = 512 / tiles;
+    static const int r2 = env_int("GIP_CONV_KSPLIT_R2", 0);
+    ksplit = r2 ? (512 + tiles - 1) / tiles : 512 / tiles;
     if (ksplit > KT / 8) ksplit = KT / 8;
     if (ksplit > 16) ksplit = 16;
     while (ksplit > 1 && (size_t)ksplit * M * Cout * sizeof(float) > workspace_bytes) ksplit--;
@@ -385,14 +711,15 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   // of weights: 55 -> 50 us); measured slower everywhere else, also at 16x16 (tools/exp_conv5.py)
   int nmajor = m_tiles <= 8 && n_tiles > 1 ? 1 : 0;
   if (gip_dbg_conv_order >= 0) nmajor = gip_dbg_conv_order;
-  int lds_epi = 1;
+  static const int env_epi = env_int("GIP_CONV_EPILOGUE", 1);
+  int lds_epi = env_epi;
   if (gip_dbg_conv_epilogue >= 0) lds_epi = gip_dbg_conv_epilogue;
   if (chan_stats) {            // statistics come out of the LDS epilogue of whole-K tiles
     if (GEGLU || (Cout & 7)) return 1;
     ksplit = 1;
     lds_epi = 1;
   }
-  geom |= (nmajor << 24) | (lds_epi << 25);
+  geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26);   // bits 26-28: timing ablations (WRONG results)
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
                      N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats);

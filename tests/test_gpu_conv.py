@@ -139,3 +139,41 @@ def test_transposed_weight_cache_is_never_stale(monkeypatch):
         del w
     assert len(ptrs) == 6 and len(fused._wt_cache) == 6          # every weight kept its own address while cached
     fused._wt_cache.clear()
+
+
+# ---- round 3: the 256 x 256 tile 8-wave kernel (conv_big_kernel) ----
+@pytest.mark.parametrize("shape", [(4, 256, 256, 128, 128), (1, 64, 256, 241, 239), (2, 128, 512, 160, 192)])
+def test_conv_big_tile_kernel(shape):
+    """Shapes whose 256-pixel x 256-channel tiles fill the chip take conv_big_kernel; forced on and off through the debug
+    knob, both against the fp32 convolution of the same operands — bias, residual, ragged M (57 599 pixels), the epilogue
+    statistics of both 128-row blocks of a tile."""
+    import ctypes
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    N, ci, co, H, W = shape
+    knob = ctypes.c_int.in_dll(_lib.nn_lib()._lib, "gip_dbg_conv_big")
+    g = torch.Generator(device="cuda").manual_seed(ci + co + H)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, ci, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(co, ci, 3, 3, device="cuda", generator=g) / (3 * ci ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(co, device="cuda", generator=g).half()
+    r = torch.randn(N, co, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    outs = {}
+    try:
+        for big in (0, 1):
+            knob.value = big
+            outs[big] = (fused._conv_call(x, w, co, b), fused._conv_call(x, w, co, b, r))
+            if (H * W) % 128 == 0:
+                holder = []
+                ys = fused._conv_call(x, w, co, b, r, holder)
+                assert holder and torch.equal(ys, outs[big][1])
+                rows = ys.permute(0, 2, 3, 1).reshape(-1, 128, co).double()
+                want = torch.stack([rows.sum(1), (rows * rows).sum(1)], dim=-1)
+                assert float((holder[0].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    finally:
+        knob.value = -1
+    for big in (0, 1):
+        assert float((outs[big][0].float() - ref).abs().max()) <= 1.5e-3 * float(ref.abs().max())
+        assert float((outs[big][1].float() - (ref + r.float())).abs().max()) <= 1.5e-3 * float((ref + r.float()).abs().max())
+    assert torch.equal(outs[0][0], outs[1][0])       # same summation order: bit-identical
