@@ -184,6 +184,10 @@ def nn_lib():
         lib.gip_gn_silu_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64,
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp,
                                              ctypes.c_size_t, _vp]
+        lib.gip_gn_silu_backward_accum.restype = ctypes.c_int
+        lib.gip_gn_silu_backward_accum.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64,
+                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp,
+                                                   ctypes.c_size_t, _vp]
         lib.gip_gn_silu_forward_stats.restype = ctypes.c_int
         lib.gip_gn_silu_forward_stats.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
                                                   ctypes.c_int32, ctypes.c_float, ctypes.c_int32, _vp, ctypes.c_int32, _vp,

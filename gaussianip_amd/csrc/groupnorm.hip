@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(GN_BLOCK)
 gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const __half* __restrict__ gamma,
                 const __half* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
                 const float* __restrict__ partial, half8* __restrict__ out, long long HW, int C, int G, int splits,
-                int out_splits, float eps, int silu, const __half* __restrict__ addend, int addend_stride) {
+                int out_splits, float eps, int silu, const __half* __restrict__ addend, int addend_stride,
+                const half8* __restrict__ accum) {
   extern __shared__ float s_g[];   // [G][2]: forward mean, rstd ; backward S1/m, S2/m
   const int n = blockIdx.y, split = blockIdx.x;
   const GnGeom gm = geom(C);
@@ -202,6 +203,12 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
           if (silu) g *= dsilu_f(ga[j] * xh + be[j]);
           const float dxh = g * ga[j];
           o[j] = rs[j] * (dxh - m1[j] - xh * m2[j]);
+        }
+        if (accum) {      // the other gradient that reaches x (ResnetBlock2D: the shortcut's), added before the one rounding
+          float a[8];
+          unpack8(accum[base + r * gm.tpr], a);
+#pragma unroll
+          for (int j = 0; j < 8; j++) o[j] += a[j];
         }
       }
       out[base + r * gm.tpr] = pack8(o);
@@ -292,7 +299,7 @@ extern "C" int gip_gn_silu_forward(const void* x, const void* gamma, const void*
   hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
                      (const float*)partial, (half8*)y, (long long)HW, C, G, rsplits, splits, eps, apply_silu,
-                     (const __half*)addend, addend_stride);
+                     (const __half*)addend, addend_stride, (const half8*)nullptr);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -310,14 +317,13 @@ extern "C" int gip_gn_silu_forward_stats(const void* x, const void* gamma, const
   hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
                      (const float*)nullptr, (half8*)y, (long long)HW, C, G, 0, splits, eps, apply_silu,
-                     (const __half*)addend, addend_stride);
+                     (const __half*)addend, addend_stride, (const half8*)nullptr);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
-extern "C" int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
-                                    const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G,
-                                    int32_t apply_silu, const void* addend, int32_t addend_stride,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+static int gn_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean, const float* rstd,
+                       void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu, const void* addend,
+                       int32_t addend_stride, const void* accum, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check(x, dx, N, HW, C, G, workspace_bytes);
   if (rc) return rc;
   if (!dy || !gamma || !beta || !mean || !rstd || !workspace) return 1;
@@ -331,8 +337,26 @@ extern "C" int gip_gn_silu_backward(const void* x, const void* dy, const void* g
   hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta,
                      const_cast<float*>(mean), const_cast<float*>(rstd), (const float*)partial, (half8*)dx,
-                     (long long)HW, C, G, rsplits, splits, 0.f, apply_silu, (const __half*)addend, addend_stride);
+                     (long long)HW, C, G, rsplits, splits, 0.f, apply_silu, (const __half*)addend, addend_stride,
+                     (const half8*)accum);
   return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
+                                    const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G,
+                                    int32_t apply_silu, const void* addend, int32_t addend_stride,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return gn_backward(x, dy, gamma, beta, mean, rstd, dx, N, HW, C, G, apply_silu, addend, addend_stride, nullptr, workspace,
+                     workspace_bytes, stream);
+}
+
+extern "C" int gip_gn_silu_backward_accum(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
+                                          const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G,
+                                          int32_t apply_silu, const void* addend, int32_t addend_stride, const void* accum,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!accum) return 1;
+  return gn_backward(x, dy, gamma, beta, mean, rstd, dx, N, HW, C, G, apply_silu, addend, addend_stride, accum, workspace,
+                     workspace_bytes, stream);
 }
 
 

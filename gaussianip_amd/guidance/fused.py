@@ -407,6 +407,123 @@ def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None):
     return y if residual is None else y + residual
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# ResnetBlock2D with frozen weights as ONE autograd node (the differentiable VAE encoder)
+# ---------------------------------------------------------------------------------------------------------------------
+def _gn_fwd_raw(x, gn, addend, chan_stats):
+    """(y, mean, rstd) of GroupNormAct `gn` on NHWC fp16 x through the C-ABI (no autograd)."""
+    N, C, H, W = x.shape
+    lib = _lib.nn_lib()
+    ad_ptr, ad_stride = ctypes.c_void_p(None), 0
+    if addend is not None:
+        ad_ptr, ad_stride = _p(addend), (addend.stride(0) if addend.dim() == 2 and addend.shape[0] > 1 else 0)
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    mean = torch.empty((N, gn.num_groups), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    if chan_stats is not None:
+        rc = lib.gip_gn_silu_forward_stats(_p(x), _p(gn.weight), _p(gn.bias), _p(y), _p(mean), _p(rstd), N, H * W, C, gn.num_groups,
+                                           float(gn.eps), int(gn.act), ad_ptr, ad_stride, _p(chan_stats), (H * W) // 128, stream)
+    else:
+        ws = _workspace(x.device, lib.gip_gn_workspace_bytes(N, gn.num_groups))
+        rc = lib.gip_gn_silu_forward(_p(x), _p(gn.weight), _p(gn.bias), _p(y), _p(mean), _p(rstd), N, H * W, C, gn.num_groups,
+                                     float(gn.eps), int(gn.act), ad_ptr, ad_stride, _p(ws), ws.numel(), stream)
+    if rc != 0:
+        raise RuntimeError("GroupNorm forward failed with status %d" % rc)
+    return y, mean, rstd
+
+
+def _gn_bwd_raw(x, dy, gn, mean, rstd, addend, accum=None):
+    """dL/dx of the same GroupNorm (+ `accum`, the other gradient reaching x, in the same pass)."""
+    N, C, H, W = x.shape
+    lib = _lib.nn_lib()
+    ad_ptr, ad_stride = ctypes.c_void_p(None), 0
+    if addend is not None:
+        ad_ptr, ad_stride = _p(addend), (addend.stride(0) if addend.dim() == 2 and addend.shape[0] > 1 else 0)
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    ws = _workspace(x.device, lib.gip_gn_workspace_bytes(N, gn.num_groups))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    if accum is None:
+        rc = lib.gip_gn_silu_backward(_p(x), _p(dy), _p(gn.weight), _p(gn.bias), _p(mean), _p(rstd), _p(dx), N, H * W, C,
+                                      gn.num_groups, int(gn.act), ad_ptr, ad_stride, _p(ws), ws.numel(), stream)
+    else:
+        rc = lib.gip_gn_silu_backward_accum(_p(x), _p(dy), _p(gn.weight), _p(gn.bias), _p(mean), _p(rstd), _p(dx), N, H * W, C,
+                                            gn.num_groups, int(gn.act), ad_ptr, ad_stride, _p(accum), _p(ws), ws.numel(), stream)
+    if rc != 0:
+        raise RuntimeError("GroupNorm backward failed with status %d" % rc)
+    return dx
+
+
+def _dgrad_ok(x_shape, w):
+    N, _, H, W = x_shape
+    return w.shape[0] % 64 == 0 and w.shape[1] % 4 == 0 and _conv_tiles(N, H, W, w.shape[1]) >= _MIN_CONV_TILES
+
+
+def resblock_grad_supported(x, block):
+    """The whole-block autograd node applies: fp16 NHWC input that needs a gradient, frozen fp16 weights, no time embedding
+    (the VAE encoder's ResnetBlock2D), both convolutions and both data gradients on the MFMA kernel."""
+    c1, c2 = block.conv1.weight, block.conv2.weight
+    return (os.environ.get("GIP_RESBLOCK_NODE", "1") != "0" and fusable(x) and torch.is_grad_enabled() and x.requires_grad and
+            block.time_emb_proj is None and not c1.requires_grad and c1.dtype == torch.float16 and
+            c1.is_contiguous(memory_format=torch.channels_last) and c2.is_contiguous(memory_format=torch.channels_last) and
+            x.shape[1] % 64 == 0 and c1.shape[0] % 64 == 0 and x.numel() * 2 < (1 << 31) and
+            x.shape[0] * x.shape[2] * x.shape[3] * c1.shape[0] * 2 < (1 << 31) and
+            _conv_tiles(x.shape[0], x.shape[2], x.shape[3], c1.shape[0]) >= _MIN_CONV_TILES and
+            _dgrad_ok(x.shape, c1) and _dgrad_ok((x.shape[0], c1.shape[0], x.shape[2], x.shape[3]), c2) and
+            block.norm1.weight.dtype == torch.float16 and not block.norm1.weight.requires_grad)
+
+
+class _ResBlockNode(torch.autograd.Function):
+    """ResnetBlock2D (GroupNorm+SiLU -> conv1 -> GroupNorm+SiLU -> conv2, + shortcut) with frozen weights, differentiable
+    with respect to x only.  One node instead of five, so that its backward can do what autograd cannot: x receives two
+    gradients (through norm1 and through the shortcut) and their sum rides in the GroupNorm backward's apply pass
+    (gip_gn_silu_backward_accum) instead of a separate pass over the tensor; nothing but x, conv1's output and the four
+    statistics vectors is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, block, stats_out):
+        c1, c2 = block.conv1, block.conv2
+        y1, mean1, rstd1 = _gn_fwd_raw(x, block.norm1, None, producer_stats(x))
+        h1_stats = []
+        h = _conv_call(y1, c1.weight, c1.weight.shape[0], None, None, h1_stats)
+        del y1
+        y2, mean2, rstd2 = _gn_fwd_raw(h, block.norm2, c1.bias, h1_stats[0] if h1_stats else None)      # conv1's bias enters as the addend
+        if block.conv_shortcut is None:
+            res = x
+        else:
+            res = conv1x1(x, block.conv_shortcut.weight, block.conv_shortcut.bias)
+        out = _conv_call(y2, c2.weight, c2.weight.shape[0], c2.bias, res.contiguous(memory_format=torch.channels_last), stats_out)
+        ctx.save_for_backward(x, h, mean1, rstd1, mean2, rstd2)
+        ctx.block = block
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        block = ctx.block
+        c1, c2 = block.conv1, block.conv2
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        d_y2 = _conv_call(dy, _transposed_weight(c2.weight), c2.weight.shape[1])
+        d_h = _gn_bwd_raw(h, d_y2, block.norm2, mean2, rstd2, c1.bias)
+        del d_y2
+        d_y1 = _conv_call(d_h, _transposed_weight(c1.weight), c1.weight.shape[1])
+        del d_h
+        if block.conv_shortcut is None:
+            short = dy
+        else:
+            ws_ = block.conv_shortcut.weight
+            wt = _wt_cache.get("1x1t", ws_, lambda t: t.detach().reshape(t.shape[0], t.shape[1]).t().contiguous())   # [Cin, Cout]
+            N, Co, H, W = dy.shape
+            short = F.linear(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt).view(N, H, W, wt.shape[0]).permute(0, 3, 1, 2)
+        return _gn_bwd_raw(x, d_y1, block.norm1, mean1, rstd1, None, accum=short), None, None
+
+
+def resblock_with_grad(x, block):
+    holder = []
+    out = _ResBlockNode.apply(x, block, holder)
+    return attach_stats(out, holder[0] if holder else None)
+
+
 def _conv_s2_supported(x, w):
     return (fusable(x) and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0 and w.dtype == torch.float16 and
             w.is_contiguous(memory_format=torch.channels_last) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and

@@ -93,6 +93,7 @@ class PromptEmbeddings:
             idx = self.direction_fn(elevation, azimuth, center, all_vis_all, camera_distances)
         else:
             idx = torch.zeros(B, dtype=torch.long, device=self.pos.device)
+        idx = idx.to(self.pos.device, non_blocking=True)
         pick = lambda tab: tab[idx % tab.shape[0]]  # noqa: E731
         return torch.cat([pick(self.pos), pick(self.neg), pick(self.null)], dim=0)
 

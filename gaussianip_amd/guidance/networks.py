@@ -74,6 +74,8 @@ class ResBlock(nn.Module):
         projection enter norm2 as its per-(sample, channel) addend; conv2's bias, the shortcut's bias and the residual
         add are one pass.  `self.staged_addend` (set by _Encoder.stage_time_embedding) already holds
         conv1.bias + time_emb_proj(silu(temb)) for this block when the batched projection is in use."""
+        if fused.resblock_grad_supported(x, self):
+            return fused.resblock_with_grad(x, self)         # differentiable path (VAE encoder): one autograd node per block
         addend, self.staged_addend = self.staged_addend, None
         if addend is not None and addend.shape[0] != x.shape[0]:
             addend = addend[:x.shape[0]]           # shared prefix of a replicated batch (see _Encoder.encode)

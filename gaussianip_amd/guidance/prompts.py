@@ -96,7 +96,7 @@ class PromptProcessorOutput:
         B = elevation.shape[0]
         if view_dependent_prompting:
             idx = direction_index(elevation, azimuth, center, all_vis_all, camera_distances, self.head_offset)
-            idx = idx.to(self.text_embeddings_vd.device)
+            idx = idx.to(self.text_embeddings_vd.device, non_blocking=True)      # a host-side batch: the lookup ran on the host
             text, uncond = self.text_embeddings_vd[idx], self.uncond_text_embeddings_vd[idx]
         else:
             text = self.text_embeddings.expand(B, -1, -1)

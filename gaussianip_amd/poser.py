@@ -34,15 +34,27 @@ class Skeleton:
         if points3D is None:
             pts[:, [1, 2]] = pts[:, [2, 1]]                     # opengl -> blender (poser.py:694)
         self.device = torch.device(device)
-        self.points3D = torch.cat([torch.from_numpy(pts), torch.ones(pts.shape[0], 1)], dim=1).to(self.device)   # homogeneous
-        self.lines = torch.tensor(LINES, dtype=torch.long, device=self.device)
+        self._points3D_host = torch.cat([torch.from_numpy(pts), torch.ones(pts.shape[0], 1)], dim=1)              # homogeneous
+        self.points3D = self._points3D_host.to(self.device)
+        self._lines_host = torch.tensor(LINES, dtype=torch.long)
+        self.lines = self._lines_host.to(self.device)
         zoom = torch.zeros(18, dtype=torch.bool)
         zoom[[0, 1, 3, 6, 14, 15, 16, 17]] = True              # key points kept in a head zoom (poser.py:846-849)
+        self._zoom_host = zoom
         self._zoom = zoom.to(self.device)
         self.name = list(NAMES)
 
     def scale(self, delta):
         self.points3D[:, :3] *= 1.1 ** (-delta)
+        if self.points3D.data_ptr() != self._points3D_host.data_ptr():
+            self._points3D_host[:, :3] *= 1.1 ** (-delta)
+
+    def _on(self, dev):
+        """(points3D, lines, zoom) on `dev`: host-side batches (the data module's tensors are CPU tensors) are projected and
+        classified on the host — a few hundred flops per view — instead of through ~100 two-microsecond GPU launches."""
+        if dev.type == "cpu":
+            return self._points3D_host, self._lines_host, self._zoom_host
+        return self.points3D, self.lines, self._zoom
 
     @property
     def hand_centers(self):
@@ -51,7 +63,7 @@ class Skeleton:
     # ------------------------------------------------------------------ projection + visibility (poser.py:836-876)
     def project(self, mvp, H, W):
         """mvp [V,4,4] -> NDC points [V,18,3], pixel xs, ys [V,18]."""
-        pts = self.points3D.to(mvp.dtype) @ mvp.transpose(1, 2)              # [V,18,4]
+        pts = self._on(mvp.device)[0].to(mvp.dtype) @ mvp.transpose(1, 2)              # [V,18,4]
         ndc = pts[..., :3] / pts[..., 3:]
         return ndc, (ndc[..., 0] + 1) / 2 * W, (ndc[..., 1] + 1) / 2 * H
 
@@ -62,7 +74,7 @@ class Skeleton:
         V = mask.shape[0]
         az = torch.as_tensor(azimuth, device=mask.device, dtype=torch.float32).reshape(V)
         hz = torch.as_tensor(head_zoom, device=mask.device, dtype=torch.bool).reshape(V, 1)
-        mask = torch.where(hz, self._zoom.to(mask.device)[None].expand(V, 18), mask).clone()
+        mask = torch.where(hz, self._on(mask.device)[2][None].expand(V, 18), mask).clone()
         mask[:, 16] &= ~((az > 0) & (az < 60))
         mask[:, 17] &= ~((az > 120) & (az < 180))
         z0, z_l, z_r = ndc[:, 0, 2], ndc[:, 17, 2], ndc[:, 16, 2]
@@ -78,12 +90,13 @@ class Skeleton:
 
     def limb_parameters(self, xs, ys, mask):
         """[V,17,6] float32: (int centre x, int centre y, int(len/2), drawn?, cos, sin of the int-degree angle) — poser.py:889-895."""
-        X, Y = xs[:, self.lines], ys[:, self.lines]                            # [V,17,2]
+        lines = self._on(xs.device)[1]
+        X, Y = xs[:, lines], ys[:, lines]                            # [V,17,2]
         mX, mY = X.mean(dim=-1), Y.mean(dim=-1)
         length = ((Y[..., 0] - Y[..., 1]) ** 2 + (X[..., 0] - X[..., 1]) ** 2) ** 0.5
         ang = torch.rad2deg(torch.atan2((Y[..., 0] - Y[..., 1]).double(), (X[..., 0] - X[..., 1]).double())).trunc()
         rad = torch.deg2rad(ang)
-        on = mask[:, self.lines[:, 0]] & mask[:, self.lines[:, 1]]
+        on = mask[:, lines[:, 0]] & mask[:, lines[:, 1]]
         return torch.stack([mX.trunc().float(), mY.trunc().float(), (length / 2).trunc().float(), on.float(),
                             torch.cos(rad).float(), torch.sin(rad).float()], dim=-1).contiguous()
 
@@ -92,13 +105,19 @@ class Skeleton:
         """mvp [V,4,4] (or [4,4]) -> (canvas [V,H,W,3] float32 in [0,1], all_vis [V] (1 if every key point is drawn),
         xy [V,18,2]).  Same outputs as poser.py:832-904 per view, batched."""
         single = mvp.dim() == 2
-        mvp = mvp.reshape(-1, 4, 4).to(self.device, torch.float32, non_blocking=True)
+        # host-side inputs (mvp, azimuth, head_zoom all CPU / Python values): the small per-view algebra stays on the host
+        # and only the three packed parameter arrays of the drawing kernel are uploaded; all_vis / xy then are CPU tensors
+        host = mvp.device.type == "cpu" and not (torch.is_tensor(azimuth) and azimuth.is_cuda) and \
+            not (torch.is_tensor(head_zoom) and head_zoom.is_cuda)
+        mvp = mvp.reshape(-1, 4, 4).to(torch.float32) if host else mvp.reshape(-1, 4, 4).to(self.device, torch.float32, non_blocking=True)
         V = mvp.shape[0]
         ndc, xs, ys = self.project(mvp, H, W)
         mask = self.visibility(ndc, xs, ys, H, W, azimuth, head_zoom, enable_occlusion)
         limbs = self.limb_parameters(xs, ys, mask)
         pts_px = torch.stack([xs.trunc(), ys.trunc()], dim=-1).to(torch.int32).contiguous()
         vis8 = mask.to(torch.uint8).contiguous()
+        if host and self.device.type == "cuda":
+            pts_px, vis8, limbs = (t.to(self.device, non_blocking=True) for t in (pts_px, vis8, limbs))
         if self.device.type == "cuda":
             from . import _lib
             canvas = torch.empty((V, H, W, 3), dtype=torch.float32, device=self.device)

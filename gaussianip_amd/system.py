@@ -137,7 +137,8 @@ class StageOneStep:
             az, cent, mvp = torch.as_tensor(batch["azimuth"]), torch.as_tensor(batch["center"]), batch["mvp_mtx"]
             if self.sharding is not None:           # (indexing with a Python list would synchronise: cached index tensors)
                 az, cent, mvp = self._take(az, ids), self._take(cent, ids), self._take(mvp, ids)
-            az, cent = az.to(dev, non_blocking=True), cent.to(dev, non_blocking=True)
+            if not (mvp.device.type == "cpu" and az.device.type == "cpu" and cent.device.type == "cpu"):
+                az, cent = az.to(dev, non_blocking=True), cent.to(dev, non_blocking=True)       # device-side batch: stay on the device
             head_zoom = (cent == self.head_offset) & (az > 0)        # :176
             pose, all_vis, _ = self.skeleton.openpose_draw(mvp, self.pose_hw[0], self.pose_hw[1], az, head_zoom, True)
             out["pose"], out["all_vis_all"] = pose, all_vis

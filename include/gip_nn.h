@@ -38,6 +38,13 @@ int gip_gn_silu_backward(const void* x, const void* dy, const void* gamma, const
                          const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu,
                          const void* addend, int32_t addend_stride,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* gip_gn_silu_backward with `accum` [N, HW, C] half added to the result in the same pass: dx = dL/dx of the GroupNorm +
+ * accum (fp32 sum, one rounding).  In ResnetBlock2D's backward x receives two gradients — through norm1 and through the
+ * shortcut — which autograd would add in a separate pass over the tensor.  dx may alias accum. */
+int gip_gn_silu_backward_accum(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
+                               const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu,
+                               const void* addend, int32_t addend_stride, const void* accum,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* Forward with the statistics pass taken out: `chan_stats` [N * blocks_per_sample][C][2] float holds, per 128-row block of
  * x and channel, the sum and the sum of squares of x's elements — written by the epilogue of the kernel that PRODUCED x
  * (gip_conv3x3_stats_nhwc_f16 / gip_linear_stats_f16; HW % 128 == 0 so that a block never straddles two samples).  One

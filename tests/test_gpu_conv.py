@@ -177,3 +177,49 @@ def test_conv_big_tile_kernel(shape):
         assert float((outs[big][0].float() - ref).abs().max()) <= 1.5e-3 * float(ref.abs().max())
         assert float((outs[big][1].float() - (ref + r.float())).abs().max()) <= 1.5e-3 * float((ref + r.float()).abs().max())
     assert torch.equal(outs[0][0], outs[1][0])       # same summation order: bit-identical
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (128, 256)])
+def test_resblock_as_one_autograd_node(cin, cout, monkeypatch):
+    """The differentiable ResnetBlock2D of the VAE encoder as ONE autograd node (fused._ResBlockNode: the shortcut's
+    gradient rides in the GroupNorm backward's apply pass) against the same block in fp32 PyTorch ops, forward and
+    dL/dx, and against the five-node path."""
+    from gaussianip_amd.guidance import fused
+    from gaussianip_amd.guidance.networks import ResBlock, init_for_benchmark
+    torch.manual_seed(0)
+    blk = init_for_benchmark(ResBlock(cin, cout, temb_dim=0, eps=1e-6), seed=3)
+    with torch.no_grad():
+        for m in (blk.norm1, blk.norm2):
+            m.weight.add_(torch.randn_like(m.weight) * 0.2)
+            m.bias.add_(torch.randn_like(m.bias) * 0.2)
+        blk.conv1.bias.add_(torch.randn_like(blk.conv1.bias) * 0.3)
+        blk.conv2.bias.add_(torch.randn_like(blk.conv2.bias) * 0.3)
+    ref_blk = blk.cuda().float()
+    import copy
+    blk = copy.deepcopy(ref_blk).half().to(memory_format=torch.channels_last).requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(2, cin, 64, 64, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, cout, 64, 64, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+
+    def run(node):
+        monkeypatch.setenv("GIP_RESBLOCK_NODE", "1" if node else "0")
+        xi = x.clone(memory_format=torch.channels_last).requires_grad_(True)
+        seen = []
+        orig = fused._ResBlockNode.apply
+        monkeypatch.setattr(fused._ResBlockNode, "apply", staticmethod(lambda *a: (seen.append(1), orig(*a))[1]))
+        y = blk(xi)
+        monkeypatch.setattr(fused._ResBlockNode, "apply", orig)
+        assert bool(seen) == node
+        (dx,) = torch.autograd.grad(y, xi, dy)
+        return y.detach(), dx
+
+    y1, dx1 = run(True)
+    y0, dx0 = run(False)
+    xr = x.float().contiguous().requires_grad_(True)
+    ref_blk.requires_grad_(False)
+    yr = ref_blk(xr)
+    (dxr,) = torch.autograd.grad(yr, xr, dy.float().contiguous())
+    for got_y, got_dx in ((y1, dx1), (y0, dx0)):
+        assert float((got_y.float() - yr).abs().max()) < 6e-3 * max(1.0, float(yr.abs().max()))
+        assert float((got_dx.float() - dxr).abs().max()) < 8e-3 * max(1.0, float(dxr.abs().max()))
+    assert float((dx1.float() - dx0.float()).abs().max()) < 4e-3 * max(1.0, float(dx0.float().abs().max()))

@@ -64,3 +64,26 @@ def test_pose_maps_match_the_oracle_and_the_loop_rules():
     # single-view form, as the reference calls it
     c0, v0, xy0 = sk.openpose_draw(mvp[0], H, W, azs[0], head_zoom[0])
     assert torch.equal(c0, canvas[0]) and int(v0) == int(all_vis[0])
+
+
+def test_host_side_batch_gives_the_same_pose_maps():
+    """mvp / azimuth / head_zoom as CPU tensors (the data module's batch): projection, visibility rules and limb
+    parameters run on the host, only the drawing kernel's packed parameters are uploaded — same canvas, same flags."""
+    import scenes
+    from gaussianip_amd.poser import Skeleton
+    sk = Skeleton("cuda")
+    sk.scale(-10)
+    H = W = 512
+    azs = torch.tensor([-170.0, -95.0, 10.0, 45.0, 100.0, 150.0])
+    cams = [scenes.camera(e, float(a), 1.5, 55.0, H, W) for e, a in zip((-20, 5, 25, 0, -10, 15), azs)]
+    mvp = torch.stack([torch.from_numpy(c["projmatrix"]).T for c in cams])
+    hz = torch.tensor([False, False, True, False, True, False])
+    c_dev, v_dev, xy_dev = sk.openpose_draw(mvp.cuda(), H, W, azs.cuda(), hz.cuda())
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        c_host, v_host, xy_host = sk.openpose_draw(mvp, H, W, azs, hz)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert v_host.device.type == "cpu" and c_host.is_cuda
+    assert torch.equal(v_host, v_dev.cpu())
+    assert torch.equal(c_host, c_dev)

@@ -89,7 +89,8 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         st.visibility_filter = st.visibility(st.radii)
 
     def step(i):
-        batch = scenes.train_batch(cam_rng, B, H, W, device=dev)
+        # the data module's batch: CPU tensors (camera matrices AND the per-view scalars); what the GPU needs is uploaded by its consumer
+        batch = scenes.train_batch(cam_rng, B, H, W, device=None if os.environ.get("GIP_HOST_BATCH", "1") == "1" else dev)
         loss, out, gout = stage.training_step(i, batch, guidance, prompt_utils, True)
         stage.optimizer_step(loss, i, scaler=scaler, exchange=(shard.exchange if shard is not None else exchange) if world > 1 else None)
         return loss
