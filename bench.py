@@ -7,10 +7,17 @@ threestudio/systems/GaussianIP.py:154-173), inputs resident in HBM, synthetic da
 a 100k-point human-shaped surface (SMPL-X weights are licensed and absent), isotropic 3-NN scales, opacity 0.1, SH
 degree 0 — the shipped init (gaussian_model.py:113-136) — and 4 cameras from the training ranges.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own 4 views of the replicated
-Gaussian state (weak scaling, view-sharded data parallelism) and the per-step exchange of SURVEY.md §8e runs inside the
-timed region over RCCL: all_reduce(sum) of the parameter gradients (one flat 14*P-float bucket), all_reduce(sum) of the
-view-space gradient norms and all_reduce(max) of the radii.
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] — the 4 views of ONE optimizer
+step are sharded over the ranks of a seed group (2 GPUs: 2 views each, 4 GPUs: 1 view each, 8 GPUs: 4 views x 2 seed
+groups; parallel.ViewSharding) and the per-step exchange of SURVEY.md §8e runs inside the timed region over RCCL, inside
+each seed group: all_reduce(sum) of the parameter gradients + view-space gradient norms (one flat bucket) and
+all_reduce(max) of the radii / depth maximum.  `value` = all ranks' views x H x W per second ("scaling": "strong": the
+work of an optimizer step is fixed, a rank's share shrinks with N).  The round-1/2 layout (every rank its own 4 cameras,
+a 4 x N batch) is reported beside it as `replicas_layout`.
+
+Timing: W warmup steps, then R = --repeats windows of EXACTLY K steps, each bracketed by barrier + synchronize on both
+sides and MAX-reduced over the ranks; `ms_per_step` / `value` are the MEDIAN window (config.repeats, all windows in
+`window_ms_per_step`): 20 steps are a 10 ms region, a single one is a +-2 % instrument.
 
 "ahds": the full AHDS stage-1 training step of BASELINE.json configs[2] (render 4 views -> VAE encode -> ControlNet +
 U-Net ANPG at batch 12 -> SDS -> backward -> Adam), measured by tools/bench_ahds.py after the raster timing; steps/s,
@@ -64,7 +71,10 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=10)
     ap.add_argument("--no-ahds", action="store_true", help="skip the full AHDS training-step measurement (configs[2])")
     ap.add_argument("--ahds-steps", type=int, default=10)
-    ap.add_argument("--prewarm", type=int, default=60, help="untimed steps in front of the warmup steps (GPU clock ramp)")
+    ap.add_argument("--prewarm", type=int, default=0, help="extra untimed steps in front of the warmup steps (reported)")
+    ap.add_argument("--repeats", type=int, default=11, help="timed windows of --steps steps each; the median is reported")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact_lists mode measurement")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the 1-GPU proxy of one configs[3] rank's shard")
     ap.add_argument("--no-trained", action="store_true", help="skip the secondary raster measurement on a trained-looking state")
     args = ap.parse_args()
 
@@ -94,67 +104,85 @@ def main():
     P, H, W, V = args.gaussians, args.size, args.size, args.views
     K = 1  # SH coefficients per channel at the shipped sh_degree 0
     sc = scenes.make_scene("human", P, seed=42, sh_degree=0)
-    cams = scenes.train_cameras(V, seed=42 + rank, H=H, W=W)   # each rank (= view shard) gets its own cameras
+    from gaussianip_amd import parallel
     bg = torch.zeros(3, device=dev)
-    sts = [GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
-        viewmatrix=torch.from_numpy(c["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(c["projmatrix"]).to(dev),
-        sh_degree=0, campos=torch.from_numpy(c["campos"]).to(dev), prefiltered=False, debug=False) for c in cams]
+
+    def settings(cam_list):
+        return [GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+            viewmatrix=torch.from_numpy(c["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(c["projmatrix"]).to(dev),
+            sh_degree=0, campos=torch.from_numpy(c["campos"]).to(dev), prefiltered=False, debug=False) for c in cam_list]
+
+    shard = parallel.ViewSharding(V) if world > 1 else None
+    # N = 1: the 4 cameras of the step.  N > 1 (configs[3]): every rank of a seed group draws the SAME 4 cameras (seed offset
+    # per seed group, launch.py:80) and renders its share of them
+    cams = scenes.train_cameras(V, seed=42 + (shard.seed_id if shard is not None else 0), H=H, W=W)
+    sts = settings(cams if shard is None else [c for i, c in enumerate(cams) if i in shard.views])
+    Vl = len(sts)                                   # views this rank renders per step
     t = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in sc.items()}
     gen = torch.Generator(device=dev).manual_seed(1234)
     gC = torch.randn((V, 3, H, W), device=dev, generator=gen) * 1e-3
     gD = torch.randn((V, 1, H, W), device=dev, generator=gen) * 1e-3
     names = ["means3D", "shs", "opacities", "scales", "rotations"]
-
-    from gaussianip_amd import parallel
     plist = [t[n] for n in names]
 
-    def step():
-        m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
-        color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], sts, shs=t["shs"],
-                                                     scales=t["scales"], rotations=t["rotations"])
-        if world > 1:       # the MAX bucket holds forward outputs: its all-reduce overlaps the backward
-            pending = parallel.exchange_forward_stats(radii, depth)
-        grads = torch.autograd.grad([color, depth], plist + [m2d], [gC, gD])
-        if world > 1:
-            for p_, g_ in zip(plist, grads[:-1]):
-                p_.grad = g_
-            parallel.exchange_sum(plist, viewspace_grads=grads[-1])
-            pending.wait()
-        return color
+    def make_step(st_list, group, exchange):
+        nv = len(st_list)
 
-    # Clock pre-warm (reported as config.prewarm_steps): a process starts on an idle GPU and the first ~30 ms of work run at
-    # ramping clocks (measured: 0.67 -> 0.60 ms per synchronised step over the first 40 steps, tools/diag/step_settling.py);
-    # with a short --warmup that ramp would sit inside the timed region.  These steps are the same step, untimed, in front
-    # of the W warmup steps of the contract; the same count on every rank (the step has collectives at N > 1).
+        def step():
+            m2d = torch.zeros((nv, P, 3), device=dev, requires_grad=True)
+            color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], st_list, shs=t["shs"],
+                                                         scales=t["scales"], rotations=t["rotations"])
+            if exchange:       # the MAX bucket holds forward outputs: its all-reduce overlaps the backward
+                pending = parallel.exchange_forward_stats(radii, depth, group=group)
+            grads = torch.autograd.grad([color, depth], plist + [m2d], [gC[:nv], gD[:nv]])
+            if exchange:
+                for p_, g_ in zip(plist, grads[:-1]):
+                    p_.grad = g_
+                parallel.exchange_sum(plist, viewspace_grads=grads[-1], group=group)
+                pending.wait()
+            return color
+        return step
+
+    def timed_windows(step_fn, repeats, steps, warmup):
+        """W warmup steps, then `repeats` windows of exactly `steps` steps, each between barrier + synchronize pairs and
+        MAX-reduced over the ranks.  Returns the per-window seconds."""
+        for _ in range(warmup):
+            step_fn()
+        out_ = []
+        for _ in range(repeats):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:
+                et = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(et, op=dist.ReduceOp.MAX)
+                el = float(et.item())
+            out_.append(el)
+        return out_
+
+    step = make_step(sts, shard.group if shard is not None else None, world > 1)
     for _ in range(args.prewarm):
         step()
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
-
+    windows = timed_windows(step, max(args.repeats, 1), args.steps, args.warmup)
+    elapsed = sorted(windows)[len(windows) // 2]                     # the median window
+    n_groups = shard.n_seed_groups if shard is not None else 1
     ms_per_step = elapsed / args.steps * 1e3
-    views_total = world * V * args.steps
+    views_total = n_groups * V * args.steps                          # views of all optimizer steps taken in a window
     mpix_s = views_total * H * W / elapsed / 1e6
 
     # forward only (SURVEY §8d asks for forward and forward+backward separately): the same 4-view launch set rendered
     # without a backward to follow.  Grad mode stays on so that the capacity check stays deferred as in training; an
     # output render under no_grad additionally waits for its header (one host round trip per call)
     def fwd_step():
-        m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        m2d = torch.zeros((Vl, P, 3), device=dev, requires_grad=True)
         return rasterize_views(t["means3D"], m2d, t["opacities"], sts, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
     for _ in range(3):
         fwd_step()
@@ -173,10 +201,10 @@ def main():
         pl_ = [tt_[n] for n in names]
 
         def step_t():
-            m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+            m2d = torch.zeros((Vl, P, 3), device=dev, requires_grad=True)
             color, radii, depth, alpha = rasterize_views(tt_["means3D"], m2d, tt_["opacities"], sts, shs=tt_["shs"],
                                                          scales=tt_["scales"], rotations=tt_["rotations"])
-            torch.autograd.grad([color, depth], pl_ + [m2d], [gC, gD])
+            torch.autograd.grad([color, depth], pl_ + [m2d], [gC[:Vl], gD[:Vl]])
         for _ in range(max(args.warmup, 3)):
             step_t()
         torch.cuda.synchronize()
@@ -185,50 +213,38 @@ def main():
             step_t()
         torch.cuda.synchronize()
         dtt = (time.perf_counter() - t0) / args.steps
-        trained = {"ms_per_step": round(dtt * 1e3, 4), "mpix_per_s": round(V * H * W / dtt / 1e6, 1),
+        trained = {"ms_per_step": round(dtt * 1e3, 4), "mpix_per_s": round(Vl * H * W / dtt / 1e6, 1),
                    "state": "opacity 0.6, scales x U(1,3) per axis, random rotations / colours (tests/scenes.trained_look)"}
         del tt_, pl_
 
-    # ---- BASELINE.json configs[3] layout of the same raster step (N > 1): the 4 views of ONE optimizer step sharded over
-    # the ranks of a seed group (8 GPUs: 2 seed groups with their own process groups), gradients SUM-reduced inside it
-    config3 = None
+    # ---- N > 1 extra: the replica layout of rounds 1-2 (every rank its own 4 cameras of the replicated Gaussians, a 4 x N
+    # batch, gradients averaged over all ranks) — weak scaling, NOT the contract value
+    replicas = None
     if world > 1:
-        shard = parallel.ViewSharding(V)
-        cams3 = scenes.train_cameras(V, seed=42 + shard.seed_id, H=H, W=W)        # one camera set per seed group
-        sts3 = [GaussianRasterizationSettings(
-            image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
-            viewmatrix=torch.from_numpy(c["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(c["projmatrix"]).to(dev),
-            sh_degree=0, campos=torch.from_numpy(c["campos"]).to(dev), prefiltered=False, debug=False)
-            for i, c in enumerate(cams3) if i in shard.views]
-        Vl = len(sts3)
+        sts_r = settings(scenes.train_cameras(V, seed=42 + rank, H=H, W=W))
+        wr_ = timed_windows(make_step(sts_r, None, True), 3, args.steps, args.warmup)
+        dtr = sorted(wr_)[1] / args.steps
+        replicas = {"layout": "replicas: %d ranks x %d cameras, one averaged optimizer step" % (world, V),
+                    "ms_per_step": round(dtr * 1e3, 4), "views_per_s": round(world * V / dtr, 2),
+                    "mpix_per_s": round(world * V * H * W / dtr / 1e6, 2), "scaling": "weak"}
 
-        def step3():
-            m2d = torch.zeros((Vl, P, 3), device=dev, requires_grad=True)
-            color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], sts3, shs=t["shs"],
-                                                         scales=t["scales"], rotations=t["rotations"])
-            pending = parallel.exchange_forward_stats(radii, depth, group=shard.group)
-            grads = torch.autograd.grad([color, depth], plist + [m2d], [gC[:Vl], gD[:Vl]])
-            for p_, g_ in zip(plist, grads[:-1]):
-                p_.grad = g_
-            vs = grads[-1].sum(0)
-            parallel.exchange_sum(plist, vs, group=shard.group)
-            pending.wait()
-
-        for _ in range(args.warmup):
-            step3()
-        dist.barrier()
+    # ---- the bit-exact-lists mode (GipRasterConfig::exact_lists: the fork's tile / index buffers bit for bit; the default
+    # emits the same lists minus provably dead entries): the same step, driver-measured (N = 1 only)
+    exact = None
+    if world == 1 and not args.no_exact:
+        os.environ["GIP_RASTER_EXACT_LISTS"] = "1"
+        try:
+            we_ = timed_windows(step, 5, args.steps, max(args.warmup, 3))
+            dte = sorted(we_)[2] / args.steps
+            stages_e, nr_e = R.profile_stages(t["means3D"].detach(), t["opacities"].detach(), sts, gC[:Vl], gD[:Vl], None, shs=t["shs"].detach(),
+                                              scales=t["scales"].detach(), rotations=t["rotations"].detach(), iters=3)
+            exact = {"ms_per_step": round(dte * 1e3, 4), "mpix_per_s": round(V * H * W / dte / 1e6, 1),
+                     "num_rendered_per_view": int(nr_e / V), "slowdown_vs_default": round(dte * 1e3 / ms_per_step, 4)}
+        finally:
+            os.environ["GIP_RASTER_EXACT_LISTS"] = "0"
+        for _ in range(3):
+            step()                      # back to the default mode's capacity hint
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step3()
-        dist.barrier()
-        torch.cuda.synchronize()
-        et = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        dt3 = float(et.item()) / args.steps
-        config3 = {"layout": "4 views sharded over %d GPU(s) x %d seed group(s)" % (shard.group_size, shard.n_seed_groups),
-                   "ms_per_step": round(dt3 * 1e3, 4), "optimizer_steps_per_s": round(shard.n_seed_groups / dt3, 2),
-                   "views_per_s": round(shard.n_seed_groups * V / dt3, 2), "scaling": "strong within a seed group"}
 
     # ---- metric (i) of BASELINE.json: full AHDS training steps/s (configs[2]; at N>1 configs[3]'s view sharding) ----
     ahds = None
@@ -238,55 +254,88 @@ def main():
         try:
             ahds = bench_ahds.measure(steps=args.ahds_steps, warmup=4, gaussians=P, flops=(rank == 0), rank=rank,
                                       world=world, device=dev)
+            if world == 1 and not args.no_trained:
+                tr = bench_ahds.measure(steps=max(args.ahds_steps // 2, 4), warmup=3, gaussians=P, device=dev, trained=True, pieces=False)
+                ahds["trained_state"] = {"value": tr["value"], "ms_per_step": tr["ms_per_step"],
+                                         "state": "opacity 0.6, scales x U(1,3) per axis, random rotations / colours (tests/scenes.trained_look)"}
+            if world == 1 and not args.no_proxy:
+                # 1-GPU proxy of ONE rank of BASELINE.json configs[3] (no 8-GPU node here): the shard of a rank in a 4-rank
+                # seed group (1 view raster + 1-image VAE fwd/bwd + batch-3 ControlNet / U-Net) and in a 2-rank group
+                # (2 views), collectives not executed (a rank's step then lacks two small all-reduces, ~0.1 ms measured with
+                # stubs in tools/exp_exchange_overhead.py).  implied_* = what N such ranks deliver if nothing else is lost.
+                prox = {}
+                for k in (4, 2):
+                    r_ = bench_ahds.measure(steps=max(args.ahds_steps // 2, 4), warmup=3, gaussians=P, device=dev, proxy_group=k, pieces=False)
+                    prox["group_of_%d" % k] = {"views_per_rank": 4 // k, "ms_per_step": r_["ms_per_step"]}
+                t1, t4, t2 = ahds["ms_per_step"], prox["group_of_4"]["ms_per_step"], prox["group_of_2"]["ms_per_step"]
+                prox["implied_views_per_s"] = {"1": round(4e3 / t1, 2), "2": round(4e3 / t2, 2), "4": round(4e3 / t4, 2), "8": round(8e3 / t4, 2)}
+                prox["implied_speedup_vs_1gpu"] = {"2": round(t1 / t2, 3), "4": round(t1 / t4, 3), "8": round(2 * t1 / t4, 3)}
+                prox["note"] = "measured on ONE GPU; the RCCL all-reduces of a real group are not in these times"
+                ahds["config3_proxy"] = prox
         except Exception as e:  # the raster line above is the contract metric: never lose it to the secondary measurement
-            ahds = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            ahds = dict(ahds or {}, error="%s: %s" % (type(e).__name__, str(e)[:300]))
     out = None
     if rank == 0:
         # ---- roofline: live per-kernel durations (hipEvents on the launch stream) ----
         stages, num_rendered = R.profile_stages(
-            t["means3D"].detach(), t["opacities"].detach(), sts, gC, gD, None, shs=t["shs"].detach(),
+            t["means3D"].detach(), t["opacities"].detach(), sts, gC[:Vl], gD[:Vl], None, shs=t["shs"].detach(),
             scales=t["scales"].detach(), rotations=t["rotations"].detach(), iters=args.profile_iters)
-        Rv = num_rendered / V
+        Rv = num_rendered / Vl
         T = ((H + 15) // 16) * ((W + 15) // 16)
         N = H * W
         b_f, b_b = algorithmic_bytes(P, K, Rv, T, N)
         kernel_stages = [s for s in stages if s != "clear"]
         dom = max(kernel_stages, key=lambda s: stages[s])
-        dom_bytes = stage_bytes(dom, P, K, Rv, T, N) * V
+        dom_bytes = stage_bytes(dom, P, K, Rv, T, N) * Vl
         achieved = dom_bytes / (stages[dom] * 1e-3) / 1e9
         # HBM traffic and vector-issue counters come from committed rocprofv3 --pmc passes of THIS build (separate passes,
         # tools/collect_profiles.sh; FETCH_SIZE doubled and KiB units per the MI355X guide): they cannot be collected
         # inside this run, so the line names its source
-        traffic, valu = None, None
+        traffic, valu, pmc_note = None, None, "profiles/pmc.json missing"
         ppath = os.path.join(ROOT, "profiles", "pmc.json")
         if os.path.exists(ppath):
             try:
+                import hashlib
                 pmc = json.load(open(ppath))
+                lib_sha = hashlib.sha256(open(os.path.join(ROOT, "gaussianip_amd", "lib", "libgip_raster.so"), "rb").read()).hexdigest()[:16]
+                stamp = pmc.get("_build", {})
                 c = pmc.get(dom, {})
-                traffic = int(c["hbm_fetch_bytes"] + c["hbm_write_bytes"])
-                # vector-issue roofline of the same kernel: a gfx950 SIMD retires one wave64 fp32 vector instruction
-                # per 4 cycles (transcendental and packed forms take longer), the chip has 256 CUs x 4 SIMDs, the launch
-                # lasted GRBM_GUI_ACTIVE / 8 XCD cycles: frac = 4 * SQ_INSTS_VALU / (1024 * cycles) is the share of the
-                # launch's SIMD issue cycles that the kernel's vector instructions need at that best-case rate.
-                cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-                valu = {"bound": "valu-issue", "kernel": "gip_%s_kernel" % dom, "wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
-                        "cycles_per_wave_instruction_assumed": 4,
-                        "needed_simd_cycles": int(4.0 * c["SQ_INSTS_VALU"]), "available_simd_cycles": int(cycles * 1024),
-                        "frac": round(4.0 * c["SQ_INSTS_VALU"] / (cycles * 1024), 4),
-                        "busy_quad_cycles_counter": int(c["SQ_ACTIVE_INST_VALU"]), "launch_cycles": int(cycles),
-                        "source": "profiles/pmc.json (rocprofv3 --pmc, this build)",
-                        "formula": "4 * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"}
-            except Exception:
-                traffic, valu = None, None
+                if stamp.get("libgip_raster_sha16") != lib_sha:
+                    # counters of ANOTHER build of the kernels: not this line's business (they went stale silently)
+                    pmc_note = "profiles/pmc.json was collected on libgip_raster %s, this run uses %s: counters withheld" % (
+                        stamp.get("libgip_raster_sha16"), lib_sha)
+                else:
+                    pmc_note = "profiles/pmc.json (rocprofv3 --pmc passes of this build, git %s)" % stamp.get("git", "?")
+                    traffic = int(c["hbm_fetch_bytes"] + c["hbm_write_bytes"])
+                    # Vector-issue roofline of the same kernel.  Issue cost per wave64 instruction on one SIMD, measured
+                    # with s_memtime stamps (tools/micro/valu_rate.hip -> profiles/r03_valu_rate.json): plain fp32
+                    # (v_fma_f32) 2.24 cycles with >= 4 waves per SIMD (2.5 with 2; 4.9 for a lone wave), packed
+                    # (v_pk_fma_f32) 4.2, transcendental (v_exp_f32) 8.1.  `frac` prices EVERY vector instruction at the
+                    # plain rate — a lower bound of the issue time the kernel needs; `frac_lone_wave` at the 4.9 cycles a
+                    # lone wave sustains (round 2 assumed 4).
+                    vr = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_rate.json")))
+                    c_sat, c_lone = vr["v_fma_f32"]["simd_cycles_ge4_waves"], vr["v_fma_f32"]["simd_cycles_1_wave"]
+                    cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+                    valu = {"bound": "valu-issue", "kernel": "gip_%s_kernel" % dom, "wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
+                            "cycles_per_wave_instruction": c_sat, "rate_source": "profiles/r03_valu_rate.json (tools/micro/valu_rate.hip)",
+                            "available_simd_cycles": int(cycles * 1024),
+                            "frac": round(c_sat * c["SQ_INSTS_VALU"] / (cycles * 1024), 4),
+                            "frac_lone_wave": round(c_lone * c["SQ_INSTS_VALU"] / (cycles * 1024), 4),
+                            "simd_cycles_per_instruction_achieved": round(cycles * 1024 / c["SQ_INSTS_VALU"], 3),
+                            "SQ_ACTIVE_INST_VALU_over_SQ_INSTS_VALU": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 3),
+                            "launch_cycles": int(cycles), "source": pmc_note,
+                            "formula": "c * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"}
+            except Exception as e:      # noqa: BLE001
+                traffic, valu, pmc_note = None, None, "profiles/pmc.json unreadable: %s" % e
         roofline = {"bound": "hbm", "kernel": "gip_%s_kernel" % dom, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "traffic_source": "profiles/pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build)",
+                    "traffic": traffic, "traffic_source": pmc_note,
                     "algorithmic_bytes_per_launch": int(dom_bytes),
                     "avg_launch_ms": round(stages[dom], 4),
                     "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-                    "whole_step_GBs": round((b_f + b_b) * V / (ms_per_step * 1e-3) / 1e9, 2),
-                    "whole_step_frac": round((b_f + b_b) * V / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "pair_evals_per_s_fwd": round(Rv * V * 256 / (stages["render_fwd"] * 1e-3), 0)}
+                    "whole_step_GBs": round((b_f + b_b) * Vl / (ms_per_step * 1e-3) / 1e9, 2),
+                    "whole_step_frac": round((b_f + b_b) * Vl / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "pair_evals_per_s_fwd": round(Rv * Vl * 256 / (stages["render_fwd"] * 1e-3), 0)}
 
         cpu = None
         if not args.no_cpu_baseline:
@@ -328,16 +377,20 @@ def main():
 
         out = {"metric": "raster_fwd_bwd_mpix_per_s", "value": round(mpix_s, 2), "unit": "Mpix/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[1]: %d Gaussians (synthetic human surface, SMPL-X-style "
-                                      "init), %dx%d, %d views/step per GPU, raster forward+backward" % (P, H, W, V),
-                          "gaussians": P, "height": H, "width": W, "views_per_step_per_gpu": V, "prewarm_steps": args.prewarm,
+                                      "init), %dx%d, %d views per optimizer step, raster forward+backward" % (P, H, W, V),
+                          "gaussians": P, "height": H, "width": W, "views_per_step": V, "views_per_step_per_gpu": Vl,
+                          "prewarm_steps": args.prewarm, "repeats": len(windows), "value_is": "median window",
                           "num_rendered_per_view": int(Rv), "sh_degree": 0,
-                          "parallelism": "view-sharded dp%d" % world},
+                          "parallelism": "1 GPU" if world == 1 else "BASELINE configs[3]: %d views sharded over %d GPU(s) x %d seed group(s)" % (
+                              V, shard.group_size, shard.n_seed_groups)},
+               "window_ms_per_step": [round(w_ / args.steps * 1e3, 4) for w_ in windows],
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
-               "forward_only": {"ms_per_step": round(fwd_ms, 4), "mpix_per_s_per_gpu": round(V * H * W / fwd_ms / 1e3, 1)},
+               "forward_only": {"ms_per_step": round(fwd_ms, 4), "mpix_per_s_per_gpu": round(Vl * H * W / fwd_ms / 1e3, 1)},
                "trained_state": trained,
-               "config3_layout": config3,
+               "exact_lists": exact,
+               "replicas_layout": replicas,
                "roofline": roofline, "roofline_valu": valu, "cpu_baseline": cpu}
     if rank == 0:
         out["ahds"] = ahds

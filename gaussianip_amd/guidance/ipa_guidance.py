@@ -23,7 +23,11 @@ from .networks import IP_TOKENS, TEXT_TOKENS, ControlNet, UNet, VAEEncoder, init
 
 _NO_SHARED_PREFIX = __import__("os").environ.get("GIP_SHARE_PREFIX", "1") == "0"      # A/B switch (tools/)
 _TWO_STREAMS = __import__("os").environ.get("GIP_GUIDANCE_STREAMS", "2") != "1"    # A/B switch: ControlNet beside the U-Net encoder
-_GRAPH_DENOISE = __import__("os").environ.get("GIP_GRAPH_DENOISE", "0") == "1"    # opt-in: the denoise as one HIP-graph launch (for a slow host)
+# The frozen, fixed-shape networks replay from HIP graphs (round 3 default): the Python host needs ~28 us per launch, which
+# made a ONE-view shard of configs[3] (1305 launches, 20 ms of GPU work) launch-bound at 30 ms.  GIP_GRAPH_DENOISE=0 /
+# GIP_GRAPH_VAE=0 restore the eager launches (same kernels, same values).
+_GRAPH_DENOISE = __import__("os").environ.get("GIP_GRAPH_DENOISE", "1") == "1"
+_GRAPH_VAE = __import__("os").environ.get("GIP_GRAPH_VAE", "1") == "1"
 
 
 @dataclass
@@ -289,7 +293,29 @@ class StableDiffusionGuidance:
         if self.cfg.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
         with torch.autocast("cuda", enabled=False):
+            if (_GRAPH_VAE and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and self.cfg.channels_last and
+                    not torch.cuda.is_current_stream_capturing()):
+                return self._encode_graphed(x, generator).to(imgs.dtype)
             return self.vae.encode(x, generator).to(imgs.dtype)
+
+    _vae_graphs = None
+
+    def _encode_graphed(self, x, generator):
+        """The differentiable VAE encoder (fixed shape, frozen weights: ~350 launches forward, ~400 backward) as two HIP-graph
+        launches: torch.cuda.make_graphed_callables captures `moments` and its backward; the stochastic part of
+        latent_dist.sample() (ipa_guidance.py:522-531) stays outside the graph.  First call of a shape runs eagerly (lazy
+        one-time initialisations must not be captured), the second captures."""
+        if self._vae_graphs is None:
+            self._vae_graphs = {}
+        key = (tuple(x.shape), x.dtype, x.device.index, bool(fused._DISABLED))
+        ent = self._vae_graphs.get(key)
+        if ent is None:
+            self._vae_graphs[key] = "warm"
+            return self.vae.encode(x, generator)
+        if ent == "warm":
+            sample = torch.zeros_like(x, memory_format=torch.channels_last).requires_grad_(True)
+            ent = self._vae_graphs[key] = torch.cuda.make_graphed_callables(lambda t_: self.vae.moments(t_), (sample,), num_warmup_iters=2)
+        return self.vae.sample(ent(x), generator)
 
     # ------------------------------------------------------------------ gradients
     def _prompt_embeds(self, prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, n_sets):

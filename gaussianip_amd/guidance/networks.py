@@ -536,7 +536,10 @@ class VAEEncoder(nn.Module):
 
     def encode(self, x, generator=None):
         """latent_dist.sample() * scaling_factor — stochastic and differentiable, like ipa_guidance.py:522-531."""
-        mean, logvar = self.moments(x).chunk(2, dim=1)
+        return self.sample(self.moments(x), generator)
+
+    def sample(self, moments, generator=None):
+        mean, logvar = moments.chunk(2, dim=1)
         std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
         noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
         return (mean + std * noise) * self.scaling_factor

@@ -185,6 +185,7 @@ def test_graph_replay_of_the_denoise_equals_the_eager_launches(monkeypatch):
         return torch.cat([lat] * 3), ctrl, torch.cat([tt] * 3), emb
     sets = [inputs() for _ in range(4)]
     with torch.no_grad():
+        monkeypatch.setattr(ipa_guidance, "_GRAPH_DENOISE", False)
         gd.forward_unet(*sets[0][:4], True, replicas=3)      # the libraries' first call of a shape may pick another GEMM algorithm
         eager = [gd.forward_unet(x, c, t, e, True, replicas=3) for x, c, t, e in sets]
         monkeypatch.setattr(ipa_guidance, "_GRAPH_DENOISE", True)
@@ -195,3 +196,30 @@ def test_graph_replay_of_the_denoise_equals_the_eager_launches(monkeypatch):
         # test's small shapes: 2e-3, the fp16 rounding level; bit-equal at the training shapes, tools/exp_graph.py)
         assert float((a - b).abs().max()) <= 5e-3 * max(1.0, float(a.abs().max()))
     assert replayed[2].data_ptr() != replayed[3].data_ptr()           # results are copies, not the graph's static buffer
+
+
+def test_graph_replay_of_the_vae_encoder_equals_the_eager_launches(monkeypatch):
+    """GIP_GRAPH_VAE (default on): the differentiable VAE encoder's forward and backward as two HIP-graph launches
+    (torch.cuda.make_graphed_callables over `moments`; the latent sampling stays outside) against the eager launches:
+    same latents for the same generator state, same gradient with respect to the images."""
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance, ipa_guidance
+    from gaussianip_amd.guidance.ahds import AHDSSchedule
+    gd = StableDiffusionGuidance(GuidanceConfig(), schedule=AHDSSchedule(list(range(2400))))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    imgs = [torch.rand(2, 3, 256, 256, device="cuda", generator=g).half() for _ in range(4)]
+    gout = torch.randn(2, 4, 32, 32, device="cuda", generator=g).half()
+
+    def run(img, seed):
+        x = img.clone().requires_grad_(True)
+        z = gd.encode_images(x, torch.Generator(device="cuda").manual_seed(seed))
+        (dx,) = torch.autograd.grad(z, x, gout)
+        return z.detach().clone(), dx.clone()
+    monkeypatch.setattr(ipa_guidance, "_GRAPH_VAE", False)
+    run(imgs[0], 0)
+    eager = [run(im, 10 + i) for i, im in enumerate(imgs)]
+    monkeypatch.setattr(ipa_guidance, "_GRAPH_VAE", True)
+    replayed = [run(im, 10 + i) for i, im in enumerate(imgs)]          # eager (warm), capture, replay, replay
+    assert gd._vae_graphs and any(callable(v) for v in gd._vae_graphs.values())
+    for (z0, d0), (z1, d1) in zip(eager, replayed):
+        assert float((z0.float() - z1.float()).abs().max()) <= 5e-3 * max(1.0, float(z0.float().abs().max()))
+        assert float((d0.float() - d1.float()).abs().max()) <= 5e-3 * max(1e-6, float(d0.float().abs().max()))

@@ -19,13 +19,17 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None, amp=True,
-            fused_adam=True, layout="views"):
+            fused_adam=True, layout="views", trained=False, proxy_group=0, pieces=True):
     """Runs the step `warmup + steps` times and returns the result dict.  The timed step is the reference's
     training_step + optimizer step as the system runs them (system.StageOneStep.training_step / optimizer_step):
     learning-rate update, render of the 4 cameras, OpenPose pose maps drawn on the GPU from the batch's mvp matrices,
     view-dependent prompt lookup, guidance call, loss assembly, backward, densification statistics, Adam — with a
     GradScaler when `amp` (the reference trains with `precision: 16-mixed`, configs/exp.yaml:193; its scaler.step() is
     the one host synchronisation of the step, as in the reference).
+    `trained`: the Gaussians get the trained-looking state of tests/scenes.trained_look (opacity 0.6, anisotropic 1-3x scales,
+    random rotations / colours) instead of the init state.  `proxy_group` = k (1 GPU): this process runs the shard of ONE
+    rank of a k-rank seed group of configs[3] (4 / k views, batch 3 x 4 / k denoise) with no collectives.  `pieces`: also
+    time the denoise and the VAE on their own.
     With world > 1 (process group initialised by the caller) and layout "views" — BASELINE.json configs[3] — the 4 views
     of an optimizer step are sharded over the ranks of a seed group (2 GPUs: 2 views each; 4: 1 view each; 8: two
     independent seed groups of 4, each with its own process group: parallel.ViewSharding), the guidance runs on the local
@@ -47,6 +51,8 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     torch.manual_seed(42)
     rng = np.random.default_rng(42)
     shard = parallel.ViewSharding(4) if (world > 1 and layout == "views") else None
+    if proxy_group:
+        shard = parallel.ViewSharding(4, rank=0, world=proxy_group, make_groups=False)       # inactive: no process group -> no collectives
     # views layout: every rank of a seed group draws the SAME 4 cameras (seed offset per seed group, launch.py:80) and
     # renders its share; replicas layout: rank-specific cameras
     cam_rng = np.random.default_rng(42 + (shard.seed_id if shard is not None else rank))
@@ -56,6 +62,14 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the model announces its size on stdout like the reference; keep stdout for the JSON line
         gm.create_from_pcd(BasicPointCloud(pts, np.full((P, 3), 0.5, np.float32), None), 4.0)
+    if trained:
+        tl = scenes.trained_look(dict(means3D=pts, opacities=np.full((P, 1), 0.1, np.float32), shs=np.zeros((P, 1, 3), np.float32),
+                                      scales=np.exp(gm._scaling.detach().cpu().numpy()), rotations=np.tile(np.float32([1, 0, 0, 0]), (P, 1))), seed=7)
+        with torch.no_grad():
+            gm._opacity.copy_(torch.logit(torch.from_numpy(tl["opacities"]).clamp(1e-4, 1 - 1e-4)).to(gm._opacity.device))
+            gm._scaling.copy_(torch.log(torch.from_numpy(tl["scales"])).to(gm._scaling.device))
+            gm._rotation.copy_(torch.from_numpy(tl["rotations"]).to(gm._rotation.device))
+            gm._features_dc.copy_(torch.from_numpy(tl["shs"]).reshape(gm._features_dc.shape).to(gm._features_dc.device))
     gm.training_setup(OptimizationParams(ArgumentParser()), fused=fused_adam)
     skel = Skeleton(dev)
     skel.scale(-10)
@@ -92,7 +106,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         # the data module's batch: CPU tensors (camera matrices AND the per-view scalars); what the GPU needs is uploaded by its consumer
         batch = scenes.train_batch(cam_rng, B, H, W, device=None if os.environ.get("GIP_HOST_BATCH", "1") == "1" else dev)
         loss, out, gout = stage.training_step(i, batch, guidance, prompt_utils, True)
-        stage.optimizer_step(loss, i, scaler=scaler, exchange=(shard.exchange if shard is not None else exchange) if world > 1 else None)
+        stage.optimizer_step(loss, i, scaler=scaler, exchange=(shard.exchange if shard is not None else exchange) if (world > 1 or proxy_group) else None)
         return loss
 
     for i in range(warmup):
@@ -139,6 +153,9 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
 
+    if not pieces:
+        return {"value": round((shard.n_seed_groups if shard is not None and not proxy_group else 1) / dt, 3), "ms_per_step": round(dt * 1e3, 2),
+                "host_enqueue_ms_per_step": round(host_ms, 2)}
     lat = torch.randn(B, 4, 64, 64, device=dev)
     ctrl = pose.permute(0, 3, 1, 2)
     emb = torch.randn(3 * B, 81, 768, device=dev, dtype=torch.float16) * 0.1
@@ -183,9 +200,12 @@ def main():
     ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--flops", action="store_true")
     ap.add_argument("--no-amp", action="store_true", help="no GradScaler (the reference trains with 16-mixed)")
+    ap.add_argument("--proxy-group", type=int, default=0, help="run ONE rank's shard of a k-rank configs[3] seed group on this GPU (no collectives)")
+    ap.add_argument("--trained", action="store_true", help="trained-looking Gaussian state instead of the init state")
     ap.add_argument("--plain-adam", action="store_true", help="torch's default Adam like the reference (GradScaler.step then synchronises)")
     args = ap.parse_args()
-    print(json.dumps(measure(args.steps, args.warmup, args.gaussians, not args.no_channels_last, args.flops, amp=not args.no_amp, fused_adam=not args.plain_adam)), flush=True)
+    print(json.dumps(measure(args.steps, args.warmup, args.gaussians, not args.no_channels_last, args.flops, amp=not args.no_amp, fused_adam=not args.plain_adam,
+                             proxy_group=args.proxy_group, trained=args.trained)), flush=True)
 
 
 if __name__ == "__main__":

@@ -4,10 +4,10 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ahds --no-trained > $OUT/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --profile-iters 1 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --profile-iters 1 > $OUT/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --profile-iters 1 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 --profile-iters 1 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 --profile-iters 1 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 --profile-iters 1 > $OUT/pmc_sq.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections, os
 out = "$OUT"
@@ -28,6 +28,12 @@ for k in sorted(agg):
     traffic[stage] = int(fetch + write)
     pmc[stage] = dict(c, hbm_fetch_bytes=int(fetch), hbm_write_bytes=int(write))
     lines.append("%-34s HBM bytes/launch ~ %12d (fetch x2 %12d + write %12d)  " % (k, fetch + write, fetch, write) + "  ".join("%s=%.4g" % kv for kv in sorted(c.items())))
+import hashlib
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+sha = hashlib.sha256(open(root + "/gaussianip_amd/lib/libgip_raster.so", "rb").read()).hexdigest()[:16]
+pmc["_build"] = {"libgip_raster_sha16": sha, "git": os.environ.get("GIP_GIT", "unknown"),
+                 "note": "bench.py emits roofline.traffic / roofline_valu only when this hash equals the library it runs"}
+lines.insert(0, "# counters of libgip_raster.so sha256[:16] = %s, git %s" % (sha, os.environ.get("GIP_GIT", "unknown")))
 open(out + "/pmc_summary.txt", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
 json.dump(pmc, open(out + "/pmc.json", "w"), indent=1)
@@ -38,5 +44,6 @@ cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv
 if [ -n "$SKIP_AHDS" ]; then tail -1 $OUT/bench_stats.log | cut -c1-600; exit 0; fi
 rocprofv3 --kernel-trace -d /tmp/prof_ahds -o st -- python3 $GRAFT_REPO_ROOT/tools/bench_ahds.py --steps 6 --warmup 4 > $OUT/ahds_trace.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/analyze_db.py /tmp/prof_ahds/st_results.db gip_preprocess_kernel 60 > $OUT/ahds_step_summary.txt
+python3 $GRAFT_REPO_ROOT/tools/dump_step.py /tmp/prof_ahds/st_results.db gip_preprocess_kernel > $OUT/ahds_step_trace.txt 2>&1
 head -16 $OUT/ahds_step_summary.txt
 tail -1 $OUT/bench_stats.log | cut -c1-300
