@@ -151,7 +151,9 @@ def model_lib():
         lib.gip_gather_rows.restype = ctypes.c_int
         lib.gip_gather_rows.argtypes = [ctypes.POINTER(GipGatherTensor), ctypes.c_int32, _vp, ctypes.c_int64, ctypes.c_int64, _vp]
         lib.gip_openpose_draw.restype = ctypes.c_int
-        lib.gip_openpose_draw.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]
+        lib.gip_openpose_draw.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]
+        lib.gip_openpose_workspace_bytes.restype = ctypes.c_size_t
+        lib.gip_openpose_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
         lib.gip_pack_bucket.restype = ctypes.c_int
         lib.gip_pack_bucket.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, _vp,
                                         ctypes.c_int32, ctypes.c_int64, _vp, _vp]

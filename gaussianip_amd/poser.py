@@ -4,7 +4,8 @@ Mirrors the part of `Skeleton` the training loop uses (threestudio/utils/poser.p
 pose (:665-684, y/z swapped as :694), `scale` (:819-822), the projection + self-occlusion visibility rules
 (:836-876) and `openpose_draw` (:832-904).  The reference draws every view with OpenCV on the CPU after a D2H copy of
 its mvp matrix and uploads the map again (GaussianIP.py:175-196); here projection and visibility are tensor ops over
-the view axis and the canvas is one HIP launch (include/gip_pose.h), so a step issues no host synchronisation for
+the view axis and the canvas is two HIP launches (include/gip_pose.h: OpenCV's ellipse2Poly / fillConvexPoly restated per limb,
+then the per-pixel draw), so a step issues no host synchronisation for
 its pose maps.  CPU tensors take a numpy path through the same spec (oracle-free: it is the host mirror used by tests).
 """
 import ctypes
@@ -89,16 +90,16 @@ class Skeleton:
         return mask
 
     def limb_parameters(self, xs, ys, mask):
-        """[V,17,6] float32: (int centre x, int centre y, int(len/2), drawn?, cos, sin of the int-degree angle) — poser.py:889-895."""
+        """[V,17,6] float32: (int centre x, int centre y, int(len/2), drawn?, int angle in degrees, 0) — the arguments of
+        cv2.ellipse2Poly at poser.py:889-895."""
         lines = self._on(xs.device)[1]
         X, Y = xs[:, lines], ys[:, lines]                            # [V,17,2]
         mX, mY = X.mean(dim=-1), Y.mean(dim=-1)
         length = ((Y[..., 0] - Y[..., 1]) ** 2 + (X[..., 0] - X[..., 1]) ** 2) ** 0.5
         ang = torch.rad2deg(torch.atan2((Y[..., 0] - Y[..., 1]).double(), (X[..., 0] - X[..., 1]).double())).trunc()
-        rad = torch.deg2rad(ang)
         on = mask[:, lines[:, 0]] & mask[:, lines[:, 1]]
         return torch.stack([mX.trunc().float(), mY.trunc().float(), (length / 2).trunc().float(), on.float(),
-                            torch.cos(rad).float(), torch.sin(rad).float()], dim=-1).contiguous()
+                            ang.float(), torch.zeros_like(mX).float()], dim=-1).contiguous()
 
     # ------------------------------------------------------------------ the drawing call
     def openpose_draw(self, mvp, H, W, azimuth, head_zoom, enable_occlusion=True):
@@ -121,9 +122,12 @@ class Skeleton:
         if self.device.type == "cuda":
             from . import _lib
             canvas = torch.empty((V, H, W, 3), dtype=torch.float32, device=self.device)
-            rc = _lib.model_lib().gip_openpose_draw(
+            lib = _lib.model_lib()
+            ws = torch.empty(lib.gip_openpose_workspace_bytes(V, H), dtype=torch.uint8, device=self.device)     # per-row limb spans
+            rc = lib.gip_openpose_draw(
                 ctypes.c_void_p(pts_px.data_ptr()), ctypes.c_void_p(vis8.data_ptr()), ctypes.c_void_p(limbs.data_ptr()),
-                ctypes.c_void_p(canvas.data_ptr()), V, H, W, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+                ctypes.c_void_p(canvas.data_ptr()), V, H, W, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
             if rc != 0:
                 raise RuntimeError("gip_openpose_draw failed with status %d" % rc)
         else:

@@ -8,18 +8,23 @@
  *       (GaussianIP.py:175-196: one D2H of mvp + one H2D per view); here all V maps of a step are one launch and the
  *       projected key points never leave the device.
  *
- * Every pixel replays the draw order on its own byte triple: disc i if visible[i] (midpoint-circle footprint of
- * radius 4 around (int(x_i), int(y_i))), then for limb l with both ends visible: inside the ellipse with centre
- * (int(mean x), int(mean y)), half-axes (int(len / 2), 4), angle int(degrees(atan2(y0 - y1, x0 - x1))) the blend source
- * is the limb colour, outside it is the canvas itself; canvas = round_half_even(0.4 canvas + 0.6 source).
- * OpenCV is not available in the build environment: the ellipse footprint is the analytic ellipse inflated by half a
- * pixel rather than cv2's 1-degree polygon scan conversion, so boundary pixels may differ from cv2 — parity against
- * OpenCV itself is UNPINNED; tests pin the kernel bit-exactly against oracle/pose_oracle.py, which states this spec.
+ * Every pixel replays the draw order on its own byte triple: disc i if visible[i] (cv::Circle's filled midpoint circle of
+ * radius 4 around (int(x_i), int(y_i))), then for limb l with both ends visible the footprint OpenCV paints for
+ *   cv2.fillConvexPoly(canvas, cv2.ellipse2Poly((int(mean x), int(mean y)), (int(len / 2), 4), int(degrees(atan2(y0 - y1, x0 - x1))), 0, 360, 1), colour)
+ * is the blend source, elsewhere the canvas itself; canvas = round_half_even(0.4 canvas + 0.6 source) (cv2.addWeighted).
+ * The footprint is computed as OpenCV 4.x computes it (modules/imgproc/src/drawing.cpp: SinTable / ellipse2Poly in double
+ * arithmetic + cvRound + duplicate removal; FillConvexPoly = outline by clipLine + 8-connected LineIterator, then the
+ * XY_SHIFT = 16 fixed-point scanline fill), one wave per (view, limb), and handed to the pixel kernel as one [lo, hi]
+ * span per image row through `workspace` (gip_openpose_workspace_bytes(V, H) bytes).  opencv-python is a dependency of
+ * the reference that is absent from its tree and not installed in the build environment: the restatement follows the
+ * published source; parity against the OpenCV binary is unpinned; tests pin the kernel bit-exactly against
+ * oracle/pose_oracle.py, which states the same routines in numpy.
  *
  * points_px [V,18,2] int32 = (int(x), int(y)) of the projected key points; visible [V,18] uint8; limbs [V,17,6] float =
- * (centre x, centre y, half-axis a, drawn?, cos(angle), sin(angle)) per limb, prepared by the caller with tensor ops on the
- * device (gaussianip_amd/poser.py) so that the kernel holds only exactly reproducible arithmetic; out [V,H,W,3] float.
- * Status 0 ok, 1 bad argument, 3 HIP error.
+ * (int centre x, int centre y, int half-axis a, drawn?, int angle in degrees, 0) per limb, prepared by the caller
+ * (gaussianip_amd/poser.py) so that the kernels hold only exactly reproducible arithmetic; out [V,H,W,3] float.
+ * H <= 2048, W <= 32766.
+ * Status 0 ok, 1 bad argument, 2 workspace too small, 3 HIP error.
  */
 #ifndef GIP_POSE_H
 #define GIP_POSE_H
@@ -30,8 +35,9 @@ extern "C" {
 #endif
 #define GIP_POSE_POINTS 18
 #define GIP_POSE_LIMBS 17
+size_t gip_openpose_workspace_bytes(int32_t V, int32_t H);
 int gip_openpose_draw(const int32_t* points_px, const uint8_t* visible, const float* limbs, float* out, int32_t V,
-                      int32_t H, int32_t W, void* stream);
+                      int32_t H, int32_t W, void* workspace, size_t workspace_bytes, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -87,3 +87,47 @@ def test_host_side_batch_gives_the_same_pose_maps():
     assert v_host.device.type == "cpu" and c_host.is_cuda
     assert torch.equal(v_host, v_dev.cpu())
     assert torch.equal(c_host, c_dev)
+
+
+def test_limb_footprints_match_the_opencv_restatement_on_hard_cases():
+    """gip_pose_limb_spans_kernel against oracle/pose_oracle.py (ellipse2Poly + fillConvexPoly restated from OpenCV's
+    drawing.cpp), bit-exact canvas: every integer angle class, degenerate half-axes (0, 1), long limbs, limbs cut by
+    each image border, and the 'not drawn' flag."""
+    import ctypes
+    from gaussianip_amd import _lib
+    from oracle import pose_oracle
+    rng = np.random.default_rng(4)
+    H, W, V = 96, 128, 12
+    limbs = np.zeros((V, 17, 6), np.float32)
+    for v in range(V):
+        for l in range(17):
+            border = rng.random() < 0.35
+            cx = rng.integers(-6, W + 6) if border else rng.integers(20, W - 20)
+            cy = rng.integers(-6, H + 6) if border else rng.integers(20, H - 20)
+            a = [0, 1, 2, 60][rng.integers(0, 4)] if rng.random() < 0.3 else rng.integers(3, 40)
+            limbs[v, l] = (cx, cy, a, float(rng.random() < 0.85), rng.integers(-180, 181), 0)
+    limbs[0, :8, 4] = [-180, -90, 0, 90, 180, 45, -135, 1]
+    pts = np.stack([rng.integers(-3, W + 3, (V, 18)), rng.integers(-3, H + 3, (V, 18))], -1).astype(np.int32)
+    vis = (rng.random((V, 18)) < 0.7)
+    dev = torch.device("cuda")
+    lib = _lib.model_lib()
+    t_pts, t_vis, t_l = torch.from_numpy(pts).to(dev), torch.from_numpy(vis.astype(np.uint8)).to(dev), torch.from_numpy(limbs).to(dev)
+    canvas = torch.empty((V, H, W, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.gip_openpose_workspace_bytes(V, H), dtype=torch.uint8, device=dev)
+    rc = lib.gip_openpose_draw(ctypes.c_void_p(t_pts.data_ptr()), ctypes.c_void_p(t_vis.data_ptr()), ctypes.c_void_p(t_l.data_ptr()),
+                               ctypes.c_void_p(canvas.data_ptr()), V, H, W, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                               ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0
+    got = canvas.cpu().numpy()
+    spans = ws.view(torch.int32).reshape(V, 17, H).cpu().numpy()
+    for v in range(V):
+        for l in range(17):                               # the spans themselves, limb by limb
+            m = pose_oracle.limb_mask(H, W, *limbs[v, l, [0, 1, 2, 4]]) if limbs[v, l, 3] else np.zeros((H, W), bool)
+            lo, hi = spans[v, l] & 0xffff, spans[v, l] >> 16
+            mk = (np.arange(W)[None, :] >= lo[:, None]) & (np.arange(W)[None, :] <= hi[:, None]) & ~((lo == 32767) & (hi == 0))[:, None]
+            assert np.array_equal(mk, m), (v, l, limbs[v, l])
+        want = pose_oracle.draw(pts[v], vis[v], limbs[v], H, W)
+        assert np.array_equal(got[v], want), v
+    assert lib.gip_openpose_draw(ctypes.c_void_p(t_pts.data_ptr()), ctypes.c_void_p(t_vis.data_ptr()), ctypes.c_void_p(t_l.data_ptr()),
+                                 ctypes.c_void_p(canvas.data_ptr()), V, H, W, ctypes.c_void_p(ws.data_ptr()), 16,
+                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 2        # workspace too small
