@@ -44,14 +44,17 @@ union Frag8 {
 };
 
 template <int D, bool TWO>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, D > 128 ? 1 : 2)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
                 const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2, int ld_kv, int ld_kv2) {
   // ld_kv / ld_kv2: elements between consecutive key rows of (k, v) / (k2, v2).  H * D for packed projections; larger
   // when a layer's keys are a column range of one wide matrix holding the key / value projections of MANY layers
-  static_assert(D % 8 == 0 && D <= 128, "head dim");
-  constexpr int AT_ROW = D <= 64 ? 128 : 256;          // bytes per LDS row
+  static_assert(D % 8 == 0 && D <= 160, "head dim");
+  // D = 160 (the 16x16 and 8x8 levels of the U-Net: 1280 channels / 8 heads): 512-byte rows, one workgroup per CU with the
+  // whole 512-register file per lane (O^T alone is 5 accumulator tiles) — tiny layers, but they were the last ones on
+  // torch SDPA (an AOTriton kernel on ROCm)
+  constexpr int AT_ROW = D <= 64 ? 128 : (D <= 128 ? 256 : 512);          // bytes per LDS row
   constexpr int AT_TILE = AT_BKV * AT_ROW;             // one K or V stage
   constexpr int NS = (D + 15) / 16;      // k-steps of the S^T product
   constexpr int ND = (D + 31) / 32;      // 32-row tiles of O^T
@@ -66,6 +69,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   const int b = blockIdx.y / H, h = blockIdx.y - b * H;
   const int C = H * D;
   const int q0 = blockIdx.x * AT_BQ + wave * 32;
+  const bool q_valid = q0 < Nq;          // Nq % 32 == 0: a wave's 32 query rows exist or not as a whole (the 8x8 level has 64)
 
   // Q^T fragments (B operand): lane = query column, element j = feature 16 s + 8 hh + j; zero beyond D
   f16x8 qf[NS];
@@ -76,7 +80,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
       const int d0 = 16 * s + 8 * hh;
       Frag8 f;
       f.u = make_uint4(0, 0, 0, 0);
-      if (d0 < D) f.u = *(const uint4*)(qp + d0);
+      if (d0 < D && q_valid) f.u = *(const uint4*)(qp + d0);
       qf[s] = f.v;
     }
   }
@@ -95,41 +99,32 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   // staging descriptors: every thread moves two chunks of K and of V per block; the tail indices wrap around (a few
   // chunks are moved twice with identical data) so that no load or LDS store is predicated; rows past the end of a
   // ragged key set are clamped to its last row (they are masked to -inf before the softmax)
-  static_assert(PER == 2 || PER == 3, "two or three staging chunks per thread");
-  int idx0 = tid, idx1 = tid + 256, idx2 = tid + 512;
-  if (idx1 >= AT_BKV * CH) idx1 -= AT_BKV * CH;
-  if (idx2 >= AT_BKV * CH) idx2 -= AT_BKV * CH;
-  if (idx2 >= AT_BKV * CH) idx2 -= AT_BKV * CH;
-  const int row0 = idx0 / CH, ch0 = idx0 - row0 * CH, row1 = idx1 / CH, ch1 = idx1 - row1 * CH, row2 = idx2 / CH, ch2 = idx2 - row2 * CH;
-  const int kl0 = row0 * AT_ROW + ((ch0 ^ kswz<AT_ROW>(row0)) << 4), kl1 = row1 * AT_ROW + ((ch1 ^ kswz<AT_ROW>(row1)) << 4);
-  const int kl2 = row2 * AT_ROW + ((ch2 ^ kswz<AT_ROW>(row2)) << 4);
-  const int vl0 = AT_TILE + row0 * AT_ROW + ((ch0 ^ vswz<AT_ROW>(row0)) << 4);
-  const int vl1 = AT_TILE + row1 * AT_ROW + ((ch1 ^ vswz<AT_ROW>(row1)) << 4);
-  const int vl2 = AT_TILE + row2 * AT_ROW + ((ch2 ^ vswz<AT_ROW>(row2)) << 4);
-  uint4 kr0, kr1, kr2, vr0, vr1, vr2;
+  static_assert(PER >= 2 && PER <= 5, "staging chunks per thread");
+  int st_row[PER], st_ch[PER], st_kl[PER], st_vl[PER];
+#pragma unroll
+  for (int e = 0; e < PER; e++) {
+    int idx = tid + 256 * e;
+    while (idx >= AT_BKV * CH) idx -= AT_BKV * CH;
+    st_row[e] = idx / CH;
+    st_ch[e] = idx - st_row[e] * CH;
+    st_kl[e] = st_row[e] * AT_ROW + ((st_ch[e] ^ kswz<AT_ROW>(st_row[e])) << 4);
+    st_vl[e] = AT_TILE + st_row[e] * AT_ROW + ((st_ch[e] ^ vswz<AT_ROW>(st_row[e])) << 4);
+  }
+  uint4 kr[PER], vr[PER];
 #define AT_FETCH(blk_)                                                                   \
   {                                                                                      \
-    const int ra_ = min((blk_) * AT_BKV + row0, n_keys - 1), rb_ = min((blk_) * AT_BKV + row1, n_keys - 1);  \
-    kr0 = *(const uint4*)(kp + (size_t)ra_ * ld + ch0 * 8);                               \
-    kr1 = *(const uint4*)(kp + (size_t)rb_ * ld + ch1 * 8);                               \
-    vr0 = *(const uint4*)(vp + (size_t)ra_ * ld + ch0 * 8);                               \
-    vr1 = *(const uint4*)(vp + (size_t)rb_ * ld + ch1 * 8);                               \
-    if constexpr (PER == 3) {                                                            \
-      const int rc_ = min((blk_) * AT_BKV + row2, n_keys - 1);                           \
-      kr2 = *(const uint4*)(kp + (size_t)rc_ * ld + ch2 * 8);                             \
-      vr2 = *(const uint4*)(vp + (size_t)rc_ * ld + ch2 * 8);                             \
+    _Pragma("unroll") for (int e_ = 0; e_ < PER; e_++) {                                 \
+      const int ra_ = min((blk_) * AT_BKV + st_row[e_], n_keys - 1);                     \
+      kr[e_] = *(const uint4*)(kp + (size_t)ra_ * ld + st_ch[e_] * 8);                   \
+      vr[e_] = *(const uint4*)(vp + (size_t)ra_ * ld + st_ch[e_] * 8);                   \
     }                                                                                    \
   }
 #define AT_DEPOSIT(stage_)                                                 \
   {                                                                        \
     unsigned char* st_ = smem + (stage_) * 2 * AT_TILE;                    \
-    *(uint4*)(st_ + kl0) = kr0;                                            \
-    *(uint4*)(st_ + kl1) = kr1;                                            \
-    *(uint4*)(st_ + vl0) = vr0;                                            \
-    *(uint4*)(st_ + vl1) = vr1;                                            \
-    if constexpr (PER == 3) {                                              \
-      *(uint4*)(st_ + kl2) = kr2;                                          \
-      *(uint4*)(st_ + vl2) = vr2;                                          \
+    _Pragma("unroll") for (int e_ = 0; e_ < PER; e_++) {                   \
+      *(uint4*)(st_ + st_kl[e_]) = kr[e_];                                 \
+      *(uint4*)(st_ + st_vl[e_]) = vr[e_];                                 \
     }                                                                      \
   }
 
@@ -284,7 +279,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int d = dt * 32 + 8 * i + 4 * hh;
-      if (d < D) {
+      if (d < D && q_valid) {
         f16x4 w;
 #pragma unroll
         for (int j = 0; j < 4; j++) w[j] = (_Float16)(TWO ? Oacc[dt][4 * i + j] : O[dt][4 * i + j]);
@@ -307,16 +302,17 @@ static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, 
 extern "C" int gip_attention_fwd_strided_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
                                              int32_t Nq, int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2,
                                              int32_t Nkv2, float weight2, int32_t ld_kv, int32_t ld_kv2, void* stream) {
-  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < AT_BQ || Nq % AT_BQ || Nkv < 1) return 1;
+  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < 32 || Nq % 32 || Nkv < 1) return 1;
   if ((k2 != nullptr) != (v2 != nullptr) || (k2 && Nkv2 < 1)) return 1;
   if (ld_kv < H * D || ld_kv % 8 || (k2 && (ld_kv2 < H * D || ld_kv2 % 8))) return 1;        // 16-byte row loads
   const float c = scale * 1.4426950408889634f;
-  const dim3 grid(Nq / AT_BQ, B * H);
+  const dim3 grid((Nq + AT_BQ - 1) / AT_BQ, B * H);
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
     case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
     case 80: launch_attn<80>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
+    case 160: launch_attn<160>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;

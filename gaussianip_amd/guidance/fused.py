@@ -336,7 +336,7 @@ def _kv_rows(t):
 
 def attention_supported(q, k, heads):
     D = q.shape[-1] // heads
-    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64, 80) and q.shape[1] % 128 == 0 and
+    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64, 80, 160) and q.shape[1] % 32 == 0 and
             k.shape[1] >= 1 and q.is_contiguous() and _kv_rows(k) is not None and
             not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
 

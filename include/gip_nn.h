@@ -119,7 +119,7 @@ int gip_linear_f16(const void* x, const void* w, const void* bias, const void* r
 /* Attention forward o = softmax(q k^T * scale) v  [+ weight2 * softmax(q k2^T * scale) v2]  (csrc/attention.hip):
  * q, o [B, Nq, H*D], k, v [B, Nkv, H*D], k2, v2 [B, Nkv2, H*D] half — the projection outputs / to_out input, heads
  * interleaved along the last axis (no head transposes).  fp32 softmax and accumulation.  No mask, no gradient (the
- * denoiser is frozen).  D in {40, 64, 80}; Nq % 128 == 0; any Nkv, Nkv2 >= 1 (ragged tails are masked).  k2 = v2 = NULL:
+ * denoiser is frozen).  D in {40, 64, 80, 160}; Nq % 32 == 0 (a workgroup takes 128 queries, a wave 32); any Nkv, Nkv2 >= 1 (ragged tails are masked).  k2 = v2 = NULL:
  * one key set — the self-attention of LoRAAttnProcessor2_0 (attention_processor_faceid.py:300-318).  With k2 / v2: the
  * decoupled cross-attention of LoRAIPAttnProcessor2_0 (:462-500), text keys (77) and image-prompt keys (4) with their
  * own softmax each, hidden = text + scale * ip, in ONE pass over the queries. */

@@ -124,13 +124,18 @@ class RasterOracle:
             self.lib.oracle_pixel_margins(self.ctx, _p(ids), ctypes.c_int(ids.shape[0]), _p(out))
         return out
 
-    def knife_edge_gaussians(self, thresh=2e-5, downstream=False):
+    def knife_edge_gaussians(self, thresh=2e-5, downstream=False, sharing=False):
         """(bool [P] mask of the Gaussians that are the subject of a knife-edge threshold test, number of such pixels);
-        with downstream=True also a [P] mask of the Gaussians blended behind such a subject at some pixel."""
+        with downstream=True also a [P] mask of the Gaussians blended behind such a subject at some pixel; with
+        sharing=True instead a [P] mask of every Gaussian that blends at a knife-edge pixel, in front of the subject or
+        behind it (raster_oracle.c: oracle_knife_edge_gaussians2)."""
         flags = np.zeros(self.P, np.uint8)
         down = np.zeros(self.P, np.uint8) if downstream else None
-        self.lib.oracle_knife_edge_gaussians.restype = ctypes.c_int
-        n = self.lib.oracle_knife_edge_gaussians(self.ctx, ctypes.c_float(thresh), _p(flags), _p(down))
+        share = np.zeros(self.P, np.uint8) if sharing else None
+        self.lib.oracle_knife_edge_gaussians2.restype = ctypes.c_int
+        n = self.lib.oracle_knife_edge_gaussians2(self.ctx, ctypes.c_float(thresh), _p(flags), _p(down), _p(share))
+        if sharing:
+            return flags.astype(bool), int(n), share.astype(bool)
         if downstream:
             return flags.astype(bool), int(n), down.astype(bool)
         return flags.astype(bool), int(n)

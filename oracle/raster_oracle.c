@@ -440,7 +440,18 @@ void oracle_pixel_margins(const oracle_ctx* c, const int32_t* pix_ids, int n, fl
  * within `thresh` at its entry): the set of gradient rows that a legitimately different decision changes by one whole
  * pixel contribution.  Entries behind a flipped one see T change by at most 0.4 % at that single pixel (alpha flips)
  * or contribute with T < 1e-4 (termination flips) and are not flagged.  Returns the number of knife-edge pixels. */
+int oracle_knife_edge_gaussians2(const oracle_ctx* c, float thresh, uint8_t* flags, uint8_t* downstream, uint8_t* sharing);
 int oracle_knife_edge_gaussians(const oracle_ctx* c, float thresh, uint8_t* flags, uint8_t* downstream) {
+  return oracle_knife_edge_gaussians2(c, thresh, flags, downstream, NULL);
+}
+
+/* sharing[g] (optional) = 1 for every Gaussian that CONTRIBUTES (alpha >= 1/255, before the walk ends) at a pixel that
+ * has a knife-edge subject — in front of it or behind it.  Behind: its transmittance changes by (1 - alpha_subject) if
+ * the subject flips.  In FRONT: the reverse-order backward hands every earlier entry the colour accumulated behind it
+ * (accum_rec), which gains or loses the subject's alpha-weighted term — the same 0.4 % of one pixel's contribution.
+ * Round 3 (tools/diag/view_outlier.py): the one entry of the 4-view headline test that sat at 0.92 x the element-wise
+ * bar is such a row — in front of the subject of pixel (489, 730) of view 1, whose alpha test is 4.7e-7 from 1/255. */
+int oracle_knife_edge_gaussians2(const oracle_ctx* c, float thresh, uint8_t* flags, uint8_t* downstream, uint8_t* sharing) {
   /* downstream[g] (optional) = 1 for every Gaussian that is blended BEHIND a knife-edge subject at some pixel: if the
    * subject's decision flips, the transmittance of everything behind it at that pixel changes by the factor
    * (1 - alpha_subject) (0.4 % for an alpha >= 1/255 flip) — a second-order effect that is visible only on gradient
@@ -475,6 +486,22 @@ int oracle_knife_edge_gaussians(const oracle_ctx* c, float thresh, uint8_t* flag
         }
       }
       if (subject) { flags[g] = 1; hit = 1; }
+    }
+    if (hit && sharing) {                      /* second walk of a knife-edge pixel: everything that blends there */
+      T = 1.0f;
+      for (uint32_t k = r0; k < r1; k++) {
+        const uint32_t g = c->values[k];
+        const float dx = c->means2D[2 * g] - (float)px, dy = c->means2D[2 * g + 1] - (float)py;
+        const float* co = c->conic_opacity + 4 * g;
+        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > 0.0f) continue;
+        const float alpha = fminf(0.99f, co[3] * expf(power));
+        if (alpha < 1.0f / 255.0f) continue;
+        const float test_T = T * (1 - alpha);
+        if (test_T < 0.0001f) break;
+        sharing[g] = 1;
+        T = test_T;
+      }
     }
     count += hit;
   }

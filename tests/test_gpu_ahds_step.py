@@ -66,11 +66,18 @@ def test_three_full_ahds_steps(rig):
     def spy_conv2d(x, w, *a, **k):
         library_convs.append((tuple(x.shape), tuple(w.shape)))
         return real_conv2d(x, w, *a, **k)
+    sdpa_calls = []
+    real_sdpa = F.scaled_dot_product_attention
+
+    def spy_sdpa(q_, *a, **k):           # torch SDPA is an AOTriton kernel on ROCm: no attention of the step may reach it
+        sdpa_calls.append(tuple(q_.shape))
+        return real_sdpa(q_, *a, **k)
     for step in range(4):
         # steps 0-2: the per-view scalars on the device (a Lightning-transferred batch); step 3: the data module's own CPU
         # tensors (pose visibility rules and prompt lookup then run on the host; bench layout)
         batch = scenes.train_batch(cam_rng, B, H, W, device=dev if step < 3 else None)
         F.conv2d = spy_conv2d if step == 0 else real_conv2d          # step 0 launches every layer eagerly
+        F.scaled_dot_product_attention = spy_sdpa if step == 0 else real_sdpa
         if step > 1:
             # steady state: nothing between the render and the optimizer may wait for the GPU (step 0 sizes the
             # rasterizer's capacity synchronously and runs the networks eagerly, step 1 captures their HIP graphs,
@@ -82,6 +89,7 @@ def test_three_full_ahds_steps(rig):
         finally:
             torch.cuda.set_sync_debug_mode("default")
             F.conv2d = real_conv2d
+            F.scaled_dot_product_attention = real_sdpa
         assert action is None and set(gout) == {"loss_sds", "grad_norm"}
         assert out["comp_rgb"].shape == (B, H, W, 3) and out["pose"].shape == (B, 512, 512, 3) and out["all_vis_all"].shape == (B,)
         losses.append(loss.detach())
@@ -106,6 +114,7 @@ def test_three_full_ahds_steps(rig):
     # no 3x3 convolution the MFMA kernel covers (input channels a multiple of 64, >= 64 output channels, 16^2 and larger)
     # may fall back to the library: a tensor that silently lost its NHWC layout (Tensor.repeat, an eager add) once sent
     # a whole ResnetBlock2D there.  What legitimately stays: the 3-channel stems and the 4 / 8-channel output convolutions
+    assert not sdpa_calls, sdpa_calls            # every attention (head dims 40 / 80 / 160; the VAE's single wide head runs as GEMMs) is the HIP kernel
     stray = [(xs, ws) for xs, ws in library_convs if ws[2:] == (3, 3) and ws[1] % 64 == 0 and ws[0] >= 64 and xs[2] >= 16]
     assert not stray, stray
 

@@ -10,7 +10,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("B,H,Nq,Nkv,D", [(1, 1, 128, 64, 40), (2, 8, 256, 256, 40), (2, 3, 1024, 1024, 64), (12, 8, 4096, 4096, 40),
                                           (1, 2, 384, 1152, 40), (2, 8, 512, 77, 40), (2, 8, 256, 81, 40), (1, 2, 128, 1, 64),
                                           (1, 2, 128, 130, 40), (1, 2, 2048, 16384, 40),
-                                          (2, 8, 1024, 1024, 80), (1, 3, 256, 77, 80), (2, 8, 4096, 8192, 80)])
+                                          (2, 8, 1024, 1024, 80), (1, 3, 256, 77, 80), (2, 8, 4096, 8192, 80),
+                                          # round 3: head dim 160 (the 16x16 / 8x8 levels) and query counts that are multiples of 32 only
+                                          (12, 8, 256, 256, 160), (12, 8, 64, 64, 160), (3, 8, 256, 81, 160), (2, 8, 64, 77, 160), (1, 2, 96, 200, 40),
+                                          (2, 4, 32, 5, 80)])
 @pytest.mark.parametrize("spread", [1.0, 6.0])
 def test_attention_matches_fp32_reference(B, H, Nq, Nkv, D, spread):
     from gaussianip_amd.guidance import fused

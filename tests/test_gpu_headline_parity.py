@@ -14,9 +14,12 @@ tensor (the six parameter gradients + means2D) within
     Gaussians that walk through a PROVEN knife-edge pixel (a threshold test of the blend within 2e-5 of flipping in
     the oracle: oracle.knife_edge_gaussians) are left out of the element-wise bar only — v_exp_f32 and libm expf may
     decide such a pixel differently, which moves that Gaussian's gradient by one whole pixel contribution; their
-    count is printed and bounded.  Gaussians blended BEHIND such a subject at that pixel see its transmittance change
-    by the factor (1 - alpha) = 0.4 % there; that matters only where a gradient entry is a small sum of cancelling
-    terms, and those rows (oracle: downstream=True) get the looser REL_TOL_DOWNSTREAM.
+    count is printed and bounded.  Gaussians that blend at the SAME pixel see a second-order change: behind the subject
+    their transmittance changes by the factor (1 - alpha) = 0.4 %, in front of it the colour accumulated behind them
+    (the reverse-order backward's accum_rec) gains or loses the subject's term; that matters only where a gradient
+    entry is a small sum of cancelling terms.  Those rows (oracle: sharing=True; a few per cent of the Gaussians) get the
+    looser REL_TOL_DOWNSTREAM, and at most MAX_LOOSE_ENTRIES of their entries per tensor may actually exceed REL_TOL
+    (measured: none, once one).
 The achieved errors are printed (pytest -s) and written to gpurun_out/parity_headline.json when that directory exists.
 Reference call sites: gaussian_renderer/__init__.py:85-93, threestudio/systems/GaussianIP.py:452-457."""
 import json
@@ -37,6 +40,7 @@ MAX_TOL = 2e-3
 REL_TOL = 1e-2
 FLOOR_FRAC = 1e-3
 REL_TOL_DOWNSTREAM = 5e-2
+MAX_LOOSE_ENTRIES = 4           # entries (of ~1e4-6e4 candidates per tensor) allowed between REL_TOL and REL_TOL_DOWNSTREAM (measured: 0, once 1)
 _report = {}
 
 
@@ -68,11 +72,23 @@ def _compare(tag, name, ours, ref, floor=0.0, ref_end_to_end=None, skip_rows=Non
     if loose_rows is not None:          # rows behind a knife-edge subject: looser element-wise bar
         lb = big.copy()
         lb[~loose_rows] = False
-        e_loose = float((err[lb] / np.abs(ref[lb])).max()) if lb.any() else 0.0
+        rl = err[lb] / np.abs(ref[lb]) if lb.any() else np.zeros(0)
+        e_loose = float(rl.max()) if rl.size else 0.0
         assert e_loose < REL_TOL_DOWNSTREAM, "%s %s: per-element relative error %.3e behind a knife-edge subject" % (tag, name, e_loose)
+        # the class is large (a few per cent of the Gaussians sit behind SOME knife-edge subject) but the looser bar is
+        # needed by a handful of its entries only: at most MAX_LOOSE_ENTRIES may exceed the strict REL_TOL
+        n_over = int((rl >= REL_TOL).sum())
+        _report.setdefault(tag, {}).setdefault("_loose", {})[name] = dict(entries=int(lb.sum()), over_strict_bar=n_over, worst=e_loose)
+        assert n_over <= MAX_LOOSE_ENTRIES, "%s %s: %d entries behind knife-edge subjects exceed REL_TOL" % (tag, name, n_over)
         big[loose_rows] = False
     e_rel = float((err[big] / np.abs(ref[big])).max()) if big.any() else 0.0
     rec = dict(max_norm=e_max, rel=e_rel, entries_checked=int(big.sum()), top=top)
+    if big.any():                       # where the worst checked entry sits: which Gaussian, how large against the tensor maximum
+        relmap = np.where(big, err / np.maximum(np.abs(ref), 1e-300), 0.0)
+        idx = np.unravel_index(int(relmap.argmax()), relmap.shape)
+        rec.update(worst_row=int(idx[0]), worst_ref=float(ref[idx]), worst_ours=float(ours[idx]), worst_ref_over_top=float(abs(ref[idx]) / top))
+    if loose_rows is not None:
+        rec["loose_rows"] = int(np.asarray(loose_rows).sum())
     line = "%-22s %-11s max-normalised %.2e   per-element relative %.2e on %d entries" % (tag, name, e_max, e_rel, big.sum())
     if ref_end_to_end is not None:
         e2e = float(np.abs(ours - ref_end_to_end.astype(np.float64)).max() / top)
@@ -112,12 +128,14 @@ def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look):
         torch.cuda.synchronize()
         go_e2e = ro.backward(gC[0], gD[0], gA[0])
         go = ro.backward(gC[0], gD[0], gA[0], alpha_out=alpha.detach().cpu().numpy())
-        knife, n_knife_pixels, behind = ro.knife_edge_gaussians(downstream=True)
+        knife, n_knife_pixels, behind = ro.knife_edge_gaussians(sharing=True)
     finally:
         oracle.set_threads(1)
     tag = "1 view / " + look
     print("%s: %d knife-edge pixels, %d Gaussians are the subject of a knife-edge test" % (tag, n_knife_pixels, int(knife.sum())))
     assert n_knife_pixels <= 5e-4 * H * W and knife.sum() <= 5e-3 * P, (n_knife_pixels, int(knife.sum()))
+    print("%s: %d rows behind a knife-edge subject (REL_TOL_DOWNSTREAM class)" % (tag, int(behind.sum())))
+    assert behind.sum() <= 0.15 * P, int(behind.sum())          # a large class; the guard is MAX_LOOSE_ENTRIES in _compare
     rot_floor = float(np.abs(go["scales"] * sc["scales"]).max())      # rotation of an isotropic splat: analytically 0
     for name, ours in (("means3D", t["means3D"].grad), ("means2D", m2.grad), ("opacities", t["opacities"].grad),
                        ("shs", t["shs"].grad), ("scales", t["scales"].grad), ("rotations", t["rotations"].grad)):
@@ -153,17 +171,27 @@ def test_four_view_launch_set_at_100k_1024(oracle):
             imgs.append(out)
             ros.append(ro)
             grads.append(ro.backward(gC[v], gD[v], gA[v], alpha_out=alpha_np[v]))
-        kd = [ro.knife_edge_gaussians(downstream=True) for ro in ros]
+        kd = [ro.knife_edge_gaussians(sharing=True) for ro in ros]
         knife, behind = [k[0] for k in kd], [k[2] for k in kd]     # per view: subjects of a knife-edge test / rows behind one
     finally:
         oracle.set_threads(1)
+        knife_wide = [ro.knife_edge_gaussians(thresh=1e-3)[0] for ro in ros]      # diagnostic: near-threshold at a 50x wider margin
     knife_any, behind_any = np.logical_or.reduce(knife), np.logical_or.reduce(behind)
     assert knife_any.sum() <= 1e-2 * P, int(knife_any.sum())       # ~1e-3 of the Gaussians per view
+    # the looser REL_TOL_DOWNSTREAM class (rows blended behind a knife-edge subject) is bounded too
+    print("4 views: rows behind a knife-edge subject per view %s, union %d" % ([int(b.sum()) for b in behind], int(behind_any.sum())))
+    assert all(b.sum() <= 0.2 * P for b in behind) and behind_any.sum() <= 0.5 * P, [int(b.sum()) for b in behind]
     for v in range(4):
         o_color, o_radii, o_depth, o_alpha = imgs[v]
         assert np.array_equal(radii[v].cpu().numpy(), o_radii), "radii of view %d" % v
         _assert_images(ros[v], color[v], depth[v], alpha[v], o_color, o_depth, o_alpha)
         _compare("4 views", "means2D[%d]" % v, m2.grad[v], grads[v]["means2D"], skip_rows=knife[v], loose_rows=behind[v])
+        rec = _report["4 views"]["means2D[%d]" % v]
+        if "worst_row" in rec:          # is the worst element-wise entry a NEAR knife-edge Gaussian (margin 2e-5 .. 1e-3)?
+            rec["worst_row_near_knife_edge_1e-3"] = bool(knife_wide[v][rec["worst_row"]])
+            rec["worst_row_shares_a_knife_edge_pixel"] = bool(behind[v][rec["worst_row"]])
+            print("   worst row %d: ref %.3e (%.1e of the maximum), ours %.3e, near-knife-edge(1e-3) %s" % (
+                rec["worst_row"], rec["worst_ref"], rec["worst_ref_over_top"], rec["worst_ours"], rec["worst_row_near_knife_edge_1e-3"]))
     tot = {k: sum(g[k].astype(np.float64) for g in grads) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     rot_floor = float(np.abs(tot["scales"] * sc["scales"]).max())
     for k in ("means3D", "opacities", "shs", "scales"):

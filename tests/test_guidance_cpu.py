@@ -438,3 +438,158 @@ def test_stage_three_densify_schedule_matches_reference_quirks(tmp_path):
     want = torch.nn.functional.interpolate(refined[idx_mapper].permute(0, 3, 1, 2)[:, :, 60:890, 220:800], scale_factor=0.5,
                                            mode="bilinear", align_corners=False)     # refine.py:307-311 verbatim
     assert torch.equal(small, want)
+
+
+# ---- round 3: SD1.5 / ControlNet / VAE pinned key by key against the PUBLIC diffusers layout -------------------------------
+# The tables below are written from the published model configurations (runwayml/stable-diffusion-v1-5 unet/config.json:
+# block_out_channels 320/640/1280/1280, layers_per_block 2, cross_attention_dim 768, attention_head_dim 8,
+# use_linear_projection false; lllyasviel/control_v11p_sd15_openpose: conditioning_embedding_out_channels 16/32/96/256;
+# stabilityai/sd-vae-ft-mse: block_out_channels 128/256/512/512, layers_per_block 2, latent_channels 4) and diffusers'
+# module naming — independently of gaussianip_amd/guidance/networks.py, whose state dict must translate to exactly them.
+def _resnet(t, pre, cin, cout, temb=1280):
+    t[pre + "norm1.weight"] = t[pre + "norm1.bias"] = (cin,)
+    t[pre + "conv1.weight"], t[pre + "conv1.bias"] = (cout, cin, 3, 3), (cout,)
+    if temb:
+        t[pre + "time_emb_proj.weight"], t[pre + "time_emb_proj.bias"] = (cout, temb), (cout,)
+    t[pre + "norm2.weight"] = t[pre + "norm2.bias"] = (cout,)
+    t[pre + "conv2.weight"], t[pre + "conv2.bias"] = (cout, cout, 3, 3), (cout,)
+    if cin != cout:
+        t[pre + "conv_shortcut.weight"], t[pre + "conv_shortcut.bias"] = (cout, cin, 1, 1), (cout,)
+
+
+def _transformer(t, pre, c, ctx=768):
+    t[pre + "norm.weight"] = t[pre + "norm.bias"] = (c,)
+    t[pre + "proj_in.weight"], t[pre + "proj_in.bias"] = (c, c, 1, 1), (c,)
+    b = pre + "transformer_blocks.0."
+    for n in ("norm1", "norm2", "norm3"):
+        t[b + n + ".weight"] = t[b + n + ".bias"] = (c,)
+    for a, kv in (("attn1", c), ("attn2", ctx)):
+        t[b + a + ".to_q.weight"] = (c, c)
+        t[b + a + ".to_k.weight"] = t[b + a + ".to_v.weight"] = (c, kv)
+        t[b + a + ".to_out.0.weight"], t[b + a + ".to_out.0.bias"] = (c, c), (c,)
+    t[b + "ff.net.0.proj.weight"], t[b + "ff.net.0.proj.bias"] = (8 * c, c), (8 * c,)
+    t[b + "ff.net.2.weight"], t[b + "ff.net.2.bias"] = (c, 4 * c), (c,)
+    t[pre + "proj_out.weight"], t[pre + "proj_out.bias"] = (c, c, 1, 1), (c,)
+
+
+def _sd15_encoder_side(t):
+    chans = (320, 640, 1280, 1280)
+    t["time_embedding.linear_1.weight"], t["time_embedding.linear_1.bias"] = (1280, 320), (1280,)
+    t["time_embedding.linear_2.weight"], t["time_embedding.linear_2.bias"] = (1280, 1280), (1280,)
+    t["conv_in.weight"], t["conv_in.bias"] = (320, 4, 3, 3), (320,)
+    c = 320
+    for i, w in enumerate(chans):
+        for j in range(2):
+            _resnet(t, "down_blocks.%d.resnets.%d." % (i, j), c, w)
+            if i < 3:
+                _transformer(t, "down_blocks.%d.attentions.%d." % (i, j), w)
+            c = w
+        if i < 3:
+            t["down_blocks.%d.downsamplers.0.conv.weight" % i], t["down_blocks.%d.downsamplers.0.conv.bias" % i] = (w, w, 3, 3), (w,)
+    _resnet(t, "mid_block.resnets.0.", 1280, 1280)
+    _transformer(t, "mid_block.attentions.0.", 1280)
+    _resnet(t, "mid_block.resnets.1.", 1280, 1280)
+
+
+def sd15_unet_table():
+    t = {}
+    _sd15_encoder_side(t)
+    rev = (1280, 1280, 640, 320)
+    prev = 1280
+    for i, out in enumerate(rev):
+        inp = rev[min(i + 1, 3)]
+        for j in range(3):
+            skip = inp if j == 2 else out
+            _resnet(t, "up_blocks.%d.resnets.%d." % (i, j), (prev if j == 0 else out) + skip, out)
+            if i > 0:
+                _transformer(t, "up_blocks.%d.attentions.%d." % (i, j), out)
+        if i < 3:
+            t["up_blocks.%d.upsamplers.0.conv.weight" % i], t["up_blocks.%d.upsamplers.0.conv.bias" % i] = (out, out, 3, 3), (out,)
+        prev = out
+    t["conv_norm_out.weight"] = t["conv_norm_out.bias"] = (320,)
+    t["conv_out.weight"], t["conv_out.bias"] = (4, 320, 3, 3), (4,)
+    return t
+
+
+def sd15_controlnet_table():
+    t = {}
+    _sd15_encoder_side(t)
+    emb = (16, 32, 96, 256)
+    t["controlnet_cond_embedding.conv_in.weight"], t["controlnet_cond_embedding.conv_in.bias"] = (16, 3, 3, 3), (16,)
+    for k in range(3):
+        a, b = emb[k], emb[k + 1]
+        t["controlnet_cond_embedding.blocks.%d.weight" % (2 * k)], t["controlnet_cond_embedding.blocks.%d.bias" % (2 * k)] = (a, a, 3, 3), (a,)
+        t["controlnet_cond_embedding.blocks.%d.weight" % (2 * k + 1)], t["controlnet_cond_embedding.blocks.%d.bias" % (2 * k + 1)] = (b, a, 3, 3), (b,)
+    t["controlnet_cond_embedding.conv_out.weight"], t["controlnet_cond_embedding.conv_out.bias"] = (320, 256, 3, 3), (320,)
+    for k, c in enumerate((320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280)):
+        t["controlnet_down_blocks.%d.weight" % k], t["controlnet_down_blocks.%d.bias" % k] = (c, c, 1, 1), (c,)
+    t["controlnet_mid_block.weight"], t["controlnet_mid_block.bias"] = (1280, 1280, 1, 1), (1280,)
+    return t
+
+
+def _vae_mid(t, pre):
+    _resnet(t, pre + "mid_block.resnets.0.", 512, 512, temb=0)
+    a = pre + "mid_block.attentions.0."
+    t[a + "group_norm.weight"] = t[a + "group_norm.bias"] = (512,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        t[a + n + ".weight"], t[a + n + ".bias"] = (512, 512), (512,)
+    _resnet(t, pre + "mid_block.resnets.1.", 512, 512, temb=0)
+
+
+def sd_vae_tables():
+    enc, dec = {}, {}
+    enc["encoder.conv_in.weight"], enc["encoder.conv_in.bias"] = (128, 3, 3, 3), (128,)
+    c = 128
+    for i, w in enumerate((128, 256, 512, 512)):
+        for j in range(2):
+            _resnet(enc, "encoder.down_blocks.%d.resnets.%d." % (i, j), c, w, temb=0)
+            c = w
+        if i < 3:
+            enc["encoder.down_blocks.%d.downsamplers.0.conv.weight" % i], enc["encoder.down_blocks.%d.downsamplers.0.conv.bias" % i] = (w, w, 3, 3), (w,)
+    _vae_mid(enc, "encoder.")
+    enc["encoder.conv_norm_out.weight"] = enc["encoder.conv_norm_out.bias"] = (512,)
+    enc["encoder.conv_out.weight"], enc["encoder.conv_out.bias"] = (8, 512, 3, 3), (8,)
+    enc["quant_conv.weight"], enc["quant_conv.bias"] = (8, 8, 1, 1), (8,)
+    dec["post_quant_conv.weight"], dec["post_quant_conv.bias"] = (4, 4, 1, 1), (4,)
+    dec["decoder.conv_in.weight"], dec["decoder.conv_in.bias"] = (512, 4, 3, 3), (512,)
+    _vae_mid(dec, "decoder.")
+    c = 512
+    for i, w in enumerate((512, 512, 256, 128)):
+        for j in range(3):
+            _resnet(dec, "decoder.up_blocks.%d.resnets.%d." % (i, j), c, w, temb=0)
+            c = w
+        if i < 3:
+            dec["decoder.up_blocks.%d.upsamplers.0.conv.weight" % i], dec["decoder.up_blocks.%d.upsamplers.0.conv.bias" % i] = (w, w, 3, 3), (w,)
+    dec["decoder.conv_norm_out.weight"] = dec["decoder.conv_norm_out.bias"] = (128,)
+    dec["decoder.conv_out.weight"], dec["decoder.conv_out.bias"] = (3, 128, 3, 3), (3,)
+    return enc, dec
+
+
+def test_sd15_architecture_is_pinned_key_by_key_and_by_parameter_count():
+    """Every parameter of the repo's U-Net / ControlNet / VAE translates to a diffusers key of the public SD1.5 layout with
+    the public shape — the full key -> shape tables, not a handful of names — and the totals are the published ones:
+    UNet2DConditionModel 859 520 964 parameters in 686 tensors, ControlNetModel 361 279 120 in 340, AutoencoderKL
+    83 653 863 in 248 (encoder + quant_conv 34 163 664, decoder + post_quant_conv 49 490 199); the IP-Adapter-FaceID
+    processors add 25 509 888 (rank-128 LoRA on q / k / v / out of 32 attentions) + 19 169 280 (16 x to_k_ip / to_v_ip)."""
+    from math import prod
+    from gaussianip_amd.guidance import checkpoints as ck
+    from gaussianip_amd.guidance.networks import ControlNet, UNet, VAEDecoder, VAEEncoder
+    with torch.device("meta"):
+        nets = {"unet": UNet(0, False, 1.0), "controlnet": ControlNet(), "vae_encoder": VAEEncoder(), "vae_decoder": VAEDecoder()}
+        full = UNet(128, True, 0.5)
+    enc_t, dec_t = sd_vae_tables()
+    tables = {"unet": sd15_unet_table(), "controlnet": sd15_controlnet_table(), "vae_encoder": enc_t, "vae_decoder": dec_t}
+    totals = {"unet": (859520964, 686), "controlnet": (361279120, 340), "vae_encoder": (34163664, 108), "vae_decoder": (49490199, 140)}
+    for kind, net in nets.items():
+        ours = {ck.diffusers_key(kind, k): tuple(v.shape) for k, v in net.state_dict().items()}
+        want = tables[kind]
+        assert set(ours) == set(want), (kind, sorted(set(ours) ^ set(want))[:6])
+        wrong = {k: (ours[k], want[k]) for k in want if ours[k] != want[k]}
+        assert not wrong, (kind, list(wrong.items())[:4])
+        assert (sum(prod(s) for s in want.values()), len(want)) == totals[kind], kind
+        assert (sum(p.numel() for p in net.parameters()), len(list(net.parameters()))) == totals[kind], kind
+    assert totals["vae_encoder"][0] + totals["vae_decoder"][0] == 83653863
+    extra = sum(p.numel() for n, p in full.named_parameters() if ".lora_" in n or "_ip." in n)
+    lora = sum(p.numel() for n, p in full.named_parameters() if ".lora_" in n)
+    assert (lora, extra - lora) == (25509888, 19169280)
+    assert sum(p.numel() for p in full.parameters()) == 859520964 + 44679168
