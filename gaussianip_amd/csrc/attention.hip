@@ -100,32 +100,35 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   // chunks are moved twice with identical data) so that no load or LDS store is predicated; rows past the end of a
   // ragged key set are clamped to its last row (they are masked to -inf before the softmax)
   static_assert(PER >= 2 && PER <= 5, "staging chunks per thread");
-  int st_row[PER], st_ch[PER], st_kl[PER], st_vl[PER];
-#pragma unroll
-  for (int e = 0; e < PER; e++) {
-    int idx = tid + 256 * e;
-    while (idx >= AT_BKV * CH) idx -= AT_BKV * CH;
-    st_row[e] = idx / CH;
-    st_ch[e] = idx - st_row[e] * CH;
-    st_kl[e] = st_row[e] * AT_ROW + ((st_ch[e] ^ kswz<AT_ROW>(st_row[e])) << 4);
-    st_vl[e] = AT_TILE + st_row[e] * AT_ROW + ((st_ch[e] ^ vswz<AT_ROW>(st_row[e])) << 4);
+  // one set of NAMED scalars per staged chunk (e = 0 .. PER - 1), enumerated by macros under `if constexpr`: arrays (even
+  // with fully unrolled loops, even inside inlined lambdas) were placed in scratch memory by hipcc, which made the D = 40
+  // kernel 2x slower
+#define AT_SLOT(e)                                                                                        \
+  int idx##e = tid + 256 * e;                                                                             \
+  if (idx##e >= AT_BKV * CH) idx##e -= AT_BKV * CH;                                                       \
+  if (idx##e >= AT_BKV * CH) idx##e -= AT_BKV * CH;                                                       \
+  const int row##e = idx##e / CH, ch##e = idx##e - row##e * CH;                                           \
+  const int kl##e = row##e * AT_ROW + ((ch##e ^ kswz<AT_ROW>(row##e)) << 4);                              \
+  const int vl##e = AT_TILE + row##e * AT_ROW + ((ch##e ^ vswz<AT_ROW>(row##e)) << 4);                    \
+  uint4 kr##e = make_uint4(0, 0, 0, 0), vr##e = make_uint4(0, 0, 0, 0);
+  AT_SLOT(0) AT_SLOT(1) AT_SLOT(2) AT_SLOT(3) AT_SLOT(4)
+#undef AT_SLOT
+#define AT_FETCH1(e, blk_)                                                      \
+  if constexpr (PER > e) {                                                      \
+    const int ra_ = min((blk_) * AT_BKV + row##e, n_keys - 1);                  \
+    kr##e = *(const uint4*)(kp + (size_t)ra_ * ld + ch##e * 8);                 \
+    vr##e = *(const uint4*)(vp + (size_t)ra_ * ld + ch##e * 8);                 \
   }
-  uint4 kr[PER], vr[PER];
-#define AT_FETCH(blk_)                                                                   \
-  {                                                                                      \
-    _Pragma("unroll") for (int e_ = 0; e_ < PER; e_++) {                                 \
-      const int ra_ = min((blk_) * AT_BKV + st_row[e_], n_keys - 1);                     \
-      kr[e_] = *(const uint4*)(kp + (size_t)ra_ * ld + st_ch[e_] * 8);                   \
-      vr[e_] = *(const uint4*)(vp + (size_t)ra_ * ld + st_ch[e_] * 8);                   \
-    }                                                                                    \
+#define AT_FETCH(blk_) { AT_FETCH1(0, blk_) AT_FETCH1(1, blk_) AT_FETCH1(2, blk_) AT_FETCH1(3, blk_) AT_FETCH1(4, blk_) }
+#define AT_DEPOSIT1(e, st_)                                                     \
+  if constexpr (PER > e) {                                                      \
+    *(uint4*)(st_ + kl##e) = kr##e;                                             \
+    *(uint4*)(st_ + vl##e) = vr##e;                                             \
   }
-#define AT_DEPOSIT(stage_)                                                 \
-  {                                                                        \
-    unsigned char* st_ = smem + (stage_) * 2 * AT_TILE;                    \
-    _Pragma("unroll") for (int e_ = 0; e_ < PER; e_++) {                   \
-      *(uint4*)(st_ + st_kl[e_]) = kr[e_];                                 \
-      *(uint4*)(st_ + st_vl[e_]) = vr[e_];                                 \
-    }                                                                      \
+#define AT_DEPOSIT(stage_)                                                      \
+  {                                                                             \
+    unsigned char* stp_ = smem + (stage_) * 2 * AT_TILE;                        \
+    AT_DEPOSIT1(0, stp_) AT_DEPOSIT1(1, stp_) AT_DEPOSIT1(2, stp_) AT_DEPOSIT1(3, stp_) AT_DEPOSIT1(4, stp_)   \
   }
 
   // fragment addressing

@@ -126,16 +126,18 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    host_s = 0.0
+    host_s = host_cpu_s = 0.0
     for i in range(steps):
-        h0 = time.perf_counter()
+        h0, c0 = time.perf_counter(), time.thread_time()
         step(warmup + i)
-        host_s += time.perf_counter() - h0          # time the host needs to enqueue a step (no synchronisation inside)
+        host_s += time.perf_counter() - h0          # wall time of the enqueue calls of a step (no synchronisation inside, but the
+        host_cpu_s += time.thread_time() - c0       # runtime blocks the host once it is a queue's depth ahead); CPU time of the thread
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     host_ms = host_s / steps * 1e3
+    host_cpu_ms = host_cpu_s / steps * 1e3
     if world > 1:
         et = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
@@ -155,7 +157,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
 
     if not pieces:
         return {"value": round((shard.n_seed_groups if shard is not None and not proxy_group else 1) / dt, 3), "ms_per_step": round(dt * 1e3, 2),
-                "host_enqueue_ms_per_step": round(host_ms, 2)}
+                "host_enqueue_ms_per_step": round(host_ms, 2), "host_cpu_ms_per_step": round(host_cpu_ms, 2)}
     lat = torch.randn(B, 4, 64, 64, device=dev)
     ctrl = pose.permute(0, 3, 1, 2)
     emb = torch.randn(3 * B, 81, 768, device=dev, dtype=torch.float16) * 0.1
@@ -185,7 +187,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
            "views_per_s": round(opt_steps * views_per_step / dt, 2), "views_per_optimizer_step": views_per_step, "n_gpus": world,
            "layout": lay, "amp_gradscaler": bool(amp), "fused_adam": bool(fused_adam),
            "timed_step": "lr update + render 4 views + GPU pose maps + prompt lookup + VAE/ControlNet/U-Net ANPG + loss + backward + densification stats + Adam", "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
-           "host_enqueue_ms_per_step": round(host_ms, 2), "denoise_ms": round(den_ms, 2), "vae_enc_fwd_bwd_ms": round(vae_ms, 2), "setup_s": round(setup_s, 1),
+           "host_enqueue_ms_per_step": round(host_ms, 2), "host_cpu_ms_per_step": round(host_cpu_ms, 2), "denoise_ms": round(den_ms, 2), "vae_enc_fwd_bwd_ms": round(vae_ms, 2), "setup_s": round(setup_s, 1),
            "denoise_flops": flops, "denoise_tflops_per_s": None if not flops else round(flops / (den_ms * 1e-3) / 1e12, 1),
            "denoise_mfma_frac": None if not flops else round(flops / (den_ms * 1e-3) / 2.5e15, 4),   # fp16 dense peak ~2.5 PFLOP/s
            "data": "synthetic", "dtype": "f16 (networks) / f32 (raster)"}
