@@ -39,6 +39,54 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
+// Optional second meaning of the epilogue statistics (gnb.x != NULL): the kernel is the DATA GRADIENT of a convolution whose
+// input was y = silu?(GroupNorm(x + addend)); its output `out` is dL/dy, and the per-channel sums it leaves in chan_stats are
+// the two reductions of that GroupNorm's backward, sum(dxh) and sum(dxh * xh) with xh = (x + addend - mean) * rstd,
+// dxh = dL/dy * dsilu?(gamma xh + beta) * gamma — what gn_reduce_kernel<1> (csrc/groupnorm.hip) computes in a separate pass
+// over x and dL/dy.  Needs HW % (rows of a tile) == 0: a tile lies inside one sample.
+struct GnBwdArgs {
+  const _Float16* x;        // the GroupNorm's input [N, HW, C] (C = this kernel's Cout)
+  const _Float16* gamma;
+  const _Float16* beta;
+  const _Float16* addend;   // optional per-(sample, channel) addend, row stride addend_stride (0 = one row)
+  const float* mean;        // [N, G]
+  const float* rstd;
+  int G, silu, addend_stride, HW;
+};
+
+struct GnBwdLane {          // one lane's eight channels
+  float ga[8], be[8], mu[8], rs[8], ad[8];
+};
+
+__device__ __forceinline__ void gnb_load(const GnBwdArgs& a, int n, int c0, int C, GnBwdLane& L) {
+  const int cg = C / a.G;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int c = c0 + j, g = c / cg;
+    L.ga[j] = (float)a.gamma[c];
+    L.be[j] = (float)a.beta[c];
+    L.mu[j] = a.mean[n * a.G + g];
+    L.rs[j] = a.rstd[n * a.G + g];
+    L.ad[j] = a.addend ? (float)a.addend[(size_t)n * a.addend_stride + c] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void gnb_accumulate(const GnBwdArgs& a, const GnBwdLane& L, const f16x8& dy, const f16x8& xv, float* s8, float* q8) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const float xh = ((float)xv[j] + L.ad[j] - L.mu[j]) * L.rs[j];
+    float g = (float)dy[j];
+    if (a.silu) {
+      const float v = L.ga[j] * xh + L.be[j];
+      const float sg = 1.f / (1.f + __expf(-v));
+      g *= sg * (1.f + v * (1.f - sg));
+    }
+    const float dxh = g * L.ga[j];
+    s8[j] += dxh;
+    q8[j] = fmaf(dxh, xh, q8[j]);
+  }
+}
+
 // TAPS = 9: the 3x3 convolution.  TAPS = 1: the same machinery as a plain GEMM out[m][co] = sum_k x[m][k] w[co][k]
 // (nn.Linear / 1x1 convolution on the NHWC token view; H = 1, W = M).  GEGLU (TAPS = 1 only): w has 2 * Cout rows
 // [value | gate]; a workgroup computes 64 value and the matching 64 gate columns and writes value * gelu(gate).
@@ -47,7 +95,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom,
-               float* __restrict__ chan_stats) {
+               float* __restrict__ chan_stats, GnBwdArgs gnb) {
   // geom = stride | pad_top << 8 | pad_left << 16; H, W are the OUTPUT dims, Hin, Win the input dims (equal at stride 1)
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -255,6 +303,8 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #pragma unroll
       for (int j = 0; j < 8; j++) { s8[j] = 0.f; q8[j] = 0.f; }
       if (mine) {
+        GnBwdLane gl;
+        if (chan_stats && gnb.x) gnb_load(gnb, (int)(m0 / (unsigned)gnb.HW), co, Cout, gl);
 #pragma unroll 4
         for (int row = r0; row < CV_BM; row += RPP) {
           const unsigned m = m0 + row;
@@ -267,8 +317,12 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
           }
           *(f16x8*)(out + (size_t)m * Cout + co) = v;
           if (chan_stats) {
+            if (gnb.x) {
+              gnb_accumulate(gnb, gl, v, *(const f16x8*)(gnb.x + (size_t)m * Cout + co), s8, q8);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const float f = (float)v[j]; s8[j] += f; q8[j] = fmaf(f, f, q8[j]); }
+              for (int j = 0; j < 8; j++) { const float f = (float)v[j]; s8[j] += f; q8[j] = fmaf(f, f, q8[j]); }
+            }
           }
         }
       }
@@ -347,7 +401,7 @@ template <int BN, int TAPS>
 __global__ void __launch_bounds__(CVB_THREADS, 2)
 conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                 const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
-                int m_tiles, int n_tiles, int Hin, int Win, int geom, float* __restrict__ chan_stats) {
+                int m_tiles, int n_tiles, int Hin, int Win, int geom, float* __restrict__ chan_stats, GnBwdArgs gnb) {
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int WN = BN == 256 ? 4 : 2, WM = 8 / WN;      // wave grid: WM (pixel direction) x WN (channel direction)
@@ -533,6 +587,8 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   for (int b = 0; b < 2; b++)
 #pragma unroll
     for (int j = 0; j < 8; j++) { s8[b][j] = 0.f; q8[b][j] = 0.f; }
+  GnBwdLane gl;
+  if (chan_stats && gnb.x && mine) gnb_load(gnb, (int)(m0 / (unsigned)gnb.HW), co, Cout, gl);
 #pragma unroll
   for (int pass = 0; pass < PASSES; pass++) {
     if (PASSES == 1 || wr == pass) {
@@ -566,11 +622,17 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
         *(f16x8*)(out + (size_t)m * Cout + co) = v;
         if (chan_stats) {
           const int blk = PASSES == 2 ? pass : (row >= 128 ? 1 : 0);
+          if (gnb.x) {
+            const f16x8 xv = *(const f16x8*)(gnb.x + (size_t)m * Cout + co);
+            if (blk == 0) gnb_accumulate(gnb, gl, v, xv, s8[0], q8[0]);
+            else gnb_accumulate(gnb, gl, v, xv, s8[1], q8[1]);
+          } else {
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float f = (float)v[j];
-            if (blk == 0) { s8[0][j] += f; q8[0][j] = fmaf(f, f, q8[0][j]); }
-            else { s8[1][j] += f; q8[1][j] = fmaf(f, f, q8[1][j]); }
+            for (int j = 0; j < 8; j++) {
+              const float f = (float)v[j];
+              if (blk == 0) { s8[0][j] += f; q8[0][j] = fmaf(f, f, q8[0][j]); }
+              else { s8[1][j] += f; q8[1][j] = fmaf(f, f, q8[1][j]); }
+            }
           }
         }
       }
@@ -636,7 +698,7 @@ static int env_int(const char* name, int dflt) {
 
 template <int BN, int TAPS>
 static int launch_big(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W, int Cin,
-                      int Cout, hipStream_t s, int Hin, int Win, int geom, float* chan_stats) {
+                      int Cout, hipStream_t s, int Hin, int Win, int geom, float* chan_stats, const GnBwdArgs& gnb) {
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + CVB_BM - 1) / CVB_BM), n_tiles = (Cout + BN - 1) / BN;
   const size_t lds = 2 * (size_t)(CVB_BM + BN) * 128;
@@ -650,7 +712,7 @@ static int launch_big(const void* x, const void* w, const void* bias, const void
   }
   hipLaunchKernelGGL((conv_big_kernel<BN, TAPS>), dim3(m_tiles * n_tiles), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin, Cout,
-                     m_tiles, n_tiles, Hin, Win, geom, chan_stats);
+                     m_tiles, n_tiles, Hin, Win, geom, chan_stats, gnb);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -670,13 +732,16 @@ static int big_tile_width(long long M, int Cout) {
 template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
                   int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0, int Hin = 0, int Win = 0,
-                  int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr) {
+                  int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr, const GnBwdArgs* gnb_in = nullptr) {
+  GnBwdArgs gnb = {};
+  if (gnb_in) gnb = *gnb_in;
   if (Hin == 0) { Hin = H; Win = W; }
   const long long M = (long long)N * H * W;
   if constexpr (!GEGLU) {
     if (!(Cout & 7)) {
       const int bw = big_tile_width(M, Cout);
-      if (bw == 256) return launch_big<256, TAPS>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, Hin, Win, geom, chan_stats);
+      if (bw == 256 && !(gnb.x && gnb.HW % CVB_BM))
+        return launch_big<256, TAPS>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, Hin, Win, geom, chan_stats, gnb);
     }
   }
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
@@ -722,7 +787,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26);   // bits 26-28: timing ablations (WRONG results)
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
-                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats);
+                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats, gnb);
   if (ksplit > 1) {
     const unsigned n4 = (unsigned)(M * Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
@@ -756,6 +821,24 @@ extern "C" int gip_conv3x3_stats_nhwc_f16(const void* x, const void* w, const vo
   const int geom = 1 | (1 << 8) | (1 << 16);
   return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_stats)
               : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_stats);
+}
+
+extern "C" int gip_conv3x3_gnbwd_nhwc_f16(const void* dy_in, const void* w, void* out, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                          int32_t Cout, const void* gn_x, const void* gamma, const void* beta, const float* mean,
+                                          const float* rstd, int32_t G, int32_t apply_silu, const void* addend,
+                                          int32_t addend_stride, float* chan_sums, void* stream) {
+  if (!dy_in || !w || !out || !gn_x || !gamma || !beta || !mean || !rstd || !chan_sums || N < 1 || H < 1 || W < 1 || Cin < CV_BK ||
+      Cin % CV_BK || Cout < 8 || (Cout & 7) || G < 1 || Cout % G || ((long long)H * W) % CV_BM)
+    return 1;
+  if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;
+  GnBwdArgs g;
+  g.x = (const _Float16*)gn_x; g.gamma = (const _Float16*)gamma; g.beta = (const _Float16*)beta; g.addend = (const _Float16*)addend;
+  g.mean = mean; g.rstd = rstd; g.G = G; g.silu = apply_silu; g.addend_stride = addend_stride; g.HW = H * W;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  return wide ? launch<160, 2, 9, false>(dy_in, w, nullptr, nullptr, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_sums, &g)
+              : launch<128, 2, 9, false>(dy_in, w, nullptr, nullptr, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_sums, &g);
 }
 
 extern "C" int gip_linear_stats_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,

@@ -135,6 +135,8 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
   // fixed summation order.  splits == 0 (forward): mean / rstd were made by gn_finalize_stats_kernel, nothing to reduce
   if (MODE == 0 && splits == 0) {
     for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) { s_g[2 * gg] = mean[n * G + gg]; s_g[2 * gg + 1] = rstd[n * G + gg]; }
+  } else if (MODE == 1 && splits == 0) {      // S1 / m, S2 / m made by gn_finalize_bwd_kernel from the data-gradient kernel's sums
+    for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) { s_g[2 * gg] = partial[((long long)n * G + gg) * 2]; s_g[2 * gg + 1] = partial[((long long)n * G + gg) * 2 + 1]; }
   } else {
     float* s_part = s_g + 2 * G;                      // [slices][G][2]
     const int slices = GN_BLOCK / G > 0 ? GN_BLOCK / G : 1;
@@ -255,6 +257,29 @@ gn_finalize_stats_kernel(const float* __restrict__ chan_stats, int blocks_per_sa
   }
 }
 
+// The two reductions of the GroupNorm backward from the per-(128-row block, channel) sums that the data-gradient convolution
+// wrote in its epilogue (csrc/conv3x3.hip, GnBwdArgs): out[n][g] = (sum dxh, sum dxh xh) / (HW * C / G).  Fixed order.
+__global__ void __launch_bounds__(GN_BLOCK)
+gn_finalize_bwd_kernel(const float* __restrict__ chan_sums, int blocks_per_sample, long long HW, int C, int G, float* __restrict__ out) {
+  __shared__ float s_part[GN_BLOCK * 2];
+  const int n = blockIdx.y, g = blockIdx.x, cg = C / G;
+  const int j = threadIdx.x % cg, k = threadIdx.x / cg, K = GN_BLOCK / cg;
+  float S = 0.f, Q = 0.f;
+  if (k < K) {
+    const float* p = chan_sums + ((size_t)n * blocks_per_sample * C + (size_t)g * cg + j) * 2;
+    for (int b = k; b < blocks_per_sample; b += K) { S += p[(size_t)b * C * 2]; Q += p[(size_t)b * C * 2 + 1]; }
+  }
+  s_part[2 * threadIdx.x] = S; s_part[2 * threadIdx.x + 1] = Q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S = 0.f; Q = 0.f;
+    for (int i = 0; i < K * cg; i++) { S += s_part[2 * i]; Q += s_part[2 * i + 1]; }
+    const float inv_m = 1.f / ((float)HW * (float)cg);
+    out[((long long)n * G + g) * 2] = S * inv_m;
+    out[((long long)n * G + g) * 2 + 1] = Q * inv_m;
+  }
+}
+
 static size_t reduce_lds_bytes(int C) {
   const int tpr = C >> 3, cpt = (tpr + GN_BLOCK - 1) / GN_BLOCK, lanes_x = (tpr + cpt - 1) / cpt;
   const int rpi = GN_BLOCK / lanes_x > 0 ? GN_BLOCK / lanes_x : 1;
@@ -339,6 +364,25 @@ static int gn_backward(const void* x, const void* dy, const void* gamma, const v
                      const_cast<float*>(mean), const_cast<float*>(rstd), (const float*)partial, (half8*)dx,
                      (long long)HW, C, G, rsplits, splits, 0.f, apply_silu, (const __half*)addend, addend_stride,
                      (const half8*)accum);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_gn_silu_backward_sums(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
+                                         const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G,
+                                         int32_t apply_silu, const void* addend, int32_t addend_stride, const void* accum,
+                                         const float* chan_sums, int32_t blocks_per_sample, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  int rc = check(x, dx, N, HW, C, G, workspace_bytes);
+  if (rc) return rc;
+  if (!dy || !gamma || !beta || !mean || !rstd || !workspace || !chan_sums || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  float* sums = (float*)workspace;                       // [N, G, 2]
+  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(G, N), dim3(GN_BLOCK), 0, s, chan_sums, blocks_per_sample, (long long)HW, C, G, sums);
+  const int splits = pick_splits(N, HW, C);
+  hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
+                     (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta,
+                     const_cast<float*>(mean), const_cast<float*>(rstd), (const float*)sums, (half8*)dx,
+                     (long long)HW, C, G, 0, splits, 0.f, apply_silu, (const __half*)addend, addend_stride, (const half8*)accum);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -203,6 +203,7 @@ class LayerNorm(nn.LayerNorm):
 # ---------------------------------------------------------------------------------------------------------------------
 # 3x3 / stride 1 / pad 1 convolution on the matrix cores (csrc/conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------------
+_GN_SUMS_MIN_TILES = 256    # below it the data gradient runs split-K, whose reduce kernel does not make the sums
 _MIN_CONV_TILES = 32         # tile counts below 256 run split-K (fp32 slabs in the shared workspace); tiny problems stay on MIOpen
 _SPLITK_WS_BYTES = 64 << 20
 _WT_CACHE_MAX = 256
@@ -433,7 +434,33 @@ def _gn_fwd_raw(x, gn, addend, chan_stats):
     return y, mean, rstd
 
 
-def _gn_bwd_raw(x, dy, gn, mean, rstd, addend, accum=None):
+def _dgrad_with_gn_sums(dy, w, x_gn, gn, mean, rstd, addend):
+    """(dL/dy_gn, chan_sums): the data gradient conv3x3(dy, w^T-flipped) of a convolution whose input was gn(x_gn), with the two
+    reductions of that GroupNorm's backward taken in the kernel's epilogue (gip_conv3x3_gnbwd_nhwc_f16); chan_sums is None
+    when the shape does not qualify (the caller's GroupNorm backward then takes its own reduction pass).
+    OPT-IN (GIP_GN_BWD_SUMS=1): measured neutral in a same-box A/B of the training step (39.2 ms with and without; VAE
+    forward + backward 15.15 vs 15.28 ms) — the epilogue's extra read of the GroupNorm input and its ~20 vector
+    instructions per element (dsilu) cost the data-gradient kernel what the separate reduction pass took; unlike the
+    forward statistics (two fmas per element, no extra read), which are on by default."""
+    wt = _transposed_weight(w)
+    N, C, H, W = x_gn.shape
+    if (os.environ.get("GIP_GN_BWD_SUMS", "0") != "1" or _DISABLED or (H * W) % 256 or C % 8 or _conv_tiles(N, H, W, C) < _GN_SUMS_MIN_TILES or
+            C // gn.num_groups > 256):
+        return _conv_call(dy, wt, C), None
+    out = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    sums = torch.empty((N * H * W // 128, C, 2), dtype=torch.float32, device=dy.device)
+    ad_ptr, ad_stride = ctypes.c_void_p(None), 0
+    if addend is not None:
+        ad_ptr, ad_stride = _p(addend), (addend.stride(0) if addend.dim() == 2 and addend.shape[0] > 1 else 0)
+    rc = _lib.nn_lib().gip_conv3x3_gnbwd_nhwc_f16(_p(dy), _p(wt), _p(out), N, H, W, dy.shape[1], C, _p(x_gn), _p(gn.weight), _p(gn.bias),
+                                                  _p(mean), _p(rstd), gn.num_groups, int(gn.act), ad_ptr, ad_stride, _p(sums),
+                                                  ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("gip_conv3x3_gnbwd_nhwc_f16 failed with status %d" % rc)
+    return out, sums
+
+
+def _gn_bwd_raw(x, dy, gn, mean, rstd, addend, accum=None, chan_sums=None):
     """dL/dx of the same GroupNorm (+ `accum`, the other gradient reaching x, in the same pass)."""
     N, C, H, W = x.shape
     lib = _lib.nn_lib()
@@ -443,7 +470,12 @@ def _gn_bwd_raw(x, dy, gn, mean, rstd, addend, accum=None):
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     ws = _workspace(x.device, lib.gip_gn_workspace_bytes(N, gn.num_groups))
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    if accum is None:
+    if chan_sums is not None:
+        rc = lib.gip_gn_silu_backward_sums(_p(x), _p(dy), _p(gn.weight), _p(gn.bias), _p(mean), _p(rstd), _p(dx), N, H * W, C,
+                                           gn.num_groups, int(gn.act), ad_ptr, ad_stride,
+                                           ctypes.c_void_p(None) if accum is None else _p(accum), _p(chan_sums), (H * W) // 128,
+                                           _p(ws), ws.numel(), stream)
+    elif accum is None:
         rc = lib.gip_gn_silu_backward(_p(x), _p(dy), _p(gn.weight), _p(gn.bias), _p(mean), _p(rstd), _p(dx), N, H * W, C,
                                       gn.num_groups, int(gn.act), ad_ptr, ad_stride, _p(ws), ws.numel(), stream)
     else:
@@ -503,10 +535,11 @@ class _ResBlockNode(torch.autograd.Function):
         block = ctx.block
         c1, c2 = block.conv1, block.conv2
         dy = dy.contiguous(memory_format=torch.channels_last)
-        d_y2 = _conv_call(dy, _transposed_weight(c2.weight), c2.weight.shape[1])
-        d_h = _gn_bwd_raw(h, d_y2, block.norm2, mean2, rstd2, c1.bias)
+        # each data-gradient convolution also takes the two reductions of the GroupNorm backward that consumes its output
+        d_y2, sums2 = _dgrad_with_gn_sums(dy, c2.weight, h, block.norm2, mean2, rstd2, c1.bias)
+        d_h = _gn_bwd_raw(h, d_y2, block.norm2, mean2, rstd2, c1.bias, chan_sums=sums2)
         del d_y2
-        d_y1 = _conv_call(d_h, _transposed_weight(c1.weight), c1.weight.shape[1])
+        d_y1, sums1 = _dgrad_with_gn_sums(d_h, c1.weight, x, block.norm1, mean1, rstd1, None)
         del d_h
         if block.conv_shortcut is None:
             short = dy
@@ -515,7 +548,7 @@ class _ResBlockNode(torch.autograd.Function):
             wt = _wt_cache.get("1x1t", ws_, lambda t: t.detach().reshape(t.shape[0], t.shape[1]).t().contiguous())   # [Cin, Cout]
             N, Co, H, W = dy.shape
             short = F.linear(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt).view(N, H, W, wt.shape[0]).permute(0, 3, 1, 2)
-        return _gn_bwd_raw(x, d_y1, block.norm1, mean1, rstd1, None, accum=short), None, None
+        return _gn_bwd_raw(x, d_y1, block.norm1, mean1, rstd1, None, accum=short, chan_sums=sums1), None, None
 
 
 def resblock_with_grad(x, block):

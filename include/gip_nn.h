@@ -45,6 +45,14 @@ int gip_gn_silu_backward_accum(const void* x, const void* dy, const void* gamma,
                                const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu,
                                const void* addend, int32_t addend_stride, const void* accum,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* Backward with the reduction pass taken out: `chan_sums` [N * blocks_per_sample][C][2] float holds, per 128-row block and
+ * channel, sum(dxh) and sum(dxh * xh) — written by the epilogue of the data-gradient convolution that PRODUCED dy
+ * (gip_conv3x3_gnbwd_nhwc_f16).  One small launch folds them into the two per-group means, then the apply pass runs
+ * (+ `accum` when not NULL, as gip_gn_silu_backward_accum).  workspace: gip_gn_workspace_bytes(N, G). */
+int gip_gn_silu_backward_sums(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
+                              const float* rstd, void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu,
+                              const void* addend, int32_t addend_stride, const void* accum, const float* chan_sums,
+                              int32_t blocks_per_sample, void* workspace, size_t workspace_bytes, void* stream);
 /* Forward with the statistics pass taken out: `chan_stats` [N * blocks_per_sample][C][2] float holds, per 128-row block of
  * x and channel, the sum and the sum of squares of x's elements — written by the epilogue of the kernel that PRODUCED x
  * (gip_conv3x3_stats_nhwc_f16 / gip_linear_stats_f16; HW % 128 == 0 so that a block never straddles two samples).  One
@@ -97,6 +105,15 @@ int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const v
  * statistics pass of the GroupNorm that reads `out` next (gip_gn_silu_forward_stats).  Never split-K.  Cout % 8 == 0. */
 int gip_conv3x3_stats_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
                                int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* chan_stats, void* stream);
+/* Data gradient of a 3x3 convolution whose INPUT was y = silu?(GroupNorm(gn_x + addend)): out = dL/dy = conv3x3(dy_in, w) with
+ * w the flipped-transposed weight (no bias, no residual), and `chan_sums` [N*H*W / 128][Cout][2] = per 128-pixel block and
+ * channel sum(dxh), sum(dxh xh) of that GroupNorm's backward (xh = (gn_x + addend - mean) rstd, dxh = dL/dy dsilu?(gamma xh
+ * + beta) gamma) — the reductions gip_gn_silu_backward would take in a separate pass over gn_x and dL/dy.  (H*W) % 128 == 0
+ * (% 256 where the 256-row tile applies); never split-K. */
+int gip_conv3x3_gnbwd_nhwc_f16(const void* dy_in, const void* w, void* out, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                               int32_t Cout, const void* gn_x, const void* gamma, const void* beta, const float* mean,
+                               const float* rstd, int32_t G, int32_t apply_silu, const void* addend, int32_t addend_stride,
+                               float* chan_sums, void* stream);
 /* gip_linear_f16 (no GEGLU) with the same per-(128-row block, column) statistics of its output. */
 int gip_linear_stats_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                          int32_t K, int32_t Nout, float* chan_stats, void* stream);

@@ -180,12 +180,19 @@ def test_conv_big_tile_kernel(shape):
 
 
 @pytest.mark.parametrize("cin,cout", [(128, 128), (128, 256)])
-def test_resblock_as_one_autograd_node(cin, cout, monkeypatch):
+@pytest.mark.parametrize("sums", [False, True])
+def test_resblock_as_one_autograd_node(cin, cout, sums, monkeypatch):
     """The differentiable ResnetBlock2D of the VAE encoder as ONE autograd node (fused._ResBlockNode: the shortcut's
     gradient rides in the GroupNorm backward's apply pass) against the same block in fp32 PyTorch ops, forward and
     dL/dx, and against the five-node path."""
+    from gaussianip_amd import _lib
     from gaussianip_amd.guidance import fused
     from gaussianip_amd.guidance.networks import ResBlock, init_for_benchmark
+    # sums: the GroupNorm backward's two reductions come out of the data-gradient convolutions' epilogues
+    # (gip_conv3x3_gnbwd_nhwc_f16 -> gip_gn_silu_backward_sums) instead of their own pass
+    monkeypatch.setenv("GIP_GN_BWD_SUMS", "1" if sums else "0")
+    monkeypatch.setattr(fused, "_GN_SUMS_MIN_TILES", 0)
+    before = _lib.call_counts.get("gip_gn_silu_backward_sums", 0)
     torch.manual_seed(0)
     blk = init_for_benchmark(ResBlock(cin, cout, temb_dim=0, eps=1e-6), seed=3)
     with torch.no_grad():
@@ -214,6 +221,7 @@ def test_resblock_as_one_autograd_node(cin, cout, monkeypatch):
         return y.detach(), dx
 
     y1, dx1 = run(True)
+    assert (_lib.call_counts.get("gip_gn_silu_backward_sums", 0) - before == 2) == sums      # opt-in path (measured neutral)
     y0, dx0 = run(False)
     xr = x.float().contiguous().requires_grad_(True)
     ref_blk.requires_grad_(False)
