@@ -217,6 +217,9 @@ def nn_lib():
         lib.gip_lpips_layer_forward.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp]
         lib.gip_lpips_layer_backward.restype = ctypes.c_int
         lib.gip_lpips_layer_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, _vp]
+        lib.gip_attention_fwd_strided2_f16.restype = ctypes.c_int
+        lib.gip_attention_fwd_strided2_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [ctypes.c_float, _vp, _vp, ctypes.c_int32,
+                                                       ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]
         lib.gip_attention_fwd_f16.restype = ctypes.c_int
         lib.gip_attention_fwd_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [ctypes.c_float, _vp, _vp, ctypes.c_int32, ctypes.c_float, _vp]
         lib.gip_attention_fwd_strided_f16.restype = ctypes.c_int

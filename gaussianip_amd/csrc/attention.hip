@@ -47,7 +47,7 @@ template <int D, bool TWO>
 __global__ void __launch_bounds__(256, D > 128 ? 1 : 2)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
-                const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2, int ld_kv, int ld_kv2) {
+                const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
   // ld_kv / ld_kv2: elements between consecutive key rows of (k, v) / (k2, v2).  H * D for packed projections; larger
   // when a layer's keys are a column range of one wide matrix holding the key / value projections of MANY layers
   static_assert(D % 8 == 0 && D <= 160, "head dim");
@@ -74,7 +74,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   // Q^T fragments (B operand): lane = query column, element j = feature 16 s + 8 hh + j; zero beyond D
   f16x8 qf[NS];
   {
-    const _Float16* qp = q + ((size_t)b * Nq + q0 + r) * C + h * D;
+    const _Float16* qp = q + ((size_t)b * Nq + q0 + r) * ld_q + h * D;      // ld_q > C: q is a column range of a fused q | k | v projection
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       const int d0 = 16 * s + 8 * hh;
@@ -293,32 +293,38 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 
 template <int D>
 static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
-                        float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2) {
+                        float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
   if (k2)
     hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
-                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2, ld_kv, ld_kv2);
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
-                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv, ld_kv);
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv, ld_kv, ld_q);
 }
 
-extern "C" int gip_attention_fwd_strided_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
-                                             int32_t Nq, int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2,
-                                             int32_t Nkv2, float weight2, int32_t ld_kv, int32_t ld_kv2, void* stream) {
-  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < 32 || Nq % 32 || Nkv < 1) return 1;
+extern "C" int gip_attention_fwd_strided2_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
+                                              int32_t Nq, int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2,
+                                              int32_t Nkv2, float weight2, int32_t ld_q, int32_t ld_kv, int32_t ld_kv2, void* stream) {
+  if (!q || !k || !v || !o || B < 1 || H < 1 || Nq < 32 || Nq % 32 || Nkv < 1 || ld_q < H * D || ld_q % 8) return 1;
   if ((k2 != nullptr) != (v2 != nullptr) || (k2 && Nkv2 < 1)) return 1;
   if (ld_kv < H * D || ld_kv % 8 || (k2 && (ld_kv2 < H * D || ld_kv2 % 8))) return 1;        // 16-byte row loads
   const float c = scale * 1.4426950408889634f;
   const dim3 grid((Nq + AT_BQ - 1) / AT_BQ, B * H);
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
-    case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
-    case 80: launch_attn<80>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
-    case 160: launch_attn<160>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2); break;
+    case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2, ld_q); break;
+    case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2, ld_q); break;
+    case 80: launch_attn<80>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2, ld_q); break;
+    case 160: launch_attn<160>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2, ld_q); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_attention_fwd_strided_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
+                                             int32_t Nq, int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2,
+                                             int32_t Nkv2, float weight2, int32_t ld_kv, int32_t ld_kv2, void* stream) {
+  return gip_attention_fwd_strided2_f16(q, k, v, o, B, H, Nq, Nkv, D, scale, k2, v2, Nkv2, weight2, H * D, ld_kv, ld_kv2, stream);
 }
 
 extern "C" int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,

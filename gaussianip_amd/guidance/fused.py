@@ -206,7 +206,7 @@ class LayerNorm(nn.LayerNorm):
 _GN_SUMS_MIN_TILES = 256    # below it the data gradient runs split-K, whose reduce kernel does not make the sums
 _MIN_CONV_TILES = 32         # tile counts below 256 run split-K (fp32 slabs in the shared workspace); tiny problems stay on MIOpen
 _SPLITK_WS_BYTES = 64 << 20
-_WT_CACHE_MAX = 256
+_WT_CACHE_MAX = 512
 
 
 class _WeightCache:
@@ -335,10 +335,21 @@ def _kv_rows(t):
     return t.stride(1)
 
 
+def qkv_fusable(x, wq):
+    return (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and not wq.requires_grad and wq.dtype == torch.float16 and
+            not (torch.is_grad_enabled() and x.requires_grad) and os.environ.get("GIP_FUSE_QKV", "1") != "0")
+
+
+def qkv_weight(wq, wk, wv):
+    """[3C, C] concatenation of a self-attention layer's frozen to_q / to_k / to_v weights (cached like the transposed
+    convolution weights: keyed by the q weight's storage and version, holding a reference to it)."""
+    return _wt_cache.get("qkv", wq, lambda t: torch.cat([t.detach(), wk.detach(), wv.detach()], dim=0).contiguous())
+
+
 def attention_supported(q, k, heads):
     D = q.shape[-1] // heads
     return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and D in (40, 64, 80, 160) and q.shape[1] % 32 == 0 and
-            k.shape[1] >= 1 and q.is_contiguous() and _kv_rows(k) is not None and
+            k.shape[1] >= 1 and _kv_rows(q) is not None and _kv_rows(k) is not None and
             not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
 
 
@@ -348,7 +359,10 @@ def attention(q, k, v, heads, k2=None, v2=None, weight2=1.0):
     k / v (and k2 / v2) may be column ranges of one wide projection matrix (same row stride for the pair)."""
     B, Nq, C = q.shape
     D = C // heads
-    o = torch.empty_like(q)
+    o = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    ld_q = _kv_rows(q)                     # q may be a column range of a fused q | k | v projection (row stride 3 C)
+    if ld_q is None:
+        q, ld_q = q.contiguous(), C
     null = ctypes.c_void_p(None)
     two = k2 is not None
 
@@ -362,12 +376,12 @@ def attention(q, k, v, heads, k2=None, v2=None, weight2=1.0):
     ld2 = C
     if two:
         k2, v2, ld2 = pair(k2, v2)
-    rc = _lib.nn_lib().gip_attention_fwd_strided_f16(_p(q), _p(k), _p(v), _p(o), B, heads, Nq, k.shape[1], D, float(D) ** -0.5,
+    rc = _lib.nn_lib().gip_attention_fwd_strided2_f16(_p(q), _p(k), _p(v), _p(o), B, heads, Nq, k.shape[1], D, float(D) ** -0.5,
                                                      _p(k2) if two else null, _p(v2) if two else null,
-                                                     k2.shape[1] if two else 0, float(weight2), ld, ld2,
+                                                     k2.shape[1] if two else 0, float(weight2), ld_q, ld, ld2,
                                                      ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
     if rc != 0:
-        raise RuntimeError("gip_attention_fwd_strided_f16 failed with status %d" % rc)
+        raise RuntimeError("gip_attention_fwd_strided2_f16 failed with status %d" % rc)
     return o
 
 

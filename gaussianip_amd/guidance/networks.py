@@ -207,6 +207,14 @@ class Attention(nn.Module):
                 if k_ip is None:
                     return self._out(fused.attention(q, k, v, self.heads), residual)
                 return self._out(fused.attention(q, k, v, self.heads, k_ip, v_ip, self.ip_scale), residual)
+        if ctx is x and not self.lora_rank and self.to_q.bias is None and fused.qkv_fusable(x, self.to_q.weight):
+            # self-attention with frozen, folded weights: ONE [3C, C] projection (the tokens are read once, not three times);
+            # q, k, v are column ranges of its output and the attention kernel reads them in place through row strides
+            C = x.shape[-1]
+            qkv = F.linear(x, fused.qkv_weight(self.to_q.weight, self.to_k.weight, self.to_v.weight))
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+            if fused.attention_supported(q, k, self.heads):
+                return self._out(fused.attention(q, k, v, self.heads), residual)
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if self.lora_rank:
             q, k, v = q + self.lora_q(x), k + self.lora_k(ctx), v + self.lora_v(ctx)

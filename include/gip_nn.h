@@ -150,6 +150,11 @@ int gip_attention_fwd_f16(const void* q, const void* k, const void* v, void* o, 
 int gip_attention_fwd_strided_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t Nq,
                                   int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2, int32_t Nkv2,
                                   float weight2, int32_t ld_kv, int32_t ld_kv2, void* stream);
+/* Same, with the query rows `ld_q` halves apart as well: q, k and v may all be column ranges of ONE [B, N, 3 H D] matrix — the
+ * fused to_q | to_k | to_v projection of a self-attention layer (one GEMM that reads the tokens once instead of three). */
+int gip_attention_fwd_strided2_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t Nq,
+                                   int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2, int32_t Nkv2,
+                                   float weight2, int32_t ld_q, int32_t ld_kv, int32_t ld_kv2, void* stream);
 #ifdef __cplusplus
 }
 #endif

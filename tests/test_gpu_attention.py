@@ -226,3 +226,21 @@ def test_graph_replay_of_the_vae_encoder_equals_the_eager_launches(monkeypatch):
     for (z0, d0), (z1, d1) in zip(eager, replayed):
         assert float((z0.float() - z1.float()).abs().max()) <= 5e-3 * max(1.0, float(z0.float().abs().max()))
         assert float((d0.float() - d1.float()).abs().max()) <= 5e-3 * max(1e-6, float(d0.float().abs().max()))
+
+
+def test_fused_qkv_projection_equals_three_projections(monkeypatch):
+    """Self-attention with frozen weights: one [3C, C] GEMM whose output the attention kernel reads in place through row
+    strides (q included: gip_attention_fwd_strided2_f16) against the three separate projections."""
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import networks as nw
+    att = nw.init_for_benchmark(nw.Attention(640, None, 8)).cuda().half().requires_grad_(False)
+    x = torch.randn(3, 1024, 640, device="cuda").half()
+    res = torch.randn(3, 1024, 640, device="cuda").half()
+    with torch.no_grad():
+        before = _lib.call_counts.get("gip_attention_fwd_strided2_f16", 0)
+        monkeypatch.setenv("GIP_FUSE_QKV", "1")
+        fused_out = att(x, None, res)
+        monkeypatch.setenv("GIP_FUSE_QKV", "0")
+        plain = att(x, None, res)
+    assert _lib.call_counts.get("gip_attention_fwd_strided2_f16", 0) - before == 2
+    assert float((fused_out.float() - plain.float()).abs().max()) <= 2e-3 * max(1.0, float(plain.float().abs().max()))
