@@ -322,6 +322,12 @@ def main():
                             "frac": round(c_sat * c["SQ_INSTS_VALU"] / (cycles * 1024), 4),
                             "frac_lone_wave": round(c_lone * c["SQ_INSTS_VALU"] / (cycles * 1024), 4),
                             "simd_cycles_per_instruction_achieved": round(cycles * 1024 / c["SQ_INSTS_VALU"], 3),
+                            # class mix (SQ_INSTS_VALU_* pass): transcendentals at their own measured 8.1 cycles, the rest at c_sat;
+                            # packed v_pk_* instructions are not separable by counter and cost 4.2 — so this is still a LOWER bound
+                            "frac_class_weighted": (round((c_sat * (c["SQ_INSTS_VALU"] - c["SQ_INSTS_VALU_TRANS_F32"]) +
+                                                           vr["v_exp_f32"]["simd_cycles_ge4_waves"] * c["SQ_INSTS_VALU_TRANS_F32"]) / (cycles * 1024), 4)
+                                                    if "SQ_INSTS_VALU_TRANS_F32" in c else None),
+                            "class_mix": ({k_[len("SQ_INSTS_VALU_"):]: int(v_) for k_, v_ in c.items() if k_.startswith("SQ_INSTS_VALU_")} or None),
                             "SQ_ACTIVE_INST_VALU_over_SQ_INSTS_VALU": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 3),
                             "launch_cycles": int(cycles), "source": pmc_note,
                             "formula": "c * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"}

@@ -1,0 +1,177 @@
+// conv_small.hip — the two 3x3 convolutions of the VAE encoder that the 128-channel implicit GEMM (conv3x3.hip) does not
+// fit: conv_in (3 -> 128 channels over the full-resolution image) and its data gradient (128 -> 3 channels, the gradient
+// that leaves the VAE towards the rasterizer).  See include/gip_nn.h (gip_conv3x3_c3_fwd_nhwc_f16 / _dgrad_).
+//
+// Both are bound by ONE pass over the 128-channel tensor (268 MB at 4 x 512^2): the library route took a MIOpen kernel, a
+// bias kernel and an NCHW -> NHWC copy forward (0.25 ms), and the 128-wide MFMA tile with 4 of its 128 output channels
+// used backward (0.32 ms).  Here:
+//   forward   16 x 16 pixel tile per workgroup, the 18 x 18 x 3 input patch in LDS, K = 27 (padded to 32) in ONE
+//             v_mfma_f32_16x16x32_f16 per 16 pixels x 16 channels, weights held in registers as the A operand, bias in the
+//             epilogue, 16-byte coalesced stores through an LDS transpose;
+//   dgrad     8 x 16 pixel tile, its 10 x 18 pixel halo of dy (46 KB) brought in ONCE by LDS-DMA (16-byte chunks XOR-
+//             swizzled on the source address so that the 16-pixel fragment reads are conflict-free) and reused by all nine
+//             taps; the rearranged weight [3][9][128] sits in LDS; 36 K steps of 32 per 16 pixels; 6-byte stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gip_nn.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define CS_OOB 0xFFFF0000u
+#define CS_RSRC_FLAGS 0x00020000
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: x [N, H, W, 3] -> out [N, H, W, 128] (+ bias)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w /* [128][3][3][3] */, const _Float16* __restrict__ bias,
+                   _Float16* __restrict__ out, int H, int W) {
+  constexpr int CO = 128, NI = CO / 16;
+  constexpr int IN_W = 18 * 3;                               // halves per patch row
+  constexpr int ROWB = CO * 2 + 16;                          // padded output staging row
+  __shared__ _Float16 s_in[18 * IN_W + 8];
+  __shared__ __attribute__((aligned(16))) unsigned char s_out[4][16 * ROWB];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_x = W / 16;
+  const int n = blockIdx.y, tile = blockIdx.x, y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
+  // ---- the input patch (zeros outside the image)
+  for (int i = tid; i < 18 * IN_W; i += 256) {
+    const int hy = i / IN_W, r = i - hy * IN_W, hx = r / 3, c = r - hx * 3;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    s_in[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? x[(((size_t)n * H + iy) * W + ix) * 3 + c] : (_Float16)0.f;
+  }
+  // ---- weights as the MFMA A operand: lane (row = co % 16, kq) holds k = 8 kq .. 8 kq + 7 of w[co][k], k = (ky, kx, ci) < 27
+  const int frow = lane & 15, kq = lane >> 4;
+  f16x8 wa[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = 8 * kq + j;
+      wa[ni][j] = k < 27 ? w[(ni * 16 + frow) * 27 + k] : (_Float16)0.f;
+    }
+  }
+  // per-lane patch offsets of its eight k (relative to the patch's top-left element of the pixel)
+  int koff[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int k = 8 * kq + j;
+    koff[j] = k < 27 ? (k / 9) * IN_W + (k % 9) : -1;
+  }
+  f32x4 bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const f16x4 b = bias ? *(const f16x4*)(bias + ni * 16 + kq * 4) : (f16x4){0, 0, 0, 0};
+    bv[ni] = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+  }
+  __syncthreads();
+  unsigned char* so = s_out[wave];
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    const int ty = wave * 4 + i;
+    f16x8 pb;
+    const int base = ty * IN_W + frow * 3;
+#pragma unroll
+    for (int j = 0; j < 8; j++) pb[j] = koff[j] >= 0 ? s_in[base + koff[j]] : (_Float16)0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], pb, bv[ni], 0, 0, 0);
+      f16x4 o;
+      o[0] = (_Float16)acc[0]; o[1] = (_Float16)acc[1]; o[2] = (_Float16)acc[2]; o[3] = (_Float16)acc[3];
+      *(f16x4*)(so + frow * ROWB + (ni * 16 + kq * 4) * 2) = o;
+    }
+    // the wave's own 16 pixels x 128 channels: 16-byte chunks, 16 lanes per pixel row (only this wave touches `so`)
+    _Float16* orow = out + (((size_t)n * H + y0 + ty) * W + x0) * CO;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int px = q * 4 + (lane >> 4), ch = lane & 15;
+      *(uint4*)(orow + (size_t)px * CO + ch * 8) = *(const uint4*)(so + px * ROWB + ch * 16);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// data gradient: dy [N, H, W, 128] -> dx [N, H, W, 3];  wt [3][9][128] = w[co][2 - ty][2 - tx][c] rearranged by the host
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv_c3_dgrad_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ wt, _Float16* __restrict__ dx, int N, int H, int W) {
+  constexpr int C = 128;
+  constexpr int HALO_W = 18, HALO_H = 10, HALO = HALO_W * HALO_H;          // 180 pixels x 256 bytes
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [HALO][256] | weights [3][9 * 128] halves
+  unsigned char* s_halo = smem;
+  _Float16* s_w = (_Float16*)(smem + HALO * 256);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_x = W / 16;
+  const int n = blockIdx.y, tile = blockIdx.x, y0 = (tile / tiles_x) * 8, x0 = (tile % tiles_x) * 16;
+  // ---- halo of dy by LDS-DMA: one instruction = 4 pixels (64 lanes x 16 bytes); chunk c of pixel hp lands at chunk c ^ (hp & 15)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)N * H * W * C * 2u), CS_RSRC_FLAGS);
+  for (int i = wave; i < HALO / 4; i += 4) {
+    const int hp = i * 4 + (lane >> 4), pchunk = lane & 15, lchunk = pchunk ^ (hp & 15);
+    const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const unsigned off = ok ? (unsigned)((((unsigned)n * H + iy) * W + ix) * C + lchunk * 8) * 2u : CS_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(s_halo + i * 1024), 16, off, 0, 0, 0);
+  }
+  for (int i = tid; i < 3 * 9 * C / 8; i += 256) ((uint4*)s_w)[i] = ((const uint4*)wt)[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int frow = lane & 15, kq = lane >> 4;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+  for (int t = 0; t < 9; t++) {
+    const int ty = t / 3, tx = t - ty * 3;
+    int hp[2], sw[2];
+#pragma unroll
+    for (int cs = 0; cs < 2; cs++) {
+      hp[cs] = (wave * 2 + cs + ty) * HALO_W + frow + tx;
+      sw[cs] = hp[cs] & 15;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) {
+      f16x8 a = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (frow < 3) a = *(const f16x8*)(s_w + (frow * 9 + t) * C + cb * 32 + kq * 8);
+#pragma unroll
+      for (int cs = 0; cs < 2; cs++) {
+        const f16x8 b = *(const f16x8*)(s_halo + hp[cs] * 256 + (((cb * 4 + kq) ^ sw[cs]) << 4));
+        acc[cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[cs], 0, 0, 0);
+      }
+    }
+  }
+  // lanes 0-15 hold output channels 0..3 (3 used) of pixel frow
+  if (kq == 0) {
+#pragma unroll
+    for (int cs = 0; cs < 2; cs++) {
+      _Float16* o = dx + (((size_t)n * H + y0 + wave * 2 + cs) * W + x0 + frow) * 3;
+      o[0] = (_Float16)acc[cs][0]; o[1] = (_Float16)acc[cs][1]; o[2] = (_Float16)acc[cs][2];
+    }
+  }
+}
+
+extern "C" int gip_conv3x3_c3_fwd_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t H, int32_t W,
+                                           int32_t Cout, void* stream) {
+  if (!x || !w || !out || N < 1 || H < 16 || W < 16 || (H & 15) || (W & 15) || Cout != 128) return 1;
+  if ((long long)N * H * W * Cout * 2 >= (1ll << 32)) return 1;
+  hipLaunchKernelGGL(conv_c3_fwd_kernel, dim3((H / 16) * (W / 16), N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
+                     (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, H, W);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_conv3x3_c3_dgrad_nhwc_f16(const void* dy, const void* wt, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                             void* stream) {
+  if (!dy || !wt || !dx || N < 1 || H < 8 || W < 16 || (H & 7) || (W & 15) || C != 128) return 1;
+  if ((long long)N * H * W * C * 2 >= (1ll << 31)) return 1;          // buffer resource: 32-bit byte offsets
+  const size_t lds = 180 * 256 + 3 * 9 * 128 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_c3_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_c3_dgrad_kernel, dim3((H / 8) * (W / 16), N), dim3(256), lds, (hipStream_t)stream, (const _Float16*)dy,
+                     (const _Float16*)wt, (_Float16*)dx, N, H, W);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

@@ -637,26 +637,55 @@ def downsample_asym(x, w, bias):
     return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
 
 
+def _c3_kernels_apply(x, w):
+    """conv_in of the VAE encoder on its dedicated kernels (csrc/conv_small.hip): 3 input channels, 128 output channels, NHWC."""
+    return (x.shape[1] == 3 and w.shape[0] == 128 and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0 and
+            x.is_contiguous(memory_format=torch.channels_last) and w.is_contiguous(memory_format=torch.channels_last) and
+            x.numel() // 3 * 128 * 2 < (1 << 31) and os.environ.get("GIP_CONV_C3", "1") != "0")
+
+
 class _ConvFewInputChannels(torch.autograd.Function):
-    """3x3 / pad 1 convolution whose INPUT has very few channels (the VAE's conv_in: 3 -> 128).  Forward stays on
-    MIOpen; the data gradient (128 -> 3 channels over the full-resolution image, the gradient that flows back into the
-    rasterizer) is the MFMA convolution with the flipped-transposed weight zero-padded to 4 output channels — the
-    library's backward-data kernel for this shape runs at ~5 GFLOP/s-per-CU rates (1.4 ms for 7 GFLOP)."""
+    """3x3 / pad 1 convolution whose INPUT has very few channels (the VAE's conv_in: 3 -> 128) and its data gradient
+    (128 -> 3 channels over the full-resolution image, the gradient that flows back into the rasterizer).  Both are one
+    pass over the 128-channel tensor on the dedicated kernels of csrc/conv_small.hip (forward: the library route was a
+    MIOpen kernel + a bias kernel + an NCHW -> NHWC copy, 0.25 ms; backward: the 128-wide MFMA tile with 4 of its 128
+    output channels used, 0.32 ms; the library's backward-data kernel for this shape took 1.4 ms).  Shapes the kernels do
+    not take fall back to those routes."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(w)
+        ctx.c3 = _c3_kernels_apply(x, w)
+        if ctx.c3:
+            N, _, H, W = x.shape
+            out = torch.empty((N, 128, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            rc = _lib.nn_lib().gip_conv3x3_c3_fwd_nhwc_f16(_p(x), _p(w), ctypes.c_void_p(None) if bias is None else _p(bias), _p(out),
+                                                           N, H, W, 128, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("gip_conv3x3_c3_fwd_nhwc_f16 failed with status %d" % rc)
+            return out
         return F.conv2d(x, w, bias, padding=1)
 
     @staticmethod
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if ctx.c3:
+            # wt[c][3 ty + tx][co] = w[co][2 - ty][2 - tx][c]
+            wt = _wt_cache.get("c3t", w, lambda t: t.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+            N, _, H, W = dy.shape
+            dx = torch.empty((N, 3, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+            rc = _lib.nn_lib().gip_conv3x3_c3_dgrad_nhwc_f16(_p(dy), _p(wt), _p(dx), N, H, W, 128,
+                                                             ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("gip_conv3x3_c3_dgrad_nhwc_f16 failed with status %d" % rc)
+            return dx, None, None
+
         def make(t):
             wt4 = torch.zeros((4, t.shape[0], 3, 3), dtype=t.dtype, device=t.device)
             wt4[:t.shape[1]] = t.detach().flip(2, 3).transpose(0, 1)
             return wt4.contiguous(memory_format=torch.channels_last)
         wt = _wt_cache.get("few", w, make)
-        dy = dy.contiguous(memory_format=torch.channels_last)
         return _conv_call(dy, wt, 4)[:, :w.shape[1]], None, None
 
 

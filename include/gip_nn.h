@@ -118,6 +118,17 @@ int gip_conv3x3_gnbwd_nhwc_f16(const void* dy_in, const void* w, void* out, int3
 int gip_linear_stats_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                          int32_t K, int32_t Nout, float* chan_stats, void* stream);
 
+/* The VAE encoder's conv_in and its data gradient (csrc/conv_small.hip) — 3x3 / stride 1 / pad 1 between 3 and 128 channels,
+ * both bound by one pass over the 128-channel tensor:
+ *   forward  x [N,H,W,3] half, w [128,3,3,3] half (channels_last memory of the torch weight), bias [128] or NULL -> out [N,H,W,128];
+ *            H % 16 == 0, W % 16 == 0.  Replaces MIOpen's kernel + bias kernel + NCHW -> NHWC copy (AutoencoderKL.encoder.conv_in).
+ *   dgrad    dy [N,H,W,128] half, wt [3][9][128] half with wt[c][3 ty + tx][co] = w[co][2 - ty][2 - tx][c] -> dx [N,H,W,3]
+ *            (the gradient that leaves the VAE towards the bilinear resize and the rasterizer); H % 8 == 0, W % 16 == 0. */
+int gip_conv3x3_c3_fwd_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t H, int32_t W,
+                                int32_t Cout, void* stream);
+int gip_conv3x3_c3_dgrad_nhwc_f16(const void* dy, const void* wt, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                  void* stream);
+
 /* The same kernel at stride 2 (diffusers Downsample2D): out [N, Hin/2, Win/2, Cout]; pad_top / pad_left = 1 with the
  * symmetric padding of the U-Net / ControlNet (padding=1), 0 for the VAE's F.pad(x, (0, 1, 0, 1)) + padding=0 form (the
  * missing bottom / right rows are the usual out-of-range zeros).  Hin, Win even. */

@@ -231,3 +231,30 @@ def test_resblock_as_one_autograd_node(cin, cout, sums, monkeypatch):
         assert float((got_y.float() - yr).abs().max()) < 6e-3 * max(1.0, float(yr.abs().max()))
         assert float((got_dx.float() - dxr).abs().max()) < 8e-3 * max(1.0, float(dxr.abs().max()))
     assert float((dx1.float() - dx0.float()).abs().max()) < 4e-3 * max(1.0, float(dx0.float().abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 48), (4, 512, 512), (1, 40, 56)])
+def test_vae_conv_in_and_its_data_gradient(shape):
+    """conv_in of the VAE encoder (3 -> 128) on csrc/conv_small.hip, forward (bias, borders) and dL/dx (the gradient that
+    leaves the VAE), against fp32 PyTorch on the same fp16 operands; (1, 40, 56) is not a multiple of the 16-pixel tile and
+    takes the library / 128-wide routes."""
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    N, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(H)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, 3, H, W, device="cuda", generator=g).half().contiguous(**cl).requires_grad_(True)
+    w = (torch.randn(128, 3, 3, 3, device="cuda", generator=g) / 5.0).half().contiguous(**cl)
+    b = torch.randn(128, device="cuda", generator=g).half()
+    dy = torch.randn(N, 128, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    before = (_lib.call_counts.get("gip_conv3x3_c3_fwd_nhwc_f16", 0), _lib.call_counts.get("gip_conv3x3_c3_dgrad_nhwc_f16", 0))
+    y = fused.conv3x3_few_inputs(x, w, b)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    ran = (_lib.call_counts.get("gip_conv3x3_c3_fwd_nhwc_f16", 0) - before[0], _lib.call_counts.get("gip_conv3x3_c3_dgrad_nhwc_f16", 0) - before[1])
+    assert ran == ((1, 1) if H % 16 == 0 and W % 16 == 0 else (0, 0))
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.conv2d(xr, w.float(), b.float(), padding=1)
+    (dxr,) = torch.autograd.grad(yr, xr, dy.float())
+    assert y.shape == yr.shape and y.is_contiguous(**cl)
+    assert float((y.float() - yr).abs().max()) <= 1.5e-3 * float(yr.abs().max())
+    assert float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())

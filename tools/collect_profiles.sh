@@ -8,11 +8,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $G
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 --profile-iters 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 --profile-iters 1 > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 --profile-iters 1 > $OUT/pmc_sq.log 2>&1
+# vector-instruction class mix of the render kernels (what roofline_valu prices: transcendental 8.1 cycles, everything else 2.24)
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --output-format csv -d $OUT/pmc_mix -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ahds --no-trained --no-exact --repeats 1 --profile-iters 1 > $OUT/pmc_mix.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections, os
 out = "$OUT"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix"):
     for f in glob.glob(out + "/" + d + "/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
