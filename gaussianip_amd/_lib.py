@@ -136,6 +136,11 @@ def knn_lib():
 _model = None
 
 
+class GipAdamGroup(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("step", ctypes.c_void_p), ("n", ctypes.c_int64), ("lr", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
 class GipGatherTensor(ctypes.Structure):
     _fields_ = [("old_rows", ctypes.c_void_p), ("new_rows", ctypes.c_void_p), ("dst", ctypes.c_void_p),
                 ("row_bytes", ctypes.c_int32), ("reserved", ctypes.c_int32)]
@@ -150,6 +155,8 @@ def model_lib():
         lib = ctypes.CDLL(path)
         lib.gip_gather_rows.restype = ctypes.c_int
         lib.gip_gather_rows.argtypes = [ctypes.POINTER(GipGatherTensor), ctypes.c_int32, _vp, ctypes.c_int64, ctypes.c_int64, _vp]
+        lib.gip_adam_step.restype = ctypes.c_int
+        lib.gip_adam_step.argtypes = [ctypes.POINTER(GipAdamGroup), ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]
         lib.gip_openpose_draw.restype = ctypes.c_int
         lib.gip_openpose_draw.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]
         lib.gip_openpose_workspace_bytes.restype = ctypes.c_size_t

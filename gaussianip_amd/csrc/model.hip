@@ -186,3 +186,78 @@ extern "C" int gip_max_bucket(const int32_t* radii, int32_t V, int64_t P, const 
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gip_adam_step: all parameter groups in one launch (include/gip_model.h)
+// ---------------------------------------------------------------------------------------------------------------------
+struct AdamArgs {
+  GipAdamGroup g[GIP_ADAM_MAX_GROUPS];
+  long long start[GIP_ADAM_MAX_GROUPS + 1];     // element offsets of the groups in the flat index space
+  int n_groups;
+  float beta1, beta2, eps;
+  float w1, w2;                                  // 1 - beta1, 1 - beta2 rounded from DOUBLE like torch's host-side constants
+  double beta1d, beta2d;
+};
+
+__global__ void __launch_bounds__(256)
+gip_adam_kernel(AdamArgs a, const float* __restrict__ found_inf) {
+  if (found_inf && *found_inf != 0.f) return;                         // GradScaler: skipped step, nothing moves
+  // bias corrections per group, in double like torch's `1 - beta ** step` on Python floats; one thread per group
+  __shared__ float s_bc1[GIP_ADAM_MAX_GROUPS], s_bc2s[GIP_ADAM_MAX_GROUPS];
+  if (threadIdx.x < a.n_groups) {
+    const double t = (double)*a.g[threadIdx.x].step + 1.0;            // every block reads the OLD count; gip_adam_count_kernel stores the new one
+    s_bc1[threadIdx.x] = (float)(1.0 - pow(a.beta1d, t));
+    s_bc2s[threadIdx.x] = (float)sqrt(1.0 - pow(a.beta2d, t));
+  }
+  __syncthreads();
+  const long long total = a.start[a.n_groups];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < GIP_ADAM_MAX_GROUPS; j++) k += (j < a.n_groups && i >= a.start[j]) ? 1 : 0;
+    const GipAdamGroup& G = a.g[k];
+    const long long e = i - a.start[k];
+    const float g = ((const float*)G.grad)[e];
+    float m = ((float*)G.exp_avg)[e], v = ((float*)G.exp_avg_sq)[e];
+    m = m + a.w1 * (g - m);                                           // exp_avg.lerp_(grad, 1 - beta1)
+    v = a.beta2 * v + a.w2 * g * g;                                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(v) / s_bc2s[k] + a.eps;
+    float* p = (float*)G.param;
+    p[e] = p[e] - (G.lr / s_bc1[k]) * (m / denom);                    // param.addcdiv_(exp_avg, denom, value = -step_size)
+    ((float*)G.exp_avg)[e] = m;
+    ((float*)G.exp_avg_sq)[e] = v;
+  }
+}
+
+// the step counters are advanced by a second, one-thread-per-group launch AFTER the update kernel has read them (same stream)
+__global__ void gip_adam_count_kernel(AdamArgs a, const float* __restrict__ found_inf) {
+  if (found_inf && *found_inf != 0.f) return;
+  if (threadIdx.x < a.n_groups) *a.g[threadIdx.x].step += 1.f;
+}
+
+extern "C" int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, const float* found_inf,
+                             void* stream) {
+  if (!groups || n_groups < 1 || n_groups > GIP_ADAM_MAX_GROUPS) return 1;
+  AdamArgs a;
+  a.n_groups = n_groups; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.beta1d = (double)beta1; a.beta2d = (double)beta2;
+  // the caller's betas arrive as floats; 0.9f / 0.999f are not 0.9 / 0.999: recover the decimal the float was rounded from
+  // (6 significant digits) so that 1 - beta matches the double arithmetic of torch's Python-side constants
+  a.beta1d = (double)((long long)(a.beta1d * 1e6 + 0.5)) / 1e6; a.beta2d = (double)((long long)(a.beta2d * 1e6 + 0.5)) / 1e6;
+  a.w1 = (float)(1.0 - a.beta1d); a.w2 = (float)(1.0 - a.beta2d);
+  long long off = 0;
+  for (int i = 0; i < n_groups; i++) {
+    if (!groups[i].param || !groups[i].grad || !groups[i].exp_avg || !groups[i].exp_avg_sq || !groups[i].step || groups[i].n < 0) return 1;
+    a.g[i] = groups[i];
+    a.start[i] = off;
+    off += groups[i].n;
+  }
+  for (int i = n_groups; i <= GIP_ADAM_MAX_GROUPS; i++) a.start[i] = off;
+  if (off == 0) return 0;
+  long long blocks = (off + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, found_inf);
+  hipLaunchKernelGGL(gip_adam_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, found_inf);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

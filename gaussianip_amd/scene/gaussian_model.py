@@ -115,7 +115,7 @@ class GaussianModel:
         rots = torch.zeros((n, 4), device=dev)
         rots[:, 0] = 1
         opac = inverse_sigmoid(0.1 * torch.ones((n, 1), dtype=torch.float32, device=dev))
-        self._xyz = nn.Parameter(pts.requires_grad_(True))
+        self._xyz = nn.Parameter(pts.contiguous().requires_grad_(True))      # (a point array that arrives transposed keeps its strides otherwise)
         self._features_dc = nn.Parameter(feats[:, :, 0:1].transpose(1, 2).contiguous().requires_grad_(True))
         self._features_rest = nn.Parameter(feats[:, :, 1:].transpose(1, 2).contiguous().requires_grad_(True))
         self._scaling = nn.Parameter(scales.requires_grad_(True))
@@ -124,9 +124,10 @@ class GaussianModel:
         self.max_radii2D = torch.zeros((n,), device=dev)
 
     def training_setup(self, training_args, fused: bool = False):
-        """`fused=True` (GPU only): torch's fused Adam — the same update rule in one multi-tensor kernel, and the form that
-        lets a GradScaler skip / unscale on the device: `scaler.step()` then issues no host synchronisation (the
-        reference's plain Adam under `precision: 16-mixed` pays one `.item()` per step)."""
+        """`fused=True` (GPU only): the same update rule as torch.optim.Adam with all six groups in ONE launch
+        (scene/adam.py -> gip_adam_step; GIP_ADAM=torch selects torch's fused Adam, 18 launches), and the form that lets a
+        GradScaler skip on the device: `scaler.step()` then issues no host synchronisation (the reference's plain Adam
+        under `precision: 16-mixed` pays one `.item()` per step)."""
         n, dev = self.get_xyz.shape[0], self.get_xyz.device
         self.percent_dense = training_args.percent_dense
         self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
@@ -135,7 +136,11 @@ class GaussianModel:
                "f_rest": training_args.feature_lr / 20.0, "opacity": training_args.opacity_lr,
                "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
         self.params_list = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in _GROUPS]
-        self.optimizer = torch.optim.Adam(self.params_list, lr=0.0, eps=1e-15, **({"fused": True} if fused else {}))
+        if fused and dev.type == "cuda" and os.environ.get("GIP_ADAM", "gip") == "gip":
+            from .adam import GipAdam          # the same update as torch's fused Adam, all six groups in ONE launch
+            self.optimizer = GipAdam(self.params_list, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(self.params_list, lr=0.0, eps=1e-15, **({"fused": True} if fused else {}))
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=training_args.position_lr_init * self.spatial_lr_scale,
             lr_final=training_args.position_lr_final * self.spatial_lr_scale,

@@ -50,6 +50,29 @@ int gip_unpack_bucket(void* const* segs, const int64_t* counts, int32_t n_segs, 
  *   out[p] = max_v radii[v, p]  (p < P, int32),   out[P] = bit pattern of max(depth[0 .. n_depth))  (float32 >= 0:
  *   non-negative IEEE floats order like their bit patterns, so an int32 all_reduce(max) of the whole bucket is exact). */
 int gip_max_bucket(const int32_t* radii, int32_t V, int64_t P, const float* depth, int64_t n_depth, int32_t* out, void* stream);
+
+/* One Adam step for ALL parameter groups of the Gaussian model in ONE launch (torch.optim.Adam, no weight decay, no amsgrad;
+ * gaussiansplatting/scene/gaussian_model.py:145-155 builds six single-tensor groups with their own learning rates, eps 1e-15).
+ * torch's fused Adam launches three multi-tensor kernels per group (18 launches, 0.29 ms of a 39 ms step for 5.6 MB of state).
+ *   step_t += 1;  m = m + (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^t) * (m / (sqrt(v) / sqrt(1 - beta2^t) + eps))        (torch.optim.Adam's operation order; the bias
+ *   corrections and 1 - beta in double arithmetic like torch's Python-side constants)
+ * `step` of every group is a device float scalar (torch's own state["step"] of a fused / capturable Adam) and is incremented by
+ * the kernel.  found_inf (device float, may be NULL): a GradScaler's verdict — when non-zero nothing is written (the skipped
+ * step of torch.amp; the gradients were unscaled before).  `groups` is a HOST array (at most GIP_ADAM_MAX_GROUPS). */
+#define GIP_ADAM_MAX_GROUPS 8
+typedef struct {
+  void* param;        /* [n] float32 device */
+  const void* grad;   /* [n] float32 device */
+  void* exp_avg;      /* [n] float32 device */
+  void* exp_avg_sq;   /* [n] float32 device */
+  float* step;        /* device scalar */
+  int64_t n;
+  float lr;
+  int32_t reserved;
+} GipAdamGroup;
+int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, const float* found_inf,
+                  void* stream);
 #ifdef __cplusplus
 }
 #endif

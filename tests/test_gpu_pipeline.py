@@ -408,3 +408,47 @@ def test_the_binding_printed_in_integration_md_works():
                                                  scales=t["scales"], rotations=t["rotations"])
     assert torch.equal(color, c2) and torch.equal(radii, r2) and torch.equal(depth, d2) and torch.equal(alpha, a2)
     assert int(state[:64].view(torch.int32)[0]) == _lib.raster_lib().gip_abi_version()
+
+
+def test_single_launch_adam_matches_torch_adam():
+    """scene/adam.py::GipAdam (gip_adam_step: all parameter groups in one launch) against torch.optim.Adam on the same
+    gradients: parameters, both moments and the step counts after six steps with per-group learning rates, a learning-rate
+    change in between (update_learning_rate) and one GradScaler-skipped step (found_inf)."""
+    from gaussianip_amd.scene.adam import GipAdam
+    g = torch.Generator(device="cuda").manual_seed(0)
+    shapes, lrs = [(5000, 3), (5000, 1, 3), (5000, 0, 3), (5000, 1), (5000, 4)], [1.6e-4, 0.0125, 6e-4, 0.01, 0.001]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device="cuda", generator=g)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    mk = lambda ps: [{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(ps, lrs))]      # noqa: E731
+    ref, ours = torch.optim.Adam(mk(ref_p), lr=0.0, eps=1e-15), GipAdam(mk(our_p), lr=0.0, eps=1e-15)
+    for it in range(6):
+        grads = [torch.randn(s, device="cuda", generator=g) * 10.0 ** float(torch.randint(-6, 2, (1,))) for s in shapes]
+        for p, q, gr in zip(ref_p, our_p, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if it == 3:
+            ref.param_groups[0]["lr"] = ours.param_groups[0]["lr"] = 1.1e-4
+        if it == 4:           # a skipped step: torch.amp hands found_inf to an optimizer that supports it; torch's plain Adam simply is not called
+            ours.found_inf, ours.grad_scale = torch.ones(1, device="cuda"), None
+            ours.step()
+            del ours.found_inf, ours.grad_scale
+            continue
+        ref.step()
+        ours.step()
+    for p, q in zip(ref_p, our_p):
+        if p.numel() == 0:
+            continue
+        assert float((p - q).abs().max()) <= 2e-6 * float(p.abs().max()), (tuple(p.shape), float((p - q).abs().max()), float(p.abs().max()))
+        sr, so = ref.state[p], ours.state[q]
+        assert float(so["step"]) == float(sr["step"]) == 5.0
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert float((sr[key] - so[key]).abs().max()) <= 1e-6 * float(sr[key].abs().max()) + 1e-30
+    # and it is what GaussianModel.training_setup(fused=True) builds
+    from argparse import ArgumentParser
+    from gaussianip_amd.arguments import OptimizationParams
+    from gaussianip_amd.scene import GaussianModel
+    from gaussianip_amd.utils import BasicPointCloud
+    gm = GaussianModel(0)
+    pts = np.random.default_rng(0).normal(size=(500, 3)).astype(np.float32)
+    gm.create_from_pcd(BasicPointCloud(pts, np.full((500, 3), 0.5, np.float32), None), 4.0)
+    gm.training_setup(OptimizationParams(ArgumentParser()), fused=True)
+    assert isinstance(gm.optimizer, GipAdam) and [g_["name"] for g_ in gm.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
