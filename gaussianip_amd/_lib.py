@@ -220,6 +220,8 @@ def nn_lib():
         lib.gip_add_bias_residual.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp]
         lib.gip_geglu.restype = ctypes.c_int
         lib.gip_geglu.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp]
+        lib.gip_cat2_stats_f16.restype = ctypes.c_int
+        lib.gip_cat2_stats_f16.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp]
         lib.gip_layernorm_f16.restype = ctypes.c_int
         lib.gip_layernorm_f16.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, _vp]
         lib.gip_lpips_layer_blocks.restype = ctypes.c_int32

@@ -462,6 +462,78 @@ extern "C" int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* 
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// Skip-connection concatenation of the U-Net decoder: out[m] = [ a[m] | b[m] (+ b_add[m]) ]  ([M, Ca + Cb] half rows), with
+// the statistics of the GroupNorm that consumes it (ResnetBlock2D.norm1 over the concatenated channels) taken on the way:
+// chan_stats [M / 128][Ca + Cb][2] = per 128-row block, per channel (sum, sum of squares) of the half-rounded values
+// written — the same partials the convolution epilogue produces (csrc/conv3x3.hip), so gn_finalize_stats_kernel serves
+// both.  b_add is the ControlNet residual of that skip (`sample + residual` of diffusers, rounded to half before the
+// concatenation exactly as the separate add would).  One pass instead of add + cat + the GroupNorm's statistics pass.
+// A workgroup owns 128 rows x 64 channels (8 chunks of 8 halves x 32 row-lanes x 4 rows); Ca % 64 == 0 keeps a column
+// block inside one source.  Fixed summation order: deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cat2_stats_kernel(const half8* __restrict__ a, const half8* __restrict__ b, const half8* __restrict__ b_add,
+                  half8* __restrict__ out, float* __restrict__ chan_stats, long long M, int Ca, int Cb) {
+  __shared__ float part[32 * 64 * 2];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int Ct = Ca + Cb, col = blockIdx.y * 64 + cx * 8;
+  const long long m0 = (long long)blockIdx.x * 128;
+  const bool from_a = col < Ca;
+  float s8[8], q8[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { s8[j] = 0.f; q8[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const long long m = m0 + ry + 32 * i;
+    if (m >= M) break;
+    float v[8];
+    if (from_a) {
+      unpack8(a[(m * Ca + col) >> 3], v);
+    } else {
+      unpack8(b[(m * Cb + (col - Ca)) >> 3], v);
+      if (b_add) {
+        float r[8];
+        unpack8(b_add[(m * Cb + (col - Ca)) >> 3], r);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] += r[j];
+      }
+    }
+    const half8 h = pack8(v);
+    out[(m * Ct + col) >> 3] = h;
+    if (chan_stats) {
+      unpack8(h, v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { s8[j] += v[j]; q8[j] = fmaf(v[j], v[j], q8[j]); }
+    }
+  }
+  if (!chan_stats) return;                 // kernel argument: uniform
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    part[(ry * 64 + cx * 8 + j) * 2] = s8[j];
+    part[(ry * 64 + cx * 8 + j) * 2 + 1] = q8[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float S = 0.f, Q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r++) { S += part[(r * 64 + threadIdx.x) * 2]; Q += part[(r * 64 + threadIdx.x) * 2 + 1]; }
+    float* o = chan_stats + ((size_t)blockIdx.x * Ct + blockIdx.y * 64 + threadIdx.x) * 2;
+    o[0] = S; o[1] = Q;
+  }
+}
+
+extern "C" int gip_cat2_stats_f16(const void* a, const void* b, const void* b_add, void* out, float* chan_stats, int64_t M,
+                                  int32_t Ca, int32_t Cb, void* stream) {
+  if (!a || !b || !out || M < 1 || Ca < 64 || Cb < 64 || (Ca & 63) || (Cb & 63)) return 1;
+  if (chan_stats && (M & 127)) return 1;
+  const long long blocks = (M + 127) / 128;
+  if (blocks > 0x7fffffffll || M * (long long)(Ca + Cb) >= (1ll << 40)) return 1;
+  hipLaunchKernelGGL(cat2_stats_kernel, dim3((unsigned)blocks, (unsigned)((Ca + Cb) / 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const half8*)a, (const half8*)b, (const half8*)b_add, (half8*)out, chan_stats, (long long)M, Ca, Cb);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dimension of [M, C] half rows (BasicTransformerBlock.norm1/2/3): y = (x - mean) * rstd * w + b.
 // HBM-bound: each row is read once into registers and written once.  A row is owned by a 16-lane group (one DPP row), so
 // a wave covers 4 rows and every load instruction fetches 256 contiguous bytes per row; ITER = ceil(C / 128) half8 chunks

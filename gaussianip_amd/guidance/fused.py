@@ -167,6 +167,30 @@ def add_bias_residual(a, b, bias=None):
     return out if bias is None else out + bias.reshape(1, -1, 1, 1)
 
 
+def cat_skip(h, skip, residual=None):
+    """torch.cat([h, skip (+ residual)], dim=1) of a U-Net up-block layer in ONE pass that also takes the statistics of the
+    ResnetBlock2D.norm1 that consumes it (attached to the result, see producer_stats) — instead of an add kernel, a cat
+    kernel and the GroupNorm's own statistics read.  `skip + residual` is rounded to half before the concatenation, as the
+    separate add rounds it."""
+    if (fusable(h) and fusable(skip) and (residual is None or (fusable(residual) and residual.shape == skip.shape)) and
+            h.shape[0] == skip.shape[0] and h.shape[2:] == skip.shape[2:] and h.shape[1] % 64 == 0 and skip.shape[1] % 64 == 0 and
+            not (torch.is_grad_enabled() and (h.requires_grad or skip.requires_grad or (residual is not None and residual.requires_grad))) and
+            os.environ.get("GIP_CAT_SKIP", "1") != "0"):
+        N, Ca, H, W = h.shape
+        Cb = skip.shape[1]
+        out = torch.empty((N, Ca + Cb, H, W), dtype=h.dtype, device=h.device, memory_format=torch.channels_last)
+        want = (H * W) % 128 == 0 and (Ca + Cb) // 32 <= 256 and os.environ.get("GIP_GN_STATS", "1") != "0"
+        st = torch.empty((N * H * W // 128, Ca + Cb, 2), dtype=torch.float32, device=h.device) if want else None
+        null = ctypes.c_void_p(None)
+        rc = _lib.nn_lib().gip_cat2_stats_f16(_p(h), _p(skip), null if residual is None else _p(residual), _p(out),
+                                              null if st is None else _p(st), N * H * W, Ca, Cb,
+                                              ctypes.c_void_p(torch.cuda.current_stream(h.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_cat2_stats_f16 failed with status %d" % rc)
+        return attach_stats(out, st)
+    return torch.cat([h, skip if residual is None else skip + residual], dim=1)
+
+
 def geglu(x):
     """diffusers GEGLU on the projected tensor: value, gate = x.chunk(2, -1); value * gelu(gate)."""
     D = x.shape[-1] // 2

@@ -439,13 +439,14 @@ class UNet(_Encoder):
         h = self.mid(h, temb, ctx)
         if callable(down_residuals):          # the ControlNet ran on another stream beside the encoder: join here
             down_residuals, mid_residual = down_residuals()
+        residuals = [None] * len(skips) if down_residuals is None else list(down_residuals)
         if down_residuals is not None:
-            skips = [s + r for s, r in zip(skips, down_residuals)]
             h = h + mid_residual
         k = 0
         for i in range(4):
             for _ in range(3):
-                h = self.up_res[k](torch.cat([h, skips.pop()], dim=1), temb)
+                # skip + ControlNet residual, the concatenation and norm1's statistics: one pass (fused.cat_skip)
+                h = self.up_res[k](fused.cat_skip(h, skips.pop(), residuals.pop()), temb)
                 if i > 0:
                     h = self.up_attn[k](h, ctx)
                 k += 1

@@ -64,6 +64,16 @@ int gip_gn_silu_forward_stats(const void* x, const void* gamma, const void* beta
                               int32_t blocks_per_sample, void* stream);
 int gip_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t M, int32_t C, void* stream);
 int gip_geglu(const void* in, void* out, int64_t M, int32_t D, void* stream);
+/* Skip-connection concatenation of the U-Net decoder with the ControlNet residual and the consuming GroupNorm's statistics
+ * in one pass: out[m] = [ a[m] | half(b[m] + b_add[m]) ], a [M, Ca], b / b_add [M, Cb], out [M, Ca + Cb] half rows (NHWC
+ * tensors seen as rows); b_add may be NULL.  chan_stats (may be NULL) [M / 128][Ca + Cb][2] float receives, per 128-row
+ * block and channel, the sum and the sum of squares of the values written — the partials gip_gn_silu_forward_stats takes
+ * (M % 128 == 0 then).  Ca % 64 == 0, Cb % 64 == 0.  Replaces, in the reference's U-Net (diffusers
+ * UNet2DConditionModel.forward as driven by ipa_guidance.py:338-356): `down_block_res_sample + controlnet residual`,
+ * `torch.cat([hidden_states, res_hidden_states], dim=1)` of every up-block layer, and the statistics read of the
+ * ResnetBlock2D.norm1 that follows. */
+int gip_cat2_stats_f16(const void* a, const void* b, const void* b_add, void* out, float* chan_stats, int64_t M, int32_t Ca,
+                       int32_t Cb, void* stream);
 
 /* LayerNorm over the last dimension: y[m, :] = (x[m, :] - mean_m) * rstd_m * weight + bias, x / y [M, C] half, weight /
  * bias [C] half, fp32 statistics (biased variance, like torch.nn.LayerNorm).  C % 8 == 0, C <= 2048.  Replaces the

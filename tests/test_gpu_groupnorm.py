@@ -232,3 +232,50 @@ def test_linear_epilogue_statistics_feed_the_next_groupnorm():
     gn = fused.GroupNormAct(32, C, act=True).cuda().half().requires_grad_(False)
     ref = F.silu(F.group_norm(x.float(), 32, gn.weight.float(), gn.bias.float(), 1e-5))
     assert float((gn(x).float() - ref).abs().max()) < 4e-3 * max(1.0, float(ref.abs().max()))
+
+
+# ---- the U-Net decoder's skip concatenation: skip + ControlNet residual, torch.cat and norm1's statistics in one pass
+# (gip_cat2_stats_f16) ----
+@pytest.mark.parametrize("shape", [(8, 1280, 1280, 16, 16), (8, 1280, 640, 32, 32), (8, 640, 320, 64, 64), (2, 320, 320, 64, 64),
+                                   (8, 1280, 1280, 8, 8), (1, 64, 128, 8, 16)])
+@pytest.mark.parametrize("with_residual", [True, False])
+def test_skip_concatenation_with_residual_and_statistics(shape, with_residual):
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    N, Ca, Cb, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(11)
+    mk = lambda c: torch.randn(N, c, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)  # noqa: E731
+    h, s, r = mk(Ca), mk(Cb), (mk(Cb) if with_residual else None)
+    before = _lib.call_counts.get("gip_cat2_stats_f16", 0)
+    with torch.no_grad():
+        out = fused.cat_skip(h, s, r)
+    assert _lib.call_counts.get("gip_cat2_stats_f16", 0) == before + 1, "the HIP concatenation did not run"
+    ref = torch.cat([h, s if r is None else s + r], dim=1)
+    assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, ref)        # bit-exact: same roundings
+    st = fused.producer_stats(out)
+    if (H * W) % 128:
+        assert st is None
+        return
+    assert st is not None and st.shape == (N * H * W // 128, Ca + Cb, 2)
+    rows = ref.permute(0, 2, 3, 1).reshape(N * H * W // 128, 128, Ca + Cb).double()
+    assert float((st[..., 0].double() - rows.sum(1)).abs().max()) < 1e-3
+    assert float((st[..., 1].double() - (rows * rows).sum(1)).abs().max()) < 1e-2
+    gn = fused.GroupNormAct(32, Ca + Cb, act=True).cuda().half().requires_grad_(False)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(Ca + Cb, generator=torch.Generator().manual_seed(1)) * 0.5 + 1)
+        gn.bias.copy_(torch.randn(Ca + Cb, generator=torch.Generator().manual_seed(2)) * 0.1)
+        calls = _lib.call_counts.get("gip_gn_silu_forward_stats", 0)
+        y = gn(out)
+        assert _lib.call_counts.get("gip_gn_silu_forward_stats", 0) == calls + 1, "the GroupNorm did not take the producer's statistics"
+        y2 = gn(ref)                                                                               # own statistics pass
+    want = F.silu(F.group_norm(ref.float(), 32, gn.weight.float(), gn.bias.float(), 1e-5))
+    tol = 4e-3 * max(1.0, float(want.abs().max()))
+    assert float((y.float() - want).abs().max()) < tol and float((y.float() - y2.float()).abs().max()) < tol
+
+
+def test_skip_concatenation_falls_back_for_shapes_the_kernel_does_not_take():
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(3)
+    h = torch.randn(2, 40, 8, 8, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    s = torch.randn(2, 24, 8, 8, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(fused.cat_skip(h, s, s), torch.cat([h, s + s], dim=1))
