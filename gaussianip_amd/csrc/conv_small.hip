@@ -27,10 +27,16 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: x [N, H, W, 3] -> out [N, H, W, 128] (+ bias)
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ _Float16 silu_h(_Float16 h) {      // torch's half SiLU: fp32 on the half-rounded value, one more rounding
+  const float v = (float)h;
+  return (_Float16)(v / (1.f + __expf(-v)));
+}
+
+template <int CO, bool ACT>
 __global__ void __launch_bounds__(256)
-conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w /* [128][3][3][3] */, const _Float16* __restrict__ bias,
+conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w /* [CO][3][3][3] */, const _Float16* __restrict__ bias,
                    _Float16* __restrict__ out, int H, int W) {
-  constexpr int CO = 128, NI = CO / 16;
+  constexpr int NI = CO / 16;
   constexpr int IN_W = 18 * 3;                               // halves per patch row
   constexpr int ROWB = CO * 2 + 16;                          // padded output staging row
   __shared__ _Float16 s_in[18 * IN_W + 8];
@@ -82,16 +88,148 @@ conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ 
       f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], pb, bv[ni], 0, 0, 0);
       f16x4 o;
       o[0] = (_Float16)acc[0]; o[1] = (_Float16)acc[1]; o[2] = (_Float16)acc[2]; o[3] = (_Float16)acc[3];
+      if (ACT) { o[0] = silu_h(o[0]); o[1] = silu_h(o[1]); o[2] = silu_h(o[2]); o[3] = silu_h(o[3]); }
       *(f16x4*)(so + frow * ROWB + (ni * 16 + kq * 4) * 2) = o;
     }
-    // the wave's own 16 pixels x 128 channels: 16-byte chunks, 16 lanes per pixel row (only this wave touches `so`)
+    // the wave's own 16 pixels x CO channels: 16-byte chunks, CO / 8 lanes per pixel row (only this wave touches `so`)
     _Float16* orow = out + (((size_t)n * H + y0 + ty) * W + x0) * CO;
+    constexpr int CPP = CO / 8;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int px = q * 4 + (lane >> 4), ch = lane & 15;
+    for (int q = lane; q < 16 * CPP; q += 64) {
+      const int px = q / CPP, ch = q % CPP;
       *(uint4*)(orow + (size_t)px * CO + ch * 8) = *(const uint4*)(so + px * ROWB + ch * 16);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Few-channel 3x3 / pad 1 convolutions, stride 1 or 2, bias (+ SiLU) in the epilogue: the ControlNet's conditioning stem
+// (controlnet_cond_embedding: 16 -> 16, 16 -> 32 /2, 32 -> 32, 32 -> 96 /2, 96 -> 96, 96 -> 256 /2).  Too narrow for the
+// 128-wide implicit GEMM; on the library each layer was a MIOpen kernel + a bias kernel + a layout copy + a SiLU kernel.
+//   * a workgroup owns TR rows x 16 columns of output pixels; its input halo ((TR - 1) S + 3) x (15 S + 3) pixels x CIN
+//     channels is read ONCE into LDS (16-byte chunks, pixel stride CIN * 2 + 16 bytes: the 16-pixel fragment reads of a
+//     stride-1 layer hit 16 distinct bank groups) and reused by all nine taps and all output channels;
+//   * GEMM view per 16-pixel output row: [COUT x 9 CIN] x [9 CIN x 16]; K runs in steps of 32 = (tap, 8-channel chunk) x 4
+//     lane groups, zero weights past 9 CIN (CIN = 16: 4.5 steps); the WEIGHT is the MFMA A operand (rows = output
+//     channels) so that a lane ends up with 4 consecutive channels of one pixel = 8-byte stores;
+//   * weights come straight from global memory (L2-resident, <= 442 KB), one step ahead of the MFMAs that use them;
+//     waves split the output channels WN ways and the tile rows 4 / WN ways.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int STRIDE, int WN, int TR>
+__global__ void __launch_bounds__(256)
+conv_fewch_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w /* [COUT][3][3][CIN] */, const _Float16* __restrict__ bias,
+                  _Float16* __restrict__ out, int Hin, int Win, int Hout, int Wout, int act) {
+  constexpr int WM = 4 / WN, MI = TR / WM, NI = COUT / 16 / WN;
+  constexpr int HR = (TR - 1) * STRIDE + 3, HC = 15 * STRIDE + 3;
+  constexpr int PSB = CIN * 2 + 16, CPP = CIN / 8;                         // pixel stride (bytes), 16-byte chunks per pixel
+  constexpr int K = 9 * CIN, KS = (K + 31) / 32;
+  static_assert(TR % WM == 0 && (COUT / 16) % WN == 0 && CIN % 8 == 0, "tile split");
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_halo[];   // [HR * HC][PSB]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave % WN, wm = wave / WN;
+  const int tiles_x = Wout / 16;
+  const int n = blockIdx.y, tile = blockIdx.x, y0 = (tile / tiles_x) * TR, x0 = (tile % tiles_x) * 16;
+  const int iy0 = y0 * STRIDE - 1, ix0 = x0 * STRIDE - 1;
+  for (int i = tid; i < HR * HC * CPP; i += 256) {
+    const int hp = i / CPP, ch = i - hp * CPP;
+    const int hy = hp / HC, hx = hp - hy * HC;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win)
+      v = *(const uint4*)(x + (((size_t)n * Hin + iy) * Win + ix) * CIN + ch * 8);
+    *(uint4*)(s_halo + hp * PSB + ch * 16) = v;
+  }
+  const int frow = lane & 15, kq = lane >> 4;
+  const int n0 = wn * NI * 16;
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const f16x4 b = bias ? *(const f16x4*)(bias + n0 + ni * 16 + kq * 4) : (f16x4){0, 0, 0, 0};
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) acc[ni][mi] = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+  }
+  const _Float16* wl = w + (size_t)(n0 + frow) * K + kq * 8;               // this lane's weight row, its 8-wide K slot
+  f16x8 wa[NI], wnx[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) wa[ni] = (kq * 8 < K) ? *(const f16x8*)(wl + (size_t)ni * 16 * K) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  __syncthreads();
+#pragma unroll 3
+  for (int s = 0; s < KS; s++) {
+    const int kk = s * 32 + kq * 8;
+    if (s + 1 < KS) {
+      const bool okn = kk + 32 < K;
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+        wnx[ni] = okn ? *(const f16x8*)(wl + (size_t)ni * 16 * K + (s + 1) * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const int kc = kk < K ? kk : 0;                      // past the end: weights are zero, read any finite pixel data
+    const int tap = kc / CIN, c = kc - tap * CIN, ty = tap / 3, tx = tap - ty * 3;
+    const unsigned char* hb = s_halo + ((wm * MI * STRIDE + ty) * HC + frow * STRIDE + tx) * PSB + c * 2;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      const f16x8 pb = *(const f16x8*)(hb + mi * STRIDE * HC * PSB);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], pb, acc[ni][mi], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) wa[ni] = wnx[ni];
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    _Float16* o = out + (((size_t)n * Hout + y0 + wm * MI + mi) * Wout + x0 + frow) * COUT + n0 + kq * 4;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      const f32x4 a = acc[ni][mi];
+      f16x4 h;
+      h[0] = (_Float16)a[0]; h[1] = (_Float16)a[1]; h[2] = (_Float16)a[2]; h[3] = (_Float16)a[3];
+      if (act) { h[0] = silu_h(h[0]); h[1] = silu_h(h[1]); h[2] = silu_h(h[2]); h[3] = silu_h(h[3]); }
+      *(f16x4*)(o + ni * 16) = h;
+    }
+  }
+}
+
+template <int CIN, int COUT, int STRIDE, int WN, int TR>
+static int launch_fewch(const void* x, const void* w, const void* bias, void* out, int N, int Hin, int Win, int act, hipStream_t s) {
+  const int Hout = Hin / STRIDE, Wout = Win / STRIDE;
+  if ((Hin % STRIDE) || (Win % STRIDE) || (Hout % TR) || (Wout & 15)) return 1;
+  constexpr int HR = (TR - 1) * STRIDE + 3, HC = 15 * STRIDE + 3;
+  constexpr int lds = HR * HC * (CIN * 2 + 16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_fewch_kernel<CIN, COUT, STRIDE, WN, TR>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_fewch_kernel<CIN, COUT, STRIDE, WN, TR>), dim3((Hout / TR) * (Wout / 16), N), dim3(256), lds, s,
+                     (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, Hin, Win, Hout, Wout, act);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_conv3x3_fewch_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin, int32_t Win,
+                                          int32_t Cin, int32_t Cout, int32_t stride, int32_t act, void* stream) {
+  if (!x || !w || !out || N < 1 || Hin < 16 || Win < 16 || (stride != 1 && stride != 2)) return 1;
+  if ((long long)N * Hin * Win * (Cin > Cout ? Cin : Cout) * 2 >= (1ll << 40)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin == 3 && stride == 1 && (Cout == 16 || Cout == 128)) {
+    if ((Hin & 15) || (Win & 15)) return 1;
+    const dim3 grid((Hin / 16) * (Win / 16), N);
+    if (Cout == 16 && act)
+      hipLaunchKernelGGL((conv_c3_fwd_kernel<16, true>), grid, dim3(256), 0, s, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, Hin, Win);
+    else if (Cout == 16)
+      hipLaunchKernelGGL((conv_c3_fwd_kernel<16, false>), grid, dim3(256), 0, s, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, Hin, Win);
+    else if (act)
+      hipLaunchKernelGGL((conv_c3_fwd_kernel<128, true>), grid, dim3(256), 0, s, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, Hin, Win);
+    else
+      hipLaunchKernelGGL((conv_c3_fwd_kernel<128, false>), grid, dim3(256), 0, s, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, Hin, Win);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
+  if (Cin == 16 && Cout == 16 && stride == 1) return launch_fewch<16, 16, 1, 1, 8>(x, w, bias, out, N, Hin, Win, act, s);
+  if (Cin == 16 && Cout == 32 && stride == 2) return launch_fewch<16, 32, 2, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
+  if (Cin == 32 && Cout == 32 && stride == 1) return launch_fewch<32, 32, 1, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
+  if (Cin == 32 && Cout == 96 && stride == 2) return launch_fewch<32, 96, 2, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
+  if (Cin == 96 && Cout == 96 && stride == 1) return launch_fewch<96, 96, 1, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
+  if (Cin == 96 && Cout == 256 && stride == 2) return launch_fewch<96, 256, 2, 4, 4>(x, w, bias, out, N, Hin, Win, act, s);
+  return 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -156,7 +294,7 @@ extern "C" int gip_conv3x3_c3_fwd_nhwc_f16(const void* x, const void* w, const v
                                            int32_t Cout, void* stream) {
   if (!x || !w || !out || N < 1 || H < 16 || W < 16 || (H & 15) || (W & 15) || Cout != 128) return 1;
   if ((long long)N * H * W * Cout * 2 >= (1ll << 32)) return 1;
-  hipLaunchKernelGGL(conv_c3_fwd_kernel, dim3((H / 16) * (W / 16), N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
+  hipLaunchKernelGGL((conv_c3_fwd_kernel<128, false>), dim3((H / 16) * (W / 16), N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, H, W);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -713,6 +713,32 @@ class _ConvFewInputChannels(torch.autograd.Function):
         return _conv_call(dy, wt, 4)[:, :w.shape[1]], None, None
 
 
+# (Cin, Cout, stride) -> output rows per workgroup tile (the output height must be a multiple of it)
+_FEWCH_SHAPES = {(3, 16, 1): 16, (3, 128, 1): 16, (16, 16, 1): 8, (16, 32, 2): 8, (32, 32, 1): 8, (32, 96, 2): 8, (96, 96, 1): 8, (96, 256, 2): 4}
+
+
+def conv3x3_fewch(x, w, bias, stride=1, act=False):
+    """F.conv2d(x, w, bias, stride, padding=1) (+ F.silu) for the narrow layers of the ControlNet's conditioning stem on the
+    kernels of csrc/conv_small.hip (bias and SiLU in the epilogue: one launch instead of the library's convolution, bias,
+    layout-copy and activation kernels).  Frozen weights, no gradient path; other shapes take the library route."""
+    cin, cout = x.shape[1], w.shape[0]
+    Ho, Wo = x.shape[2] // stride, x.shape[3] // stride
+    if (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and (cin, cout, stride) in _FEWCH_SHAPES and
+            w.dtype == torch.float16 and tuple(w.shape[1:]) == (cin, 3, 3) and
+            x.is_contiguous(memory_format=torch.channels_last) and w.is_contiguous(memory_format=torch.channels_last) and
+            x.shape[2] % stride == 0 and x.shape[3] % stride == 0 and Wo % 16 == 0 and Ho % _FEWCH_SHAPES[(cin, cout, stride)] == 0 and
+            not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and os.environ.get("GIP_CONV_FEWCH", "1") != "0"):
+        out = torch.empty((x.shape[0], cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        rc = _lib.nn_lib().gip_conv3x3_fewch_nhwc_f16(_p(x), _p(w), ctypes.c_void_p(None) if bias is None else _p(bias), _p(out),
+                                                      x.shape[0], x.shape[2], x.shape[3], cin, cout, stride, int(bool(act)),
+                                                      ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_conv3x3_fewch_nhwc_f16 failed with status %d" % rc)
+        return out
+    y = F.conv2d(x, w, bias, stride=stride, padding=1)
+    return F.silu(y) if act else y
+
+
 def conv3x3_few_inputs(x, w, bias):
     if (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.requires_grad and torch.is_grad_enabled() and
             not w.requires_grad and w.shape[1] <= 4 and w.shape[0] % 64 == 0 and

@@ -484,7 +484,7 @@ class ControlNet(_Encoder):
         c = cond
         for i, conv in enumerate(self.cond_stem):
             if i < len(self.cond_stem) - 1:
-                c = F.silu(conv(c))
+                c = fused.conv3x3_fewch(c, conv.weight, conv.bias, conv.stride[0], act=True)     # bias + SiLU in the epilogue
             else:
                 c = conv3x3(c, conv.weight, conv.bias)       # 256 -> 320 at 1/8 resolution: the MFMA kernel's shape
         return c

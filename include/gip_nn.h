@@ -139,6 +139,16 @@ int gip_conv3x3_c3_fwd_nhwc_f16(const void* x, const void* w, const void* bias, 
 int gip_conv3x3_c3_dgrad_nhwc_f16(const void* dy, const void* wt, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                   void* stream);
 
+/* Few-channel 3x3 / pad 1 convolutions with bias and optional SiLU in the epilogue (csrc/conv_small.hip): the ControlNet's
+ * conditioning stem, diffusers ControlNetConditioningEmbedding (conv_in 3 -> 16, then 16 -> 16, 16 -> 32 /2, 32 -> 32,
+ * 32 -> 96 /2, 96 -> 96, 96 -> 256 /2, each followed by F.silu), which the reference runs inside self.controlnet(...)
+ * (ipa_guidance.py:338-346).  x [N,Hin,Win,Cin] half, w [Cout,3,3,Cin] half (channels_last memory of the torch weight),
+ * bias [Cout] or NULL -> out [N,Hin/stride,Win/stride,Cout]; act != 0: out = silu(half(conv + bias)) (torch's two
+ * roundings).  Supported (Cin, Cout, stride): (3, 16 | 128, 1), (16, 16, 1), (16, 32, 2), (32, 32, 1), (32, 96, 2),
+ * (96, 96, 1), (96, 256, 2); output width % 16 == 0, output height % 8 == 0 (% 16 for Cin = 3, % 4 for 96 -> 256); anything else returns 1. */
+int gip_conv3x3_fewch_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin, int32_t Win,
+                               int32_t Cin, int32_t Cout, int32_t stride, int32_t act, void* stream);
+
 /* The same kernel at stride 2 (diffusers Downsample2D): out [N, Hin/2, Win/2, Cout]; pad_top / pad_left = 1 with the
  * symmetric padding of the U-Net / ControlNet (padding=1), 0 for the VAE's F.pad(x, (0, 1, 0, 1)) + padding=0 form (the
  * missing bottom / right rows are the usual out-of-range zeros).  Hin, Win even. */

@@ -258,3 +258,50 @@ def test_vae_conv_in_and_its_data_gradient(shape):
     assert y.shape == yr.shape and y.is_contiguous(**cl)
     assert float((y.float() - yr).abs().max()) <= 1.5e-3 * float(yr.abs().max())
     assert float((dx.float() - dxr).abs().max()) <= 2e-3 * float(dxr.abs().max())
+
+
+# ---- the ControlNet's conditioning stem: few-channel 3x3 convolutions (stride 1 / 2) with bias + SiLU in the epilogue
+# (gip_conv3x3_fewch_nhwc_f16, csrc/conv_small.hip) ----
+@pytest.mark.parametrize("cfg", [(3, 16, 1, 64, 48), (3, 128, 1, 32, 32), (16, 16, 1, 64, 48), (16, 32, 2, 64, 96), (32, 32, 1, 24, 32),
+                                 (32, 96, 2, 48, 64), (96, 96, 1, 16, 48), (96, 256, 2, 24, 64)])
+@pytest.mark.parametrize("act", [True, False])
+def test_few_channel_convolutions_of_the_controlnet_stem(cfg, act):
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    cin, cout, stride, H, W = cfg
+    g = torch.Generator(device="cuda").manual_seed(cin * 1000 + cout)
+    x = torch.randn(3, cin, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (9 * cin) ** 0.5).half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, device="cuda", generator=g).half()
+    before = _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0)
+    with torch.no_grad():
+        out = fused.conv3x3_fewch(x, w, b, stride, act)
+    assert _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0) == before + 1, "the HIP kernel did not run"
+    assert out.shape == (3, cout, H // stride, W // stride) and out.is_contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.float(), w.float(), b.float(), stride=stride, padding=1)
+    if act:
+        ref = F.silu(ref.half().float())          # torch's own order: the convolution result is rounded to half first
+    scale = max(1.0, float(ref.abs().max()))
+    # tolerance: one (two with the activation) half roundings of an O(1) value + fp32 accumulation order
+    assert float((out.float() - ref).abs().max()) <= 2.5e-3 * scale
+    # borders: the first / last rows and columns see the zero padding
+    edge = torch.cat([(out.float() - ref)[:, :, 0].flatten(), (out.float() - ref)[:, :, -1].flatten(),
+                      (out.float() - ref)[:, :, :, 0].flatten(), (out.float() - ref)[:, :, :, -1].flatten()])
+    assert float(edge.abs().max()) <= 2.5e-3 * scale
+
+
+def test_controlnet_stem_runs_on_the_few_channel_kernels():
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    from gaussianip_amd.guidance.networks import ControlNet, init_for_benchmark
+    torch.manual_seed(0)
+    net = init_for_benchmark(ControlNet()).cuda().half().to(memory_format=torch.channels_last).requires_grad_(False)
+    cond = torch.rand(2, 3, 128, 128, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    before = _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0)
+    with torch.no_grad():
+        emb = net.embed_condition(cond)
+        assert _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0) - before == 7, "a stem layer took the library route"
+        with fused.disabled():
+            ref = net.embed_condition(cond)
+    assert emb.shape == (2, 320, 16, 16)
+    assert float((emb.float() - ref.float()).abs().max()) <= 4e-3 * max(1.0, float(ref.float().abs().max()))
