@@ -197,6 +197,8 @@ def nn_lib():
         lib.gip_gn_silu_backward_accum.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64,
                                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp,
                                                    ctypes.c_size_t, _vp]
+        lib.gip_conv3x3s2_dgrad_nhwc_f16.restype = ctypes.c_int
+        lib.gip_conv3x3s2_dgrad_nhwc_f16.argtypes = [_vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp]
         lib.gip_conv3x3_fewch_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_fewch_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 7 + [_vp]
         lib.gip_conv3x3_c3_fwd_nhwc_f16.restype = ctypes.c_int

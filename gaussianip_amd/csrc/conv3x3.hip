@@ -95,8 +95,11 @@ __global__ void __launch_bounds__(CV_THREADS, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom,
-               float* __restrict__ chan_stats, GnBwdArgs gnb) {
+               float* __restrict__ chan_stats, GnBwdArgs gnb, int tapsel) {
   // geom = stride | pad_top << 8 | pad_left << 16; H, W are the OUTPUT dims, Hin, Win the input dims (equal at stride 1)
+  // tapsel (TAPS = 9): bits 0-8 = the taps the K loop visits (0x1ff: all nine); bit 11 = scatter: output pixel (n, a, b) is
+  // written to row (n, 2 a + pi, 2 b + pj) of a [N, 2 H, 2 W, Cout] tensor, pi = bit 9, pj = bit 10 — one parity class of
+  // the DATA GRADIENT of a stride-2 convolution (gip_conv3x3s2_dgrad_nhwc_f16 below)
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int A_BYTES = CV_BM * 128;          // pixel tile: 128 rows x 64 halves
@@ -179,7 +182,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)Cout * (GEGLU ? 2u : 1u) * TAPS * Cin * 2u), CV_RSRC_FLAGS);
 
   const int cblocks = Cin / CV_BK;
-  const int KT_all = TAPS * cblocks;
+  const int KT_all = (TAPS == 9 ? __builtin_popcount(tapsel & 0x1ff) : TAPS) * cblocks;
   const int kt_begin = (int)((long long)split * KT_all / ksplit), kt_end = (int)((long long)(split + 1) * KT_all / ksplit);
   const int KT = kt_end - kt_begin;
 
@@ -227,9 +230,16 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     }
   };
 
-  int tap = kt_begin / cblocks, cb = kt_begin - (kt_begin / cblocks) * cblocks;     // K step the NEXT stage() call loads
+  // K step the NEXT stage() call loads: (tap, channel block); the taps run over the set bits of tapsel in ascending order
+  int taps_left = TAPS == 9 ? (tapsel & 0x1ff) : 1;
+  for (int i = 0; i < kt_begin / cblocks; i++) taps_left &= taps_left - 1;
+  int tap = TAPS == 9 ? __builtin_ctz(taps_left | 0x200) : 0, cb = kt_begin - (kt_begin / cblocks) * cblocks;
   auto advance = [&]() {
-    if (++cb == cblocks) { cb = 0; ++tap; }
+    if (++cb == cblocks) {
+      cb = 0;
+      taps_left &= taps_left - 1;
+      tap = TAPS == 9 ? __builtin_ctz(taps_left | 0x200) : 0;
+    }
   };
   // two LDS stages: the DMA of step t + 1 is in flight while the MFMAs of step t run; one wait + barrier per step.  (A
   // three-stage single-workgroup-per-CU variant and BK = 32 variants with 3 / 4 stages and counted vmcnt were measured
@@ -248,6 +258,12 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   }
 
   // ---- epilogue: lane holds out[pixel = lane & 15][co = (lane >> 4) * 4 + 0..3] of each 16x16 tile ----
+  const bool scatter = TAPS == 9 && ((tapsel >> 11) & 1);
+  auto out_row = [&](unsigned m) -> size_t {      // row of `out` that output pixel m is written to
+    if (!scatter) return (size_t)m;
+    const unsigned n = m / (unsigned)HW, rem = m - n * (unsigned)HW, a = rem / (unsigned)W, b = rem - a * (unsigned)W;
+    return ((size_t)n * (2u * H) + 2u * a + ((tapsel >> 9) & 1)) * (2u * W) + 2u * b + ((tapsel >> 10) & 1);
+  };
   auto add4 = [](f32x4& v, const _Float16* p) {
     const f16x4 b = *(const f16x4*)p;
     v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
@@ -315,7 +331,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
           }
-          *(f16x8*)(out + (size_t)m * Cout + co) = v;
+          *(f16x8*)(out + out_row(m) * Cout + co) = v;
           if (chan_stats) {
             if (gnb.x) {
               gnb_accumulate(gnb, gl, v, *(const f16x8*)(gnb.x + (size_t)m * Cout + co), s8, q8);
@@ -361,7 +377,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         f16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; j++) o[j] = (_Float16)(v[j] * (0.5f * g[j] * (1.f + erff(g[j] * 0.70710678118654752f))));
-        *(f16x4*)(out + m * Cout + co) = o;
+        *(f16x4*)(out + out_row(m) * Cout + co) = o;
       }
     } else {
 #pragma unroll
@@ -373,7 +389,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         if (residual) add4(v, residual + m * Cout + co);
         f16x4 o;
         o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
-        *(f16x4*)(out + m * Cout + co) = o;
+        *(f16x4*)(out + out_row(m) * Cout + co) = o;
       }
     }
   }
@@ -732,7 +748,8 @@ static int big_tile_width(long long M, int Cout) {
 template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
                   int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0, int Hin = 0, int Win = 0,
-                  int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr, const GnBwdArgs* gnb_in = nullptr) {
+                  int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr, const GnBwdArgs* gnb_in = nullptr,
+                  int tapsel = 0x1ff) {
   GnBwdArgs gnb = {};
   if (gnb_in) gnb = *gnb_in;
   if (Hin == 0) { Hin = H; Win = W; }
@@ -740,7 +757,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   if constexpr (!GEGLU) {
     if (!(Cout & 7)) {
       const int bw = big_tile_width(M, Cout);
-      if (bw == 256 && !(gnb.x && gnb.HW % CVB_BM))
+      if (bw == 256 && !(gnb.x && gnb.HW % CVB_BM) && tapsel == 0x1ff)
         return launch_big<256, TAPS>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, Hin, Win, geom, chan_stats, gnb);
     }
   }
@@ -759,8 +776,8 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   // fits ONE round of 2 workgroups per CU (240 tiles: 2 -> 480 workgroups; 3 -> 720 = 1.4 rounds measured 16 % slower;
   // 60 tiles: 8; tools/exp_conv5.py)
   int ksplit = 1;
-  const int tiles = m_tiles * n_tiles, KT = TAPS * (Cin / CV_BK);
-  if (!GEGLU && workspace && tiles < 256) {
+  const int tiles = m_tiles * n_tiles, KT = (TAPS == 9 ? __builtin_popcount(tapsel & 0x1ff) : TAPS) * (Cin / CV_BK);
+  if (!GEGLU && workspace && tiles < 256 && !((tapsel >> 11) & 1)) {
     static const int r2 = env_int("GIP_CONV_KSPLIT_R2", 0);
     ksplit = r2 ? (512 + tiles - 1) / tiles : 512 / tiles;
     if (ksplit > KT / 8) ksplit = KT / 8;
@@ -787,7 +804,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26);   // bits 26-28: timing ablations (WRONG results)
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
-                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats, gnb);
+                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats, gnb, tapsel);
   if (ksplit > 1) {
     const unsigned n4 = (unsigned)(M * Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
@@ -864,6 +881,31 @@ extern "C" int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* 
   const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
   return wide ? launch<160, 2, 9, false>(x, w, bias, nullptr, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes, Hin, Win, geom)
               : launch<128, 2, 9, false>(x, w, bias, nullptr, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes, Hin, Win, geom);
+}
+
+// Data gradient of the 3x3 / stride 2 convolution y[oy][ox] = sum x[2 oy + ky][2 ox + kx] w[ky][kx] (input zero beyond its
+// last row / column: the VAE's F.pad(x, (0, 1, 0, 1)) + padding = 0 form).  dx[2 a + pi][2 b + pj] only receives the taps
+// with ky = pi, kx = pj (mod 2): four independent small convolutions over dy's own grid — 4, 2, 2 and 1 taps — each a
+// launch of the implicit GEMM with a tap subset and the parity scatter in its epilogue.  Exactly the minimal FLOPs (the
+// zero-dilated form costs 4x) and no dilated copy of dy.  wt4 [4][Cout][3][3][Cin]: class c = 2 pi + pj holds, at tap (dy,
+// dx) (input offset dy - 1, dx - 1), w[co][ci][ky][kx] transposed, with ky = 2 for dy = 0 and ky = pi for dy = 1 (same in x).
+extern "C" int gip_conv3x3s2_dgrad_nhwc_f16(const void* dy, const void* wt4, void* dx, int32_t N, int32_t Ho, int32_t Wo,
+                                            int32_t Cin, int32_t Cout, void* stream) {
+  if (!dy || !wt4 || !dx || N < 1 || Ho < 1 || Wo < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 8 || (Cout & 7)) return 1;
+  if (!fits32((long long)N * Ho * Wo * 4, Cin, Cout, Cout, 9)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  static const int masks[4] = {0x01b /* taps (0,0) (0,1) (1,0) (1,1) */, 0x012 /* (0,1) (1,1) */, 0x018 /* (1,0) (1,1) */, 0x010 /* (1,1) */};
+  for (int c = 0; c < 4; c++) {
+    const int pi = c >> 1, pj = c & 1;
+    const int tapsel = masks[c] | (pi << 9) | (pj << 10) | (1 << 11);
+    const _Float16* w = (const _Float16*)wt4 + (size_t)c * Cout * 9 * Cin;
+    const int rc = wide ? launch<160, 2, 9, false>(dy, w, nullptr, nullptr, dx, N, Ho, Wo, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel)
+                        : launch<128, 2, 9, false>(dy, w, nullptr, nullptr, dx, N, Ho, Wo, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 extern "C" int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,

@@ -623,6 +623,18 @@ def downsample_sym(x, w, bias):
     return F.conv2d(x, w, bias, stride=2, padding=1)
 
 
+def _s2_dgrad_weight(w):
+    """wt4 [4][Cin][3][3][Cout] of gip_conv3x3s2_dgrad_nhwc_f16 from the forward weight w [Cout, Cin, 3, 3]."""
+    wt = w.detach().permute(1, 2, 3, 0)                       # [ci][ky][kx][co]
+    out = torch.zeros((4, w.shape[1], 3, 3, w.shape[0]), dtype=w.dtype, device=w.device)
+    for pi in range(2):
+        for pj in range(2):
+            for dy, ky in ((0, 2), (1, pi)) if pi == 0 else ((1, 1),):
+                for dx, kx in ((0, 2), (1, pj)) if pj == 0 else ((1, 1),):
+                    out[2 * pi + pj, :, dy, dx, :] = wt[:, ky, kx, :]
+    return out.contiguous()
+
+
 class _DownsampleAsym(torch.autograd.Function):
     """VAE Downsample2D: F.pad(x, (0, 1, 0, 1)) -> 3x3 / stride 2 / pad 0 convolution.  Forward stays on MIOpen; the
     DATA GRADIENT is the stride-1 MFMA convolution of the zero-dilated upstream gradient with the flipped-transposed
@@ -642,6 +654,16 @@ class _DownsampleAsym(torch.autograd.Function):
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
         N, C, H, W = ctx.x_shape
+        if (w.shape[0] % 64 == 0 and C % 8 == 0 and N * H * W * max(C, w.shape[0]) * 2 < (1 << 31) and
+                os.environ.get("GIP_CONV_S2_DGRAD", "1") != "0"):
+            # four parity classes of dx, each a small convolution over dy's grid (4 / 2 / 2 / 1 taps): minimal FLOPs
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+            rc = _lib.nn_lib().gip_conv3x3s2_dgrad_nhwc_f16(_p(dy), _p(_wt_cache.get("s2t", w, _s2_dgrad_weight)), _p(dx), N, H // 2, W // 2,
+                                                            w.shape[0], C, ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("gip_conv3x3s2_dgrad_nhwc_f16 failed with status %d" % rc)
+            return dx, None, None
         if w.shape[0] > 128:          # measured: the library's backward-data kernels are as fast at 256 / 512 channels
             return torch.nn.grad.conv2d_input((N, C, H + 1, W + 1), w, dy, stride=2)[:, :, :H, :W], None, None
         up = torch.empty((N, w.shape[0], H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()

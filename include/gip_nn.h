@@ -156,6 +156,15 @@ int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void*
                            int32_t Cin, int32_t Cout, int32_t pad_top, int32_t pad_left, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* DATA GRADIENT of that stride-2 convolution in its pad_top = pad_left = 0 form (the VAE's Downsample2D, whose gradient the
+ * reference gets from autograd through AutoencoderKL.encode, ipa_guidance.py:309-314): dy [N,Ho,Wo,Cin] half (Cin = the forward
+ * convolution's output channels), dx [N,2 Ho,2 Wo,Cout] half (every element written).  wt4 [4][Cout][3][3][Cin] half, parity
+ * class c = 2 (i & 1) + (j & 1) of the dx pixel: wt4[c][ci][dy][dx][co] = w[co][ci][ky][kx] with ky = 2 for dy = 0, ky = i & 1
+ * for dy = 1, unused otherwise (same in x; taps a class does not use are never read).  Four launches of the implicit GEMM
+ * over dy's own grid with 4 / 2 / 2 / 1 taps: the minimal FLOPs, no zero-dilated copy.  Cin % 64 == 0, Cout % 8 == 0. */
+int gip_conv3x3s2_dgrad_nhwc_f16(const void* dy, const void* wt4, void* dx, int32_t N, int32_t Ho, int32_t Wo, int32_t Cin,
+                                 int32_t Cout, void* stream);
+
 /* nn.Linear on the same MFMA machinery (TAPS = 1): out[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]) (+ residual[m][n]),
  * x [M,K], w [Nout,K] (torch Linear weight), out [M,Nout] half, fp32 accumulation, K % 64 == 0.  geglu != 0: w has
  * 2*Nout rows [value | gate], bias 2*Nout, out = (xWv + bv) * gelu(xWg + bg) — diffusers' GEGLU feed-forward input

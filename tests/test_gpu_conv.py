@@ -305,3 +305,32 @@ def test_controlnet_stem_runs_on_the_few_channel_kernels():
             ref = net.embed_condition(cond)
     assert emb.shape == (2, 320, 16, 16)
     assert float((emb.float() - ref.float()).abs().max()) <= 4e-3 * max(1.0, float(ref.float().abs().max()))
+
+
+# ---- data gradient of the VAE's stride-2 convolution as four parity classes (gip_conv3x3s2_dgrad_nhwc_f16) ----
+@pytest.mark.parametrize("N,C,Co,H,W", [(2, 128, 128, 64, 48), (1, 256, 256, 34, 18), (2, 72, 128, 20, 12), (1, 512, 512, 16, 32), (1, 320, 64, 8, 8)])
+def test_stride2_data_gradient_by_parity_classes(N, C, Co, H, W, monkeypatch):
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setattr(fused, "_MIN_CONV_TILES", 0)
+    g = torch.Generator(device="cuda").manual_seed(C + Co + H)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(**cl).requires_grad_(True)
+    w = (torch.randn(Co, C, 3, 3, device="cuda", generator=g) / (3 * C ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(Co, device="cuda", generator=g).half()
+    before = _lib.call_counts.get("gip_conv3x3s2_dgrad_nhwc_f16", 0)
+    y = fused.downsample_asym(x, w, b)
+    dy = torch.randn(y.shape, device="cuda", generator=g).half().contiguous(**cl)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    assert _lib.call_counts.get("gip_conv3x3s2_dgrad_nhwc_f16", 0) == before + 1, "the parity-class kernel did not run"
+    xr = x.detach().float().requires_grad_(True)
+    (dxr,) = torch.autograd.grad(F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.float(), b.float(), stride=2), xr, dy.float())
+    assert dx.shape == x.shape and dx.is_contiguous(**cl)
+    err = (dx.float() - dxr).abs()
+    assert float(err.max()) <= 2e-3 * float(dxr.abs().max())
+    # every parity class and the image borders (first / last rows and columns) individually
+    for pi in range(2):
+        for pj in range(2):
+            assert float(err[:, :, pi::2, pj::2].max()) <= 2e-3 * float(dxr.abs().max())
+    assert float(torch.cat([err[:, :, 0].flatten(), err[:, :, -1].flatten(), err[:, :, :, 0].flatten(), err[:, :, :, -1].flatten()]).max()) \
+        <= 2e-3 * float(dxr.abs().max())
