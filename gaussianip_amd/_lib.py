@@ -199,6 +199,8 @@ def nn_lib():
                                                    ctypes.c_size_t, _vp]
         lib.gip_conv3x3s2_dgrad_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3s2_dgrad_nhwc_f16.argtypes = [_vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp]
+        lib.gip_upsample2x_conv3x3_nhwc_f16.restype = ctypes.c_int
+        lib.gip_upsample2x_conv3x3_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp]
         lib.gip_conv3x3_fewch_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_fewch_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 7 + [_vp]
         lib.gip_conv3x3_c3_fwd_nhwc_f16.restype = ctypes.c_int

@@ -95,11 +95,25 @@ __global__ void __launch_bounds__(CV_THREADS, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom,
-               float* __restrict__ chan_stats, GnBwdArgs gnb, int tapsel) {
+               float* __restrict__ chan_stats, GnBwdArgs gnb, int tapsel_in) {
   // geom = stride | pad_top << 8 | pad_left << 16; H, W are the OUTPUT dims, Hin, Win the input dims (equal at stride 1)
   // tapsel (TAPS = 9): bits 0-8 = the taps the K loop visits (0x1ff: all nine); bit 11 = scatter: output pixel (n, a, b) is
   // written to row (n, 2 a + pi, 2 b + pj) of a [N, 2 H, 2 W, Cout] tensor, pi = bit 9, pj = bit 10 — one parity class of
-  // the DATA GRADIENT of a stride-2 convolution (gip_conv3x3s2_dgrad_nhwc_f16 below)
+  // the DATA GRADIENT of a stride-2 convolution (gip_conv3x3s2_dgrad_nhwc_f16 below).  Bit 12 = all four parity classes in
+  // ONE launch: class c = blockIdx.x / (tiles * ksplit) picks its tap set from a table (bit 13 = which: 0 the stride-2 data
+  // gradient, 1 nearest-2x-upsample + convolution) and its weight block w + c * Cout * 9 * Cin.
+  int tapsel = tapsel_in;
+  unsigned bid = blockIdx.x;
+  if (TAPS == 9 && ((tapsel_in >> 12) & 1)) {
+    const unsigned per = (unsigned)(m_tiles * n_tiles * ksplit), cls = bid / per;
+    bid -= cls * per;
+    const int pi = (int)(cls >> 1), pj = (int)(cls & 1);
+    int mask;
+    if ((tapsel_in >> 13) & 1) mask = pi ? (pj ? 0x1b0 : 0x0d8) : (pj ? 0x036 : 0x01b);      // rows {0,1} | {1,2} x columns {0,1} | {1,2}
+    else mask = pi ? (pj ? 0x010 : 0x018) : (pj ? 0x012 : 0x01b);
+    tapsel = mask | (pi << 9) | (pj << 10) | (1 << 11);
+    w += (size_t)cls * Cout * 9 * Cin;
+  }
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int A_BYTES = CV_BM * 128;          // pixel tile: 128 rows x 64 halves
@@ -113,7 +127,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   // tile of this workgroup (bijective XCD remap: ids congruent mod 8 share an XCD)
   // split-K (small pixel counts: too few output tiles to fill the chip): blockIdx.x = split * total + tile, every split
   // accumulates its share of the K steps and stores an fp32 slab; conv_splitk_reduce_kernel sums the slabs
-  const int total = m_tiles * n_tiles, id = (int)(blockIdx.x % (unsigned)total), split = (int)(blockIdx.x / (unsigned)total);
+  const int total = m_tiles * n_tiles, id = (int)(bid % (unsigned)total), split = (int)(bid / (unsigned)total);
   const int q = total >> 3, r = total & 7, xcd = id & 7;
   const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   // tile order inside an XCD's contiguous chunk (geom bit 24): m-major keeps the tiles that share a PIXEL block together
@@ -802,7 +816,8 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
     lds_epi = 1;
   }
   geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26);   // bits 26-28: timing ablations (WRONG results)
-  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit), dim3(CV_THREADS), lds, s,
+  const int classes = (tapsel >> 12) & 1 ? 4 : 1;
+  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit * classes), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
                      N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats, gnb, tapsel);
   if (ksplit > 1) {
@@ -896,16 +911,26 @@ extern "C" int gip_conv3x3s2_dgrad_nhwc_f16(const void* dy, const void* wt4, voi
   hipStream_t s = (hipStream_t)stream;
   const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
   const int geom = 1 | (1 << 8) | (1 << 16);
-  static const int masks[4] = {0x01b /* taps (0,0) (0,1) (1,0) (1,1) */, 0x012 /* (0,1) (1,1) */, 0x018 /* (1,0) (1,1) */, 0x010 /* (1,1) */};
-  for (int c = 0; c < 4; c++) {
-    const int pi = c >> 1, pj = c & 1;
-    const int tapsel = masks[c] | (pi << 9) | (pj << 10) | (1 << 11);
-    const _Float16* w = (const _Float16*)wt4 + (size_t)c * Cout * 9 * Cin;
-    const int rc = wide ? launch<160, 2, 9, false>(dy, w, nullptr, nullptr, dx, N, Ho, Wo, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel)
-                        : launch<128, 2, 9, false>(dy, w, nullptr, nullptr, dx, N, Ho, Wo, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel);
-    if (rc) return rc;
-  }
-  return 0;
+  const int tapsel = 0x1ff | (1 << 11) | (1 << 12);          // four classes in one launch, the stride-2 data-gradient tap sets
+  return wide ? launch<160, 2, 9, false>(dy, wt4, nullptr, nullptr, dx, N, Ho, Wo, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel)
+              : launch<128, 2, 9, false>(dy, wt4, nullptr, nullptr, dx, N, Ho, Wo, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel);
+}
+
+// nearest-neighbour 2x upsampling followed by the 3x3 / pad 1 convolution (diffusers Upsample2D) WITHOUT the upsampled tensor:
+// out[2 a + pi][2 b + pj] reads x rows {a - 1, a} (pi = 0) or {a, a + 1} (pi = 1), because the three taps of the upsampled
+// image fall on two source pixels — so each parity class is a 2 x 2-tap convolution over x's own grid with the weights of
+// the coinciding taps summed (by the host: wt4 [4][Cout][3][3][Cin], class c = 2 pi + pj, the summed weight stored at the tap
+// whose input offset it applies to).  4 tap-GEMMs per output pixel instead of 9, and x is read at its own size.
+extern "C" int gip_upsample2x_conv3x3_nhwc_f16(const void* x, const void* wt4, const void* bias, void* out, int32_t N, int32_t Hin,
+                                               int32_t Win, int32_t Cin, int32_t Cout, void* stream) {
+  if (!x || !wt4 || !out || N < 1 || Hin < 1 || Win < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 8 || (Cout & 7)) return 1;
+  if (!fits32((long long)N * Hin * Win * 4, Cin, Cout, Cout, 9)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  const int tapsel = 0x1ff | (1 << 11) | (1 << 12) | (1 << 13);
+  return wide ? launch<160, 2, 9, false>(x, wt4, bias, nullptr, out, N, Hin, Win, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel)
+              : launch<128, 2, 9, false>(x, wt4, bias, nullptr, out, N, Hin, Win, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel);
 }
 
 extern "C" int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,

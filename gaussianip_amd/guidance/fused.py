@@ -623,6 +623,41 @@ def downsample_sym(x, w, bias):
     return F.conv2d(x, w, bias, stride=2, padding=1)
 
 
+def _upsample_conv_weight(w):
+    """wt4 [4][Cout][3][3][Cin] of gip_upsample2x_conv3x3_nhwc_f16 from the convolution weight w [Cout, Cin, 3, 3]: per output
+    parity the taps that read the same source pixel are summed (fp32, one rounding to half)."""
+    wk = w.detach().float().permute(0, 2, 3, 1)                # [co][ky][kx][ci]
+    sets = ({0: (0,), 1: (1, 2)}, {1: (0, 1), 2: (2,)})         # parity -> {tap (input offset tap - 1): the ky it gathers}
+    out = torch.zeros((4, w.shape[0], 3, 3, w.shape[1]), dtype=torch.float32, device=w.device)
+    for pi in range(2):
+        for pj in range(2):
+            for dy, kys in sets[pi].items():
+                for dx, kxs in sets[pj].items():
+                    out[2 * pi + pj, :, dy, dx, :] = sum(wk[:, ky, kx, :] for ky in kys for kx in kxs)
+    return out.to(w.dtype).contiguous()
+
+
+def upsample2x_conv3x3(x, w, bias):
+    """conv3x3(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias) — diffusers Upsample2D.  On the GPU the four
+    output parity classes run as 2 x 2-tap convolutions over x itself (summed weights, see _upsample_conv_weight): 4 / 9 of
+    the FLOPs and no upsampled tensor.  The summed weights are rounded to half once: results differ from the two-step form
+    by fp16 weight rounding (~2^-11 relative per weight), inside the tolerance of the fp16 convolution itself."""
+    if (fusable(x) and x.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and w.dtype == torch.float16 and not w.requires_grad and
+            (bias is None or not bias.requires_grad) and not (torch.is_grad_enabled() and x.requires_grad) and
+            4 * _conv_tiles(x.shape[0], x.shape[2], x.shape[3], w.shape[0]) >= int(os.environ.get("GIP_UPCONV_MIN_TILES", "256")) and
+            x.shape[0] * 4 * x.shape[2] * x.shape[3] * max(x.shape[1], w.shape[0]) * 2 < (1 << 31) and
+            os.environ.get("GIP_UPCONV", "1") != "0"):
+        N, C, H, W = x.shape
+        out = torch.empty((N, w.shape[0], 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        rc = _lib.nn_lib().gip_upsample2x_conv3x3_nhwc_f16(_p(x), _p(_wt_cache.get("up4", w, _upsample_conv_weight)),
+                                                           ctypes.c_void_p(None) if bias is None else _p(bias), _p(out), N, H, W, C,
+                                                           w.shape[0], ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_upsample2x_conv3x3_nhwc_f16 failed with status %d" % rc)
+        return out
+    return conv3x3(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, bias)
+
+
 def _s2_dgrad_weight(w):
     """wt4 [4][Cin][3][3][Cout] of gip_conv3x3s2_dgrad_nhwc_f16 from the forward weight w [Cout, Cin, 3, 3]."""
     wt = w.detach().permute(1, 2, 3, 0)                       # [ci][ky][kx][co]

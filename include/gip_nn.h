@@ -165,6 +165,16 @@ int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void*
 int gip_conv3x3s2_dgrad_nhwc_f16(const void* dy, const void* wt4, void* dx, int32_t N, int32_t Ho, int32_t Wo, int32_t Cin,
                                  int32_t Cout, void* stream);
 
+/* Nearest-neighbour 2x upsampling + 3x3 / pad 1 convolution (diffusers Upsample2D in the U-Net decoder the reference runs,
+ * ipa_guidance.py:349-356) without materialising the upsampled tensor: x [N,Hin,Win,Cin] half -> out [N,2 Hin,2 Win,Cout] half
+ * (+ bias [Cout] or NULL).  Each output parity class (i & 1, j & 1) is a 2 x 2-tap convolution over x's own grid, the
+ * weights of the taps that fall on the same source pixel summed by the caller: wt4 [4][Cout][3][3][Cin] half, class
+ * c = 2 (i & 1) + (j & 1); rows: parity 0 -> tap 0 holds w[ky = 0], tap 1 holds w[1] + w[2]; parity 1 -> tap 1 holds
+ * w[0] + w[1], tap 2 holds w[2] (tap t = input offset t - 1; same in x; the sums taken in fp32, rounded to half once).
+ * 4 tap-GEMMs per output pixel instead of 9.  Cin % 64 == 0, Cout % 8 == 0. */
+int gip_upsample2x_conv3x3_nhwc_f16(const void* x, const void* wt4, const void* bias, void* out, int32_t N, int32_t Hin,
+                                    int32_t Win, int32_t Cin, int32_t Cout, void* stream);
+
 /* nn.Linear on the same MFMA machinery (TAPS = 1): out[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]) (+ residual[m][n]),
  * x [M,K], w [Nout,K] (torch Linear weight), out [M,Nout] half, fp32 accumulation, K % 64 == 0.  geglu != 0: w has
  * 2*Nout rows [value | gate], bias 2*Nout, out = (xWv + bv) * gelu(xWg + bg) — diffusers' GEGLU feed-forward input

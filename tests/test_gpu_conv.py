@@ -334,3 +334,34 @@ def test_stride2_data_gradient_by_parity_classes(N, C, Co, H, W, monkeypatch):
             assert float(err[:, :, pi::2, pj::2].max()) <= 2e-3 * float(dxr.abs().max())
     assert float(torch.cat([err[:, :, 0].flatten(), err[:, :, -1].flatten(), err[:, :, :, 0].flatten(), err[:, :, :, -1].flatten()]).max()) \
         <= 2e-3 * float(dxr.abs().max())
+
+
+# ---- nearest 2x upsampling + 3x3 convolution as four 2 x 2-tap parity classes (gip_upsample2x_conv3x3_nhwc_f16) ----
+@pytest.mark.parametrize("N,C,Co,H,W", [(8, 1280, 1280, 16, 16), (8, 640, 640, 32, 32), (2, 64, 72, 7, 5), (1, 128, 320, 16, 24)])
+def test_upsample_then_convolution_by_parity_classes(N, C, Co, H, W, monkeypatch):
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setenv("GIP_UPCONV_MIN_TILES", "0")
+    g = torch.Generator(device="cuda").manual_seed(C + Co + H)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(Co, C, 3, 3, device="cuda", generator=g) / (3 * C ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(Co, device="cuda", generator=g).half()
+    before = _lib.call_counts.get("gip_upsample2x_conv3x3_nhwc_f16", 0)
+    with torch.no_grad():
+        out = fused.upsample2x_conv3x3(x, w, b)
+    assert _lib.call_counts.get("gip_upsample2x_conv3x3_nhwc_f16", 0) == before + 1, "the parity-class kernel did not run"
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    assert out.shape == ref.shape and out.is_contiguous(**cl)
+    err = (out.float() - ref).abs()
+    # tolerance: half output rounding + the summed weights' one extra half rounding (2^-11 relative per weight, random signs)
+    tol = 2.5e-3 * float(ref.abs().max())
+    assert float(err.max()) <= tol
+    for pi in range(2):
+        for pj in range(2):
+            assert float(err[:, :, pi::2, pj::2].max()) <= tol
+    assert float(torch.cat([err[:, :, 0].flatten(), err[:, :, -1].flatten(), err[:, :, :, 0].flatten(), err[:, :, :, -1].flatten()]).max()) <= tol
+    # the two-step form on the same kernels agrees to the same tolerance
+    with torch.no_grad():
+        two = fused.conv3x3(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b)
+    assert float((out.float() - two.float()).abs().max()) <= tol
