@@ -308,6 +308,23 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       // half-rounded convolution output — fp16(fp16(conv + bias) + residual), diffusers' own arithmetic for
       // `input_tensor + hidden_states` in ResnetBlock2D.
       constexpr int ROWB = BN * 2 + 16;                 // padded row: 16-byte aligned, 8-byte writes at most 2-way conflicted
+      constexpr int CH = BN / 8, RPP = CV_THREADS / CH;     // 16-byte chunks per row, rows per pass
+      constexpr int RPT = (CV_BM + RPP - 1) / RPP;          // rows per thread
+      const int chunk = tid % CH, r0 = tid / CH;
+      const int co = co0 + chunk * 8;
+      const bool mine = tid < RPP * CH && co < Cout;
+      // the residual rows this thread will add are requested FIRST (geom bit 29): their HBM latency then overlaps the
+      // accumulator -> LDS staging and its barrier instead of starting after them
+      const bool res_early = residual && ((geom >> 29) & 1);
+      f16x8 rres[RPT];
+      if (res_early && mine) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int row = r0 + k * RPP;
+          const unsigned m = m0 + row;
+          rres[k] = (row < CV_BM && m < M) ? *(const f16x8*)(residual + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ni++) {
         const int cl = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
@@ -323,10 +340,6 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         }
       }
       __syncthreads();
-      constexpr int CH = BN / 8, RPP = CV_THREADS / CH;     // 16-byte chunks per row, rows per pass
-      const int chunk = tid % CH, r0 = tid / CH;
-      const int co = co0 + chunk * 8;
-      const bool mine = tid < RPP * CH && co < Cout;
       // per-channel sum / sum of squares of the FINAL half-rounded outputs of this tile (chan_stats != NULL): the
       // statistics pass of the GroupNorm that consumes this tensor (gip_gn_finalize_stats) — it never re-reads the tensor
       float s8[8], q8[8];
@@ -335,13 +348,14 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       if (mine) {
         GnBwdLane gl;
         if (chan_stats && gnb.x) gnb_load(gnb, (int)(m0 / (unsigned)gnb.HW), co, Cout, gl);
-#pragma unroll 4
-        for (int row = r0; row < CV_BM; row += RPP) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int row = r0 + k * RPP;
           const unsigned m = m0 + row;
-          if (m >= M) break;
+          if (row >= CV_BM || m >= M) break;
           f16x8 v = *(const f16x8*)(smem + row * ROWB + chunk * 16);
           if (residual) {
-            const f16x8 rr = *(const f16x8*)(residual + (size_t)m * Cout + co);
+            const f16x8 rr = res_early ? rres[k] : *(const f16x8*)(residual + (size_t)m * Cout + co);
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
           }
@@ -612,6 +626,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   const int chunk = tid % CH, r0 = tid / CH;
   const int co = co0 + chunk * 8;
   const bool mine = co < Cout;
+  const bool res_early = residual && ((geom >> 29) & 1);
   float s8[2][8], q8[2][8];                               // statistics of the tile's two 128-row blocks
 #pragma unroll
   for (int b = 0; b < 2; b++)
@@ -621,6 +636,18 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   if (chan_stats && gnb.x && mine) gnb_load(gnb, (int)(m0 / (unsigned)gnb.HW), co, Cout, gl);
 #pragma unroll
   for (int pass = 0; pass < PASSES; pass++) {
+    // the residual rows of this pass are requested before the image is staged (geom bit 29, see conv3x3_kernel)
+    constexpr int RPT = (PROWS + RPP - 1) / RPP;
+    constexpr int RPF = RPT / 2;                          // half of them: the register file is full (229 of 256 in the main loop)
+    f16x8 rres[RPF];
+    if (res_early && mine) {
+#pragma unroll
+      for (int k = 0; k < RPF; k++) {
+        const int row = r0 + k * RPP;
+        const unsigned m = m0 + pass * PROWS + row;
+        rres[k] = (row < PROWS && m < M) ? *(const f16x8*)(residual + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
     if (PASSES == 1 || wr == pass) {
 #pragma unroll
       for (int ni = 0; ni < NI; ni++) {
@@ -639,13 +666,14 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
     }
     __syncthreads();
     if (mine) {
-#pragma unroll 4
-      for (int row = r0; row < PROWS; row += RPP) {
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const int row = r0 + k * RPP;
         const unsigned m = m0 + pass * PROWS + row;
-        if (m >= M) break;
+        if (row >= PROWS || m >= M) break;
         f16x8 v = *(const f16x8*)(smem + row * ROWB + chunk * 16);
         if (residual) {
-          const f16x8 rr = *(const f16x8*)(residual + (size_t)m * Cout + co);
+          const f16x8 rr = (res_early && k < RPF) ? rres[k < RPF ? k : 0] : *(const f16x8*)(residual + (size_t)m * Cout + co);
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
         }
@@ -740,6 +768,8 @@ static int launch_big(const void* x, const void* w, const void* bias, const void
       return 3;
     attr_set = true;
   }
+  static const int env_res = env_int("GIP_CONV_RES_EARLY", 1);
+  geom |= env_res << 29;
   hipLaunchKernelGGL((conv_big_kernel<BN, TAPS>), dim3(m_tiles * n_tiles), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin, Cout,
                      m_tiles, n_tiles, Hin, Win, geom, chan_stats, gnb);
@@ -815,7 +845,8 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
     ksplit = 1;
     lds_epi = 1;
   }
-  geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26);   // bits 26-28: timing ablations (WRONG results)
+  static const int env_res = env_int("GIP_CONV_RES_EARLY", 1);
+  geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (env_res << 29);   // bits 26-28: timing ablations (WRONG results)
   const int classes = (tapsel >> 12) & 1 ? 4 : 1;
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit * classes), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,

@@ -111,6 +111,35 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
 
     for i in range(warmup):
         step(i)
+    timeline = {}
+    if os.environ.get("GIP_HOST_TIMELINE"):
+        # where does the HOST spend the step?  perf_counter / thread_time around the phase boundaries, no synchronisation added:
+        # a phase whose wall time is far above its CPU time is where the host BLOCKS on the GPU
+        def wrap(obj, name, label):
+            fn = getattr(obj, name)
+
+            def w(*a, **k):
+                t_, c_ = time.perf_counter(), time.thread_time()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    d = timeline.setdefault(label, [0.0, 0.0, 0])
+                    d[0] += time.perf_counter() - t_
+                    d[1] += time.thread_time() - c_
+                    d[2] += 1
+            setattr(obj, name, w)
+        wrap(scenes, "train_batch", "0 data batch (host)")
+        wrap(stage, "forward", "1 render + pose maps")
+        wrap(skel, "openpose_draw", "1a  pose maps")
+        wrap(guidance, "encode_images", "2a  VAE encode")
+        wrap(guidance, "forward_unet", "2b  ControlNet + U-Net")
+        wrap(type(guidance), "__call__", "2 guidance (whole)")
+        wrap(torch.Tensor, "backward", "3 backward")
+        if scaler is not None:
+            wrap(scaler, "unscale_", "4a  unscale")
+            wrap(scaler, "step", "4b  Adam")
+            wrap(scaler, "update", "4c  scaler update")
+        wrap(stage, "optimizer_step", "4 optimizer step (whole, incl. backward)")
     if os.environ.get("GIP_TORCH_PROFILE"):
         # op-level table of two steady-state steps (which aten op, with which shapes, from which line launched the glue kernels)
         from torch.profiler import ProfilerActivity, profile
@@ -137,6 +166,9 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     host_ms = host_s / steps * 1e3
+    for label in sorted(timeline):
+        d = timeline[label]
+        print("host timeline  %-44s wall %7.2f ms  cpu %6.2f ms  (%d calls / step)" % (label, d[0] / steps * 1e3, d[1] / steps * 1e3, d[2] // steps), file=sys.stderr)
     host_cpu_ms = host_cpu_s / steps * 1e3
     if world > 1:
         et = torch.tensor([dt], device=dev, dtype=torch.float64)
