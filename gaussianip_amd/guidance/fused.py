@@ -626,9 +626,10 @@ def downsample_sym(x, w, bias):
 def _upsample_conv_weight(w):
     """wt4 [4][Cout][3][3][Cin] of gip_upsample2x_conv3x3_nhwc_f16 from the convolution weight w [Cout, Cin, 3, 3]: per output
     parity the taps that read the same source pixel are summed (fp32, one rounding to half)."""
-    wk = w.detach().float().permute(0, 2, 3, 1)                # [co][ky][kx][ci]
+    acc = torch.float64 if w.dtype == torch.float64 else torch.float32
+    wk = w.detach().to(acc).permute(0, 2, 3, 1)                # [co][ky][kx][ci]
     sets = ({0: (0,), 1: (1, 2)}, {1: (0, 1), 2: (2,)})         # parity -> {tap (input offset tap - 1): the ky it gathers}
-    out = torch.zeros((4, w.shape[0], 3, 3, w.shape[1]), dtype=torch.float32, device=w.device)
+    out = torch.zeros((4, w.shape[0], 3, 3, w.shape[1]), dtype=acc, device=w.device)
     for pi in range(2):
         for pj in range(2):
             for dy, kys in sets[pi].items():
