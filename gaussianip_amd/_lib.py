@@ -220,6 +220,8 @@ def nn_lib():
                                                   ctypes.c_int32, _vp]
         lib.gip_conv3x3_stats_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_stats_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp, _vp]
+        lib.gip_conv3x3_stats_ws_nhwc_f16.restype = ctypes.c_int
+        lib.gip_conv3x3_stats_ws_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]
         lib.gip_linear_stats_f16.restype = ctypes.c_int
         lib.gip_linear_stats_f16.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp, _vp]
         lib.gip_add_bias_residual.restype = ctypes.c_int

@@ -744,6 +744,60 @@ conv_splitk_reduce_kernel(const float* __restrict__ partial, const _Float16* __r
   *(f16x4*)(out + (size_t)i * 4) = o;
 }
 
+// The same reduction for a tensor whose consumer is a GroupNorm: it also leaves the per-(RB-row block, channel) sum and sum of
+// squares of the half-rounded outputs in chan_stats [M / RB][Cout][2] (what the whole-K epilogue writes per 128-row block), so
+// the split-K layers — the 16 x 16 and 8 x 8 levels of the U-Net / ControlNet — no longer need the GroupNorm's own statistics
+// pass.  RB = 128, or 64 where a sample has only 64 pixels (a block must not straddle two samples).  A workgroup owns RB rows
+// x 64 channels: 16 lanes x 4 channels across, 16 row-lanes down; fixed summation order.
+template <int RB>
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce_stats_kernel(const float* __restrict__ partial, const _Float16* __restrict__ bias, const _Float16* __restrict__ residual,
+                                _Float16* __restrict__ out, float* __restrict__ chan_stats, unsigned M, int Cout, int ksplit, size_t slab) {
+  __shared__ float part[16 * 64 * 2];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int co = blockIdx.y * 64 + cx * 4;
+  const unsigned m0 = blockIdx.x * RB;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (co < Cout) {
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (bias) { const f16x4 b = *(const f16x4*)(bias + co); b4 = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]}; }
+#pragma unroll
+    for (int k = 0; k < RB / 16; k++) {
+      const unsigned m = m0 + ry + 16 * k;
+      if (m >= M) break;
+      const size_t i = (size_t)m * Cout + co;
+      f32x4 v = *(const f32x4*)(partial + i);
+      for (int sp = 1; sp < ksplit; sp++) {
+        const f32x4 p = *(const f32x4*)(partial + (size_t)sp * slab + i);
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+      }
+      v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+      if (residual) {
+        const f16x4 r = *(const f16x4*)(residual + i);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+      }
+      f16x4 o;
+      o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+      *(f16x4*)(out + i) = o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const float f = (float)o[j]; s4[j] += f; q4[j] = fmaf(f, f, q4[j]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    part[(ry * 64 + cx * 4 + j) * 2] = s4[j];
+    part[(ry * 64 + cx * 4 + j) * 2 + 1] = q4[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < Cout) {
+    float S = 0.f, Q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { S += part[(r * 64 + threadIdx.x) * 2]; Q += part[(r * 64 + threadIdx.x) * 2 + 1]; }
+    float* o = chan_stats + ((size_t)blockIdx.x * Cout + blockIdx.y * 64 + threadIdx.x) * 2;
+    o[0] = S; o[1] = Q;
+  }
+}
+
 // Debug / A-B knobs (tools/exp_conv*.py set them through ctypes; -1 = the shape heuristic below decides)
 extern "C" { int gip_dbg_conv_order = -1; int gip_dbg_conv_epilogue = -1; int gip_dbg_conv_ksplit = 0; int gip_dbg_conv_ablate = 0;
              int gip_dbg_conv_big = -1; }
@@ -793,7 +847,7 @@ template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
                   int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0, int Hin = 0, int Win = 0,
                   int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr, const GnBwdArgs* gnb_in = nullptr,
-                  int tapsel = 0x1ff) {
+                  int tapsel = 0x1ff, int stats_rows = 128) {
   GnBwdArgs gnb = {};
   if (gnb_in) gnb = *gnb_in;
   if (Hin == 0) { Hin = H; Win = W; }
@@ -840,8 +894,9 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   static const int env_epi = env_int("GIP_CONV_EPILOGUE", 1);
   int lds_epi = env_epi;
   if (gip_dbg_conv_epilogue >= 0) lds_epi = gip_dbg_conv_epilogue;
-  if (chan_stats) {            // statistics come out of the LDS epilogue of whole-K tiles
-    if (GEGLU || (Cout & 7)) return 1;
+  const bool stats_in_reduce = chan_stats && ksplit > 1 && !gnb.x;      // split-K: the reduce kernel makes the statistics
+  if (chan_stats && !stats_in_reduce) {            // statistics come out of the LDS epilogue of whole-K tiles (128-row blocks)
+    if (GEGLU || (Cout & 7) || stats_rows != 128) return 1;
     ksplit = 1;
     lds_epi = 1;
   }
@@ -850,8 +905,20 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   const int classes = (tapsel >> 12) & 1 ? 4 : 1;
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit * classes), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
-                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom, chan_stats, gnb, tapsel);
-  if (ksplit > 1) {
+                     N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom,
+                     stats_in_reduce ? nullptr : chan_stats, gnb, tapsel);
+  if (stats_in_reduce) {
+    if ((Cout & 3) || M % stats_rows) return 1;
+    const dim3 grid((unsigned)(M / stats_rows), (unsigned)((Cout + 63) / 64));
+    if (stats_rows == 128)
+      hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<128>), grid, dim3(256), 0, s, (const float*)workspace, (const _Float16*)bias,
+                         (const _Float16*)residual, (_Float16*)out, chan_stats, (unsigned)M, Cout, ksplit, (size_t)M * Cout);
+    else if (stats_rows == 64)
+      hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<64>), grid, dim3(256), 0, s, (const float*)workspace, (const _Float16*)bias,
+                         (const _Float16*)residual, (_Float16*)out, chan_stats, (unsigned)M, Cout, ksplit, (size_t)M * Cout);
+    else
+      return 1;
+  } else if (ksplit > 1) {
     const unsigned n4 = (unsigned)(M * Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
                        (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, n4, Cout / 4, ksplit, (size_t)M * Cout);
@@ -884,6 +951,21 @@ extern "C" int gip_conv3x3_stats_nhwc_f16(const void* x, const void* w, const vo
   const int geom = 1 | (1 << 8) | (1 << 16);
   return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_stats)
               : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, nullptr, 0, 0, 0, geom, chan_stats);
+}
+
+extern "C" int gip_conv3x3_stats_ws_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                                             int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* chan_stats,
+                                             int32_t stats_rows, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !w || !out || !chan_stats || N < 1 || H < 1 || W < 1 || Cin < CV_BK || Cin % CV_BK || Cout < 8 || (Cout & 7)) return 1;
+  if ((stats_rows != 128 && stats_rows != 64) || ((long long)H * W) % stats_rows) return 1;
+  if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  return wide ? launch<160, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes, 0, 0, geom, chan_stats,
+                                         nullptr, 0x1ff, stats_rows)
+              : launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes, 0, 0, geom, chan_stats,
+                                         nullptr, 0x1ff, stats_rows);
 }
 
 extern "C" int gip_conv3x3_gnbwd_nhwc_f16(const void* dy_in, const void* w, void* out, int32_t N, int32_t H, int32_t W, int32_t Cin,

@@ -48,7 +48,7 @@ class _FusedGN(torch.autograd.Function):
         if chan_stats is not None:
             # the producer of x (MFMA convolution / linear epilogue) already summed x per 128-row block and channel
             rc = lib.gip_gn_silu_forward_stats(_p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), N, H * W, C, groups,
-                                               float(eps), int(act), ad_ptr, ad_stride, _p(chan_stats), (H * W) // 128, stream)
+                                               float(eps), int(act), ad_ptr, ad_stride, _p(chan_stats), chan_stats.shape[0] // N, stream)
         else:
             nb = lib.gip_gn_workspace_bytes(N, groups)
             ws = _workspace(x.device, nb)
@@ -99,14 +99,15 @@ _STATS_ATTR = "_gip_chan_stats"
 
 
 def producer_stats(x):
-    """chan_stats [N * HW / 128, C, 2] float32 that the kernel which produced `x` wrote in its epilogue (attached to the
-    tensor OBJECT by conv3x3 / linear below; any view / copy of x drops it and the GroupNorm takes its own statistics
-    pass), or None."""
+    """chan_stats [N * HW / R, C, 2] float32 (R = 128 rows per block, or 64 at the 8 x 8 level) that the kernel which
+    produced `x` wrote in its epilogue (attached to the tensor OBJECT by conv3x3 / linear below; any view / copy of x drops
+    it and the GroupNorm takes its own statistics pass), or None."""
     st = getattr(x, _STATS_ATTR, None)
     if st is None or x.dim() != 4:
         return None
     N, C, H, W = x.shape
-    if st.shape != (N * H * W // 128, C, 2) or (H * W) % 128 or C // 32 > 256 or os.environ.get("GIP_GN_STATS", "1") == "0":
+    R = (N * H * W) // max(int(st.shape[0]), 1)
+    if R not in (64, 128) or st.shape != (N * H * W // R, C, 2) or (H * W) % R or C // 32 > 256 or os.environ.get("GIP_GN_STATS", "1") == "0":
         return None
     return st
 
@@ -118,10 +119,23 @@ def attach_stats(x, st):
 
 
 def stats_wanted(N, H, W, cout):
-    """The producer takes the next GroupNorm's statistics when a 128-pixel block never straddles two samples and the
-    problem has enough tiles to run without split-K (the split-K reduce kernel does not make them)."""
-    return (not _DISABLED and (H * W) % 128 == 0 and cout % 8 == 0 and _conv_tiles(N, H, W, cout) >= 256 and
+    """The producer takes the next GroupNorm's statistics when a 128-pixel block never straddles two samples (whole-K
+    tiles write them in their epilogue, split-K layers in their reduce kernel)."""
+    return (not _DISABLED and (H * W) % 128 == 0 and cout % 8 == 0 and
+            (_conv_tiles(N, H, W, cout) >= 256 or os.environ.get("GIP_SPLITK_STATS", "0") != "0") and
             os.environ.get("GIP_GN_STATS", "1") != "0")
+
+
+def _stats_rows(N, H, W, cin, cout):
+    """Rows per statistics block the 3x3 convolution can deliver for this shape: 128, 64 (samples of 64 pixels — the 8 x 8
+    level — which always run split-K: 64-row blocks come out of its reduce kernel) or 0 (none)."""
+    if stats_wanted(N, H, W, cout):
+        return 128
+    if (not _DISABLED and (H * W) % 64 == 0 and (H * W) % 128 != 0 and cout % 8 == 0 and cin >= 128 and
+            _conv_tiles(N, H, W, cout) < 256 and N * H * W * cout * 8 <= _SPLITK_WS_BYTES and
+            os.environ.get("GIP_GN_STATS", "1") != "0" and os.environ.get("GIP_SPLITK_STATS", "0") != "0"):
+        return 64
+    return 0
 
 
 class disabled:
@@ -276,13 +290,16 @@ def _conv_call(x, w, cout, bias=None, residual=None, stats=None):
     N, C, H, W = x.shape
     out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     null = ctypes.c_void_p(None)
-    if stats is not None and stats_wanted(N, H, W, cout):
-        st = torch.empty((N * H * W // 128, cout, 2), dtype=torch.float32, device=x.device)
-        rc = _lib.nn_lib().gip_conv3x3_stats_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias),
-                                                      null if residual is None else _p(residual), _p(out), N, H, W, C, cout,
-                                                      _p(st), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    rows = _stats_rows(N, H, W, C, cout) if stats is not None else 0
+    if rows:
+        st = torch.empty((N * H * W // rows, cout, 2), dtype=torch.float32, device=x.device)
+        ws = _workspace(x.device, _SPLITK_WS_BYTES) if _conv_tiles(N, H, W, cout) < 256 else None
+        rc = _lib.nn_lib().gip_conv3x3_stats_ws_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias),
+                                                         null if residual is None else _p(residual), _p(out), N, H, W, C, cout,
+                                                         _p(st), rows, null if ws is None else _p(ws), 0 if ws is None else ws.numel(),
+                                                         ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
-            raise RuntimeError("gip_conv3x3_stats_nhwc_f16 failed with status %d" % rc)
+            raise RuntimeError("gip_conv3x3_stats_ws_nhwc_f16 failed with status %d" % rc)
         stats.append(st)
         return out
     ws = _workspace(x.device, _SPLITK_WS_BYTES) if _conv_tiles(N, H, W, cout) < 256 else None
@@ -462,7 +479,7 @@ def _gn_fwd_raw(x, gn, addend, chan_stats):
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     if chan_stats is not None:
         rc = lib.gip_gn_silu_forward_stats(_p(x), _p(gn.weight), _p(gn.bias), _p(y), _p(mean), _p(rstd), N, H * W, C, gn.num_groups,
-                                           float(gn.eps), int(gn.act), ad_ptr, ad_stride, _p(chan_stats), (H * W) // 128, stream)
+                                           float(gn.eps), int(gn.act), ad_ptr, ad_stride, _p(chan_stats), chan_stats.shape[0] // N, stream)
     else:
         ws = _workspace(x.device, lib.gip_gn_workspace_bytes(N, gn.num_groups))
         rc = lib.gip_gn_silu_forward(_p(x), _p(gn.weight), _p(gn.bias), _p(y), _p(mean), _p(rstd), N, H * W, C, gn.num_groups,

@@ -226,7 +226,9 @@ class Attention(nn.Module):
         if self.heads == 1 and ip_ctx is None and q.is_cuda and q.dtype == torch.float16 and q.shape[-1] >= 256:
             # single wide head (the VAE's 512-channel mid attention): three dense GEMMs through hipBLASLt beat the
             # flash kernels at head dim 512 (forward and backward; measured in tools/exp_ab_vae.py)
-            p = torch.softmax(torch.baddbmm(q.new_zeros(()), q, k.transpose(1, 2), beta=0, alpha=q.shape[-1] ** -0.5), dim=-1)
+            # the scale goes onto q ([B, N, 512]) instead of into the product's alpha: autograd's backward of an alpha-scaled
+            # bmm multiplies the [B, N, N] score gradient (134 MB at 4 x 4096^2) by it in a pass of its own
+            p = torch.softmax(torch.bmm(q * (q.shape[-1] ** -0.5), k.transpose(1, 2)), dim=-1)
             return self._out(torch.bmm(p, v), residual)
         q = self._split(q)
         h = F.scaled_dot_product_attention(q, self._split(k), self._split(v))

@@ -124,6 +124,13 @@ int gip_conv3x3_gnbwd_nhwc_f16(const void* dy_in, const void* w, void* out, int3
                                int32_t Cout, const void* gn_x, const void* gamma, const void* beta, const float* mean,
                                const float* rstd, int32_t G, int32_t apply_silu, const void* addend, int32_t addend_stride,
                                float* chan_sums, void* stream);
+/* The same with a split-K workspace (may be NULL): layers with too few output tiles for the chip (the 16 x 16 and 8 x 8 levels)
+ * run split-K as in gip_conv3x3_nhwc_f16, and the kernel that sums the fp32 slabs also writes the statistics — per
+ * `stats_rows`-row block: 128, or 64 where a sample has only 64 pixels (H * W % stats_rows == 0; 64 requires the split-K
+ * route, i.e. a workspace and < 256 output tiles: returns 1 otherwise).  chan_stats [N * H * W / stats_rows][Cout][2]. */
+int gip_conv3x3_stats_ws_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
+                                  int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* chan_stats, int32_t stats_rows,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 /* gip_linear_f16 (no GEGLU) with the same per-(128-row block, column) statistics of its output. */
 int gip_linear_stats_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                          int32_t K, int32_t Nout, float* chan_stats, void* stream);
