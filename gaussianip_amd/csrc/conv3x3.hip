@@ -315,14 +315,16 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       const bool mine = tid < RPP * CH && co < Cout;
       // the residual rows this thread will add are requested FIRST (geom bit 29): their HBM latency then overlaps the
       // accumulator -> LDS staging and its barrier instead of starting after them
-      const bool res_early = residual && ((geom >> 29) & 1);
+      // (the data-gradient + GroupNorm-backward mode has no residual: its early rows are the GroupNorm input it reads instead)
+      const _Float16* early_src = residual ? residual : ((chan_stats && gnb.x) ? gnb.x : nullptr);
+      const bool res_early = early_src && ((geom >> 29) & 1);
       f16x8 rres[RPT];
       if (res_early && mine) {
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
           const int row = r0 + k * RPP;
           const unsigned m = m0 + row;
-          rres[k] = (row < CV_BM && m < M) ? *(const f16x8*)(residual + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          rres[k] = (row < CV_BM && m < M) ? *(const f16x8*)(early_src + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
       }
 #pragma unroll
@@ -362,7 +364,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
           *(f16x8*)(out + out_row(m) * Cout + co) = v;
           if (chan_stats) {
             if (gnb.x) {
-              gnb_accumulate(gnb, gl, v, *(const f16x8*)(gnb.x + (size_t)m * Cout + co), s8, q8);
+              gnb_accumulate(gnb, gl, v, res_early ? rres[k] : *(const f16x8*)(gnb.x + (size_t)m * Cout + co), s8, q8);
             } else {
 #pragma unroll
               for (int j = 0; j < 8; j++) { const float f = (float)v[j]; s8[j] += f; q8[j] = fmaf(f, f, q8[j]); }
@@ -626,7 +628,8 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   const int chunk = tid % CH, r0 = tid / CH;
   const int co = co0 + chunk * 8;
   const bool mine = co < Cout;
-  const bool res_early = residual && ((geom >> 29) & 1);
+  const _Float16* early_src = residual ? residual : ((chan_stats && gnb.x) ? gnb.x : nullptr);
+  const bool res_early = early_src && ((geom >> 29) & 1);
   float s8[2][8], q8[2][8];                               // statistics of the tile's two 128-row blocks
 #pragma unroll
   for (int b = 0; b < 2; b++)
@@ -645,7 +648,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
       for (int k = 0; k < RPF; k++) {
         const int row = r0 + k * RPP;
         const unsigned m = m0 + pass * PROWS + row;
-        rres[k] = (row < PROWS && m < M) ? *(const f16x8*)(residual + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        rres[k] = (row < PROWS && m < M) ? *(const f16x8*)(early_src + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
     if (PASSES == 1 || wr == pass) {
@@ -681,7 +684,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
         if (chan_stats) {
           const int blk = PASSES == 2 ? pass : (row >= 128 ? 1 : 0);
           if (gnb.x) {
-            const f16x8 xv = *(const f16x8*)(gnb.x + (size_t)m * Cout + co);
+            const f16x8 xv = (res_early && k < RPF) ? rres[k < RPF ? k : 0] : *(const f16x8*)(gnb.x + (size_t)m * Cout + co);
             if (blk == 0) gnb_accumulate(gnb, gl, v, xv, s8[0], q8[0]);
             else gnb_accumulate(gnb, gl, v, xv, s8[1], q8[1]);
           } else {

@@ -493,13 +493,13 @@ def _dgrad_with_gn_sums(dy, w, x_gn, gn, mean, rstd, addend):
     """(dL/dy_gn, chan_sums): the data gradient conv3x3(dy, w^T-flipped) of a convolution whose input was gn(x_gn), with the two
     reductions of that GroupNorm's backward taken in the kernel's epilogue (gip_conv3x3_gnbwd_nhwc_f16); chan_sums is None
     when the shape does not qualify (the caller's GroupNorm backward then takes its own reduction pass).
-    OPT-IN (GIP_GN_BWD_SUMS=1): measured neutral in a same-box A/B of the training step (39.2 ms with and without; VAE
-    forward + backward 15.15 vs 15.28 ms) — the epilogue's extra read of the GroupNorm input and its ~20 vector
-    instructions per element (dsilu) cost the data-gradient kernel what the separate reduction pass took; unlike the
-    forward statistics (two fmas per element, no extra read), which are on by default."""
+    GIP_GN_BWD_SUMS=0 switches it off.  It first measured neutral (the epilogue's extra read of the GroupNorm input and its
+    ~20 vector instructions per element (dsilu) cost the data-gradient kernel what the separate reduction pass took); with
+    the GroupNorm-input rows requested before the accumulators are staged through LDS (like the residual rows) it is worth
+    0.09 ms of the VAE's forward + backward (14.155 -> 14.065 ms, four same-box runs each)."""
     wt = _transposed_weight(w)
     N, C, H, W = x_gn.shape
-    if (os.environ.get("GIP_GN_BWD_SUMS", "0") != "1" or _DISABLED or (H * W) % 256 or C % 8 or _conv_tiles(N, H, W, C) < _GN_SUMS_MIN_TILES or
+    if (os.environ.get("GIP_GN_BWD_SUMS", "1") == "0" or _DISABLED or (H * W) % 256 or C % 8 or _conv_tiles(N, H, W, C) < _GN_SUMS_MIN_TILES or
             C // gn.num_groups > 256):
         return _conv_call(dy, wt, C), None
     out = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
