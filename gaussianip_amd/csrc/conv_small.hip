@@ -118,7 +118,9 @@ conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ 
 template <int CIN, int COUT, int STRIDE, int WN, int TR>
 __global__ void __launch_bounds__(256)
 conv_fewch_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w /* [COUT][3][3][CIN] */, const _Float16* __restrict__ bias,
-                  _Float16* __restrict__ out, int Hin, int Win, int Hout, int Wout, int act) {
+                  _Float16* __restrict__ out, int Hin, int Win, int Hout, int Wout, int act, int cout_real) {
+  // cout_real < COUT: the weight has COUT = 16 rows of which only the first cout_real are real (the 320 -> 4 / 512 -> 8 output
+  // convolutions of the U-Net / VAE encoder); bias and out have cout_real channels
   constexpr int WM = 4 / WN, MI = TR / WM, NI = COUT / 16 / WN;
   constexpr int HR = (TR - 1) * STRIDE + 3, HC = 15 * STRIDE + 3;
   constexpr int PSB = CIN * 2 + 16, CPP = CIN / 8;                         // pixel stride (bytes), 16-byte chunks per pixel
@@ -144,7 +146,7 @@ conv_fewch_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w
   f32x4 acc[NI][MI];
 #pragma unroll
   for (int ni = 0; ni < NI; ni++) {
-    const f16x4 b = bias ? *(const f16x4*)(bias + n0 + ni * 16 + kq * 4) : (f16x4){0, 0, 0, 0};
+    const f16x4 b = (bias && n0 + ni * 16 + kq * 4 < cout_real) ? *(const f16x4*)(bias + n0 + ni * 16 + kq * 4) : (f16x4){0, 0, 0, 0};
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) acc[ni][mi] = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
   }
@@ -176,20 +178,21 @@ conv_fewch_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w
   }
 #pragma unroll
   for (int mi = 0; mi < MI; mi++) {
-    _Float16* o = out + (((size_t)n * Hout + y0 + wm * MI + mi) * Wout + x0 + frow) * COUT + n0 + kq * 4;
+    _Float16* o = out + (((size_t)n * Hout + y0 + wm * MI + mi) * Wout + x0 + frow) * cout_real + n0 + kq * 4;
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
       const f32x4 a = acc[ni][mi];
       f16x4 h;
       h[0] = (_Float16)a[0]; h[1] = (_Float16)a[1]; h[2] = (_Float16)a[2]; h[3] = (_Float16)a[3];
       if (act) { h[0] = silu_h(h[0]); h[1] = silu_h(h[1]); h[2] = silu_h(h[2]); h[3] = silu_h(h[3]); }
-      *(f16x4*)(o + ni * 16) = h;
+      if (n0 + ni * 16 + kq * 4 < cout_real) *(f16x4*)(o + ni * 16) = h;
     }
   }
 }
 
 template <int CIN, int COUT, int STRIDE, int WN, int TR>
-static int launch_fewch(const void* x, const void* w, const void* bias, void* out, int N, int Hin, int Win, int act, hipStream_t s) {
+static int launch_fewch(const void* x, const void* w, const void* bias, void* out, int N, int Hin, int Win, int act, hipStream_t s,
+                        int cout_real = COUT) {
   const int Hout = Hin / STRIDE, Wout = Win / STRIDE;
   if ((Hin % STRIDE) || (Win % STRIDE) || (Hout % TR) || (Wout & 15)) return 1;
   constexpr int HR = (TR - 1) * STRIDE + 3, HC = 15 * STRIDE + 3;
@@ -201,13 +204,13 @@ static int launch_fewch(const void* x, const void* w, const void* bias, void* ou
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_fewch_kernel<CIN, COUT, STRIDE, WN, TR>), dim3((Hout / TR) * (Wout / 16), N), dim3(256), lds, s,
-                     (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, Hin, Win, Hout, Wout, act);
+                     (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, Hin, Win, Hout, Wout, act, cout_real);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 extern "C" int gip_conv3x3_fewch_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin, int32_t Win,
                                           int32_t Cin, int32_t Cout, int32_t stride, int32_t act, void* stream) {
-  if (!x || !w || !out || N < 1 || Hin < 16 || Win < 16 || (stride != 1 && stride != 2)) return 1;
+  if (!x || !w || !out || N < 1 || Hin < 1 || Win < 1 || (stride != 1 && stride != 2)) return 1;
   if ((long long)N * Hin * Win * (Cin > Cout ? Cin : Cout) * 2 >= (1ll << 40)) return 1;
   hipStream_t s = (hipStream_t)stream;
   if (Cin == 3 && stride == 1 && (Cout == 16 || Cout == 128)) {
@@ -229,6 +232,9 @@ extern "C" int gip_conv3x3_fewch_nhwc_f16(const void* x, const void* w, const vo
   if (Cin == 32 && Cout == 96 && stride == 2) return launch_fewch<32, 96, 2, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
   if (Cin == 96 && Cout == 96 && stride == 1) return launch_fewch<96, 96, 1, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
   if (Cin == 96 && Cout == 256 && stride == 2) return launch_fewch<96, 256, 2, 4, 4>(x, w, bias, out, N, Hin, Win, act, s);
+  // the narrow OUTPUT convolutions (conv_out of the U-Net: 320 -> 4, of the VAE encoder: 512 -> 8): w holds 16 rows, rows >= Cout zero
+  if (Cin == 320 && Cout == 4 && stride == 1) return launch_fewch<320, 16, 1, 1, 8>(x, w, bias, out, N, Hin, Win, act, s, 4);
+  if (Cin == 512 && Cout == 8 && stride == 1) return launch_fewch<512, 16, 1, 1, 4>(x, w, bias, out, N, Hin, Win, act, s, 8);
   return 1;
 }
 

@@ -814,6 +814,59 @@ def conv3x3_fewch(x, w, bias, stride=1, act=False):
     return F.silu(y) if act else y
 
 
+_NARROW_OUT_SHAPES = {(320, 4): 8, (512, 8): 4}       # (Cin, Cout) -> output rows per workgroup tile
+
+
+def _narrow_out_applies(x, w):
+    cin, cout = x.shape[1], w.shape[0]
+    return (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and (cin, cout) in _NARROW_OUT_SHAPES and
+            w.dtype == torch.float16 and tuple(w.shape[1:]) == (cin, 3, 3) and not w.requires_grad and
+            x.is_contiguous(memory_format=torch.channels_last) and x.shape[3] % 16 == 0 and
+            x.shape[2] % _NARROW_OUT_SHAPES[(cin, cout)] == 0 and os.environ.get("GIP_CONV_NARROW", "1") != "0")
+
+
+def _narrow_out_call(x, w, bias):
+    N, cin, H, W = x.shape
+    cout = w.shape[0]
+
+    def pad16(t):            # the kernel's weight block: 16 rows [co][ky][kx][ci], rows >= Cout zero
+        p = torch.zeros((16, cin, 3, 3), dtype=t.dtype, device=t.device)
+        p[:cout] = t.detach()
+        return p.contiguous(memory_format=torch.channels_last)
+    out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = _lib.nn_lib().gip_conv3x3_fewch_nhwc_f16(_p(x), _p(_wt_cache.get("pad16", w, pad16)), ctypes.c_void_p(None) if bias is None else _p(bias),
+                                                  _p(out), N, H, W, cin, cout, 1, 0, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("gip_conv3x3_fewch_nhwc_f16 failed with status %d" % rc)
+    return out
+
+
+class _NarrowOutConv(torch.autograd.Function):
+    """The differentiable form (VAE encoder conv_out): forward on the kernel, data gradient (8 -> 512 channels, 0.03 ms) on the library."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(w)
+        ctx.x_shape = tuple(x.shape)
+        return _narrow_out_call(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        return torch.nn.grad.conv2d_input(ctx.x_shape, w, dy.contiguous(memory_format=torch.channels_last), padding=1), None, None
+
+
+def conv3x3_narrow_out(x, w, bias):
+    """F.conv2d(x, w, bias, padding=1) for the two output convolutions with very few OUTPUT channels — conv_out of the U-Net
+    (320 -> 4) and of the VAE encoder (512 -> 8) — on csrc/conv_small.hip's halo-in-LDS kernel (the library needed a
+    convolution, a bias and a layout-copy kernel: 0.08 / 0.05 ms)."""
+    if _narrow_out_applies(x, w) and (bias is None or not bias.requires_grad):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _NarrowOutConv.apply(x, w, bias)
+        return _narrow_out_call(x, w, bias)
+    return F.conv2d(x, w, bias, padding=1)
+
+
 def conv3x3_few_inputs(x, w, bias):
     if (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.requires_grad and torch.is_grad_enabled() and
             not w.requires_grad and w.shape[1] <= 4 and w.shape[0] % 64 == 0 and

@@ -454,7 +454,7 @@ class UNet(_Encoder):
                 k += 1
             if i < 3:
                 h = self.up_sample[i](h)
-        return self.conv_out(self.norm_out(h))
+        return fused.conv3x3_narrow_out(self.norm_out(h), self.conv_out.weight, self.conv_out.bias)      # 320 -> 4
 
     @torch.no_grad()
     def fold_lora(self, scale=1.0):
@@ -543,7 +543,7 @@ class VAEEncoder(nn.Module):
         a = self.mid_attn(self.mid_norm(h).permute(0, 2, 3, 1).reshape(B, H * W, C))
         h = h + a.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = self.mid_res2(h)
-        return self.quant_conv(self.conv_out(self.norm_out(h)))
+        return self.quant_conv(fused.conv3x3_narrow_out(self.norm_out(h), self.conv_out.weight, self.conv_out.bias))      # 512 -> 8
 
     def encode(self, x, generator=None):
         """latent_dist.sample() * scaling_factor — stochastic and differentiable, like ipa_guidance.py:522-531."""

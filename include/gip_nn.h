@@ -152,7 +152,9 @@ int gip_conv3x3_c3_dgrad_nhwc_f16(const void* dy, const void* wt, void* dx, int3
  * (ipa_guidance.py:338-346).  x [N,Hin,Win,Cin] half, w [Cout,3,3,Cin] half (channels_last memory of the torch weight),
  * bias [Cout] or NULL -> out [N,Hin/stride,Win/stride,Cout]; act != 0: out = silu(half(conv + bias)) (torch's two
  * roundings).  Supported (Cin, Cout, stride): (3, 16 | 128, 1), (16, 16, 1), (16, 32, 2), (32, 32, 1), (32, 96, 2),
- * (96, 96, 1), (96, 256, 2); output width % 16 == 0, output height % 8 == 0 (% 16 for Cin = 3, % 4 for 96 -> 256); anything else returns 1. */
+ * (96, 96, 1), (96, 256, 2); output width % 16 == 0, output height % 8 == 0 (% 16 for Cin = 3, % 4 for 96 -> 256); anything else returns 1.
+ * Also the two narrow OUTPUT convolutions, (320, 4, 1) = conv_out of the U-Net and (512, 8, 1) = conv_out of the VAE encoder
+ * (output height % 8 / % 4): there w holds 16 rows [16,3,3,Cin] of which rows >= Cout are zero; bias / out have Cout channels. */
 int gip_conv3x3_fewch_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin, int32_t Win,
                                int32_t Cin, int32_t Cout, int32_t stride, int32_t act, void* stream);
 

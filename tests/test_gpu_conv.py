@@ -365,3 +365,29 @@ def test_upsample_then_convolution_by_parity_classes(N, C, Co, H, W, monkeypatch
     with torch.no_grad():
         two = fused.conv3x3(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b)
     assert float((out.float() - two.float()).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("cfg", [(320, 4, 3, 64, 64), (512, 8, 2, 64, 48), (320, 4, 1, 8, 16)])
+def test_narrow_output_convolutions(cfg):
+    """conv_out of the U-Net (320 -> 4) and of the VAE encoder (512 -> 8, differentiable) on the halo-in-LDS kernel."""
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    cin, cout, N, H, W = cfg
+    g = torch.Generator(device="cuda").manual_seed(cin + H)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, cin, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3 * cin ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(cout, device="cuda", generator=g).half()
+    before = _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0)
+    with torch.no_grad():
+        out = fused.conv3x3_narrow_out(x, w, b)
+    assert _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0) == before + 1, "the HIP kernel did not run"
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    assert out.shape == ref.shape and float((out.float() - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+    # differentiable form: forward on the kernel, dL/dx from the library
+    xg = x.clone(**cl).requires_grad_(True)
+    y = fused.conv3x3_narrow_out(xg, w, b)
+    dy = torch.randn(y.shape, device="cuda", generator=g).half().contiguous(**cl)
+    (dx,) = torch.autograd.grad(y, xg, dy)
+    dxr = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), padding=1)
+    assert torch.equal(y, out) and float((dx.float() - dxr).abs().max()) <= 2e-3 * max(1.0, float(dxr.abs().max()))
