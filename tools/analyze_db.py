@@ -11,9 +11,13 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 marks = [r[0] for r in db.execute("select start from kernels where name like ? order by start", ("%" + marker + "%",))]
 lo, hi, nstep = marks[-5], marks[-1], 4
 rows = db.execute("select name, count(*), sum(end-start) from kernels where start>=? and start<? group by name", (lo, hi)).fetchall()
-FAM = [("raster(gip)", r"gip_"), ("gn_fused", r"gn_reduce|gn_apply"), ("conv_bwd", r"igemm_bwd|igemm_wrw|bwd_data|wrw"),
+# conv3x3_kernel<BN, 2, TAPS = 1, ...> is the MFMA nn.Linear / 1x1 convolution on the convolution kernel: its own family, so that
+# "conv_fwd" is the 3x3 convolutions (forward and data gradient, incl. the split-K reduce and the few-channel kernels)
+FAM = [("raster(gip)", r"gip_"), ("gn_fused", r"gn_reduce|gn_apply|gn_finalize"), ("conv_bwd", r"igemm_bwd|igemm_wrw|bwd_data|wrw"),
+       ("linear(gip mfma)", r"conv3x3_kernelILi\d+ELi2ELi1E"),
        ("conv_fwd", r"igemm_fwd|Conv|conv"), ("miopen_aux", r"SubTensorOp|batched_transpose|transpose"),
-       ("gemm", r"Cijk|gemm|GEMM"), ("attention", r"attn|fmha|flash|Fmha"), ("layernorm", r"layer_norm|LayerNorm"),
+       ("gemm", r"Cijk|gemm|GEMM"), ("attention", r"attn|fmha|flash|Fmha"), ("layernorm", r"layer_norm|LayerNorm|layernorm"),
+       ("glue(gip)", r"geglu_kernel|cat2_stats|add_bias_residual"),
        ("groupnorm_torch", r"RowwiseMoments|GroupNorm|group_norm"), ("softmax", r"softmax"), ("adam", r"adam|Adam|multi_tensor"),
        ("elementwise", r"elementwise|vectorized|CatArray|index|copy|fill|upsample|reduce")]
 tot = sum(r[2] for r in rows)
