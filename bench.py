@@ -300,7 +300,10 @@ def main():
                 lib_sha = hashlib.sha256(open(os.path.join(ROOT, "gaussianip_amd", "lib", "libgip_raster.so"), "rb").read()).hexdigest()[:16]
                 stamp = pmc.get("_build", {})
                 c = pmc.get(dom, {})
-                if stamp.get("libgip_raster_sha16") != lib_sha:
+                if Vl != 4:
+                    # the passes were taken on the 4-view launch of N = 1; a rank of an N-GPU run launches fewer views
+                    pmc_note = "profiles/pmc.json holds counters of the 4-view launch; this rank launches %d view(s): counters withheld" % Vl
+                elif stamp.get("libgip_raster_sha16") != lib_sha:
                     # counters of ANOTHER build of the kernels: not this line's business (they went stale silently)
                     pmc_note = "profiles/pmc.json was collected on libgip_raster %s, this run uses %s: counters withheld" % (
                         stamp.get("libgip_raster_sha16"), lib_sha)
