@@ -15,7 +15,15 @@
 //   * the MFMA's A operand is the weight tile (rows = output channels) and B the pixel tile, so a lane's four
 //     accumulator registers are four consecutive output channels of one pixel = one 8-byte NHWC store;
 //   * blockIdx -> tile is remapped so that the tiles sharing a pixel block (same activations, different channel
-//     blocks) are consecutive on ONE XCD and hit in its L2.
+//     blocks) are consecutive on ONE XCD and hit in its L2;
+//   * the epilogue stages the half-rounded tile through the (free) stage buffers and writes whole 16-byte row chunks; the
+//     residual rows it adds are requested before that staging; optionally it also leaves the per-channel sums the NEXT
+//     GroupNorm needs (forward statistics, or — as a data-gradient kernel — that GroupNorm's two backward reductions).
+// Also in this file: conv_big_kernel (256 x 256 tile, 8 waves, one workgroup per CU, for the VAE's 256 / 512-channel levels),
+// TAPS = 1 = nn.Linear / 1x1 convolution (+ GEGLU) on the same machinery, split-K with its reduce kernels, and the
+// TAP-SUBSET mode (`tapsel`): a launch visits only some of the nine taps and scatters its output to one parity class of a
+// tensor of twice the size — the data gradient of a stride-2 convolution and nearest-2x-upsample + convolution, each as
+// four small convolutions over the source grid (gip_conv3x3s2_dgrad_nhwc_f16, gip_upsample2x_conv3x3_nhwc_f16).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

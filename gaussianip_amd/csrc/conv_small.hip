@@ -1,16 +1,17 @@
-// conv_small.hip — the two 3x3 convolutions of the VAE encoder that the 128-channel implicit GEMM (conv3x3.hip) does not
-// fit: conv_in (3 -> 128 channels over the full-resolution image) and its data gradient (128 -> 3 channels, the gradient
-// that leaves the VAE towards the rasterizer).  See include/gip_nn.h (gip_conv3x3_c3_fwd_nhwc_f16 / _dgrad_).
+// conv_small.hip — the 3x3 convolutions that the 128-channel implicit GEMM (conv3x3.hip) does not fit, because one side of
+// them is narrow.  See include/gip_nn.h (gip_conv3x3_c3_fwd_nhwc_f16 / _dgrad_, gip_conv3x3_fewch_nhwc_f16).
 //
-// Both are bound by ONE pass over the 128-channel tensor (268 MB at 4 x 512^2): the library route took a MIOpen kernel, a
-// bias kernel and an NCHW -> NHWC copy forward (0.25 ms), and the 128-wide MFMA tile with 4 of its 128 output channels
-// used backward (0.32 ms).  Here:
-//   forward   16 x 16 pixel tile per workgroup, the 18 x 18 x 3 input patch in LDS, K = 27 (padded to 32) in ONE
-//             v_mfma_f32_16x16x32_f16 per 16 pixels x 16 channels, weights held in registers as the A operand, bias in the
-//             epilogue, 16-byte coalesced stores through an LDS transpose;
-//   dgrad     8 x 16 pixel tile, its 10 x 18 pixel halo of dy (46 KB) brought in ONCE by LDS-DMA (16-byte chunks XOR-
-//             swizzled on the source address so that the 16-pixel fragment reads are conflict-free) and reused by all nine
-//             taps; the rearranged weight [3][9][128] sits in LDS; 36 K steps of 32 per 16 pixels; 6-byte stores.
+//   conv_c3_fwd_kernel<CO>   3 input channels -> 16 / 128 (VAE encoder conv_in, ControlNet stem conv_in): 16 x 16 pixel tile,
+//             the 18 x 18 x 3 input patch in LDS, K = 27 (padded to 32) in ONE v_mfma_f32_16x16x32_f16 per 16 pixels x 16
+//             channels, weights held in registers as the A operand, bias (+ SiLU) in the epilogue, 16-byte coalesced
+//             stores through an LDS transpose.  Bound by one pass over the output tensor (268 MB at 4 x 512^2 x 128).
+//   conv_c3_dgrad_kernel     128 -> 3 (the gradient that leaves the VAE towards the rasterizer): 8 x 16 pixel tile, its
+//             10 x 18 pixel halo of dy (46 KB) brought in ONCE by LDS-DMA (16-byte chunks XOR-swizzled on the source
+//             address so that the 16-pixel fragment reads are conflict-free) and reused by all nine taps; the rearranged
+//             weight [3][9][128] sits in LDS; 36 K steps of 32 per 16 pixels; 6-byte stores.
+//   conv_fewch_kernel<CIN, COUT, STRIDE>   16 / 32 / 96-channel layers of the ControlNet's conditioning stem (stride 1 and
+//             2, bias + SiLU in the epilogue) and the two narrow OUTPUT convolutions 320 -> 4, 512 -> 8: input halo once
+//             in LDS, weights straight from L2 one K step ahead, the weight as the MFMA A operand (documented at the kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
