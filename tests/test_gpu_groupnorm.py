@@ -241,7 +241,7 @@ def test_linear_epilogue_statistics_feed_the_next_groupnorm():
 # ---- the U-Net decoder's skip concatenation: skip + ControlNet residual, torch.cat and norm1's statistics in one pass
 # (gip_cat2_stats_f16) ----
 @pytest.mark.parametrize("shape", [(8, 1280, 1280, 16, 16), (8, 1280, 640, 32, 32), (8, 640, 320, 64, 64), (2, 320, 320, 64, 64),
-                                   (8, 1280, 1280, 8, 8), (1, 64, 128, 8, 16)])
+                                   (8, 1280, 1280, 8, 8), (1, 64, 128, 8, 16), (1, 64, 128, 5, 7), (3, 128, 64, 3, 1)])     # the last two: ragged row counts
 @pytest.mark.parametrize("with_residual", [True, False])
 def test_skip_concatenation_with_residual_and_statistics(shape, with_residual):
     from gaussianip_amd import _lib
