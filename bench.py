@@ -192,6 +192,19 @@ def main():
         fwd_step()
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    # an OUTPUT render (torch.no_grad(): orbit frames, the refine pass' inputs): GipRasterConfig::forward_only — the kernel
+    # skips the checkpoints and the n_contrib / final_T images — and the capacity header is awaited in every call
+    def nograd_step():
+        with torch.no_grad():
+            return rasterize_views(t["means3D"], None, t["opacities"], sts, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    for _ in range(3):
+        nograd_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nograd_step()
+    torch.cuda.synchronize()
+    nograd_ms = (time.perf_counter() - t0) / args.steps * 1e3
 
     # ---- the same step on a TRAINED-looking state (secondary: the headline config is the init state SURVEY §8d prescribes)
     trained = None
@@ -396,7 +409,9 @@ def main():
                               V, shard.group_size, shard.n_seed_groups)},
                "window_ms_per_step": [round(w_ / args.steps * 1e3, 4) for w_ in windows],
                "raster_steps_per_s": round(1e3 / ms_per_step, 3), "views_per_s": round(views_total / elapsed, 2),
-               "forward_only": {"ms_per_step": round(fwd_ms, 4), "mpix_per_s_per_gpu": round(Vl * H * W / fwd_ms / 1e3, 1)},
+               "forward_only": {"ms_per_step": round(fwd_ms, 4), "mpix_per_s_per_gpu": round(Vl * H * W / fwd_ms / 1e3, 1),
+                                "no_grad_render_ms_per_call": round(nograd_ms, 4),
+                                "note": "ms_per_step: forward with the state a backward needs, capacity check deferred; no_grad_render: forward_only kernels, header awaited per call"},
                "trained_state": trained,
                "exact_lists": exact,
                "replicas_layout": replicas,

@@ -22,7 +22,7 @@ class GipRasterConfig(ctypes.Structure):
                 ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32), ("prefiltered", ctypes.c_int32),
                 ("debug", ctypes.c_int32), ("scale_modifier", ctypes.c_float),
                 ("tanfovx", ctypes.c_float * GIP_MAX_VIEWS), ("tanfovy", ctypes.c_float * GIP_MAX_VIEWS),
-                ("capacity", ctypes.c_uint64), ("exact_lists", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("capacity", ctypes.c_uint64), ("exact_lists", ctypes.c_int32), ("forward_only", ctypes.c_int32)]
 
 
 class GipRasterInputs(ctypes.Structure):

@@ -80,6 +80,7 @@ static void fill_params(const GipRasterConfig* c, const GipRasterStateLayout& L,
   kp->scale_modifier = c->scale_modifier;
   kp->capacity = (uint32_t)c->capacity;
   kp->exact_lists = c->exact_lists ? 1 : 0;
+  kp->forward_only = c->forward_only ? 1 : 0;
   kp->ckpt_capacity = (uint32_t)(c->capacity / GIP_SEGMENT + 1);
   kp->seg_capacity = kp->ckpt_capacity + (uint32_t)(kp->V * kp->T);
   for (int v = 0; v < c->V; v++) {
@@ -232,6 +233,7 @@ static int backward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, 
   int rc = check_inputs(cfg, in);
   if (rc != GIP_OK) return rc;
   if (!gin || !gin->alpha || !gin->color || !gin->depth || !gout || !state || !scratch) return GIP_ERR_BAD_ARGUMENT;
+  if (cfg->forward_only) return GIP_ERR_BAD_ARGUMENT;      // that forward kept nothing for a backward
   GipRasterStateLayout L;
   gip_raster_state_layout(cfg, &L);
   if (state_bytes < L.total || scratch_bytes < gip_raster_scratch_bytes(cfg)) return GIP_ERR_BUFFER_TOO_SMALL;

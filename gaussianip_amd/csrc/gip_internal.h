@@ -46,6 +46,7 @@ struct GipKernelParams {
   uint32_t seg_capacity;    // capacity / GIP_SEGMENT + V*T
   uint32_t ckpt_capacity;   // capacity / GIP_SEGMENT
   int exact_lists;          // GipRasterConfig::exact_lists
+  int forward_only;         // GipRasterConfig::forward_only: nothing is kept for a backward
   GipViewConst view[GIP_MAX_VIEWS];
 };
 

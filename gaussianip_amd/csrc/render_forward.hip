@@ -175,7 +175,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
           // this tile as an independent work item (render_backward.hip).  The two lane halves hold partial sums.
           const float s0 = CG.x + xchg32(CG.x, hh), s1 = CG.y + xchg32(CG.y, hh), s2 = BD.x + xchg32(BD.x, hh), sd = BD.y + xchg32(BD.y, hh);
           const uint32_t slot = ckpt_start[vt] + rel / GIP_SEGMENT - 1;
-          if (slot < kp.ckpt_capacity && hh == 0) {
+          if (slot < kp.ckpt_capacity && hh == 0 && !kp.forward_only) {
             float* cp = checkpoints + (size_t)slot * (GIP_CKPT_FLOATS * GIP_BLOCK) + cpix;
             cp[0] = T; cp[GIP_BLOCK] = s0; cp[2 * GIP_BLOCK] = s1; cp[3 * GIP_BLOCK] = s2; cp[4 * GIP_BLOCK] = sd;
           }
@@ -256,8 +256,10 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
     oc[2 * HW + pix] = C2 + T * bg[2];
     out_depth[(size_t)v * HW + pix] = Dp;
     out_alpha[(size_t)v * HW + pix] = Wt;
-    n_contrib[(size_t)v * HW + pix] = last_contributor;
-    final_T[(size_t)v * HW + pix] = T;
+    if (!kp.forward_only) {          // the backward's inputs; a forward-only render (GipRasterConfig::forward_only) skips them
+      n_contrib[(size_t)v * HW + pix] = last_contributor;
+      final_T[(size_t)v * HW + pix] = T;
+    }
   }
 }
 

@@ -110,7 +110,7 @@ class _Plan:
     pass
 
 
-def _make_config(P, V, H, W, sh_degree, M, scale_modifier, tanfovx, tanfovy, capacity, prefiltered, debug):
+def _make_config(P, V, H, W, sh_degree, M, scale_modifier, tanfovx, tanfovy, capacity, prefiltered, debug, forward_only=False):
     cfg = _lib.GipRasterConfig()
     cfg.P, cfg.V, cfg.H, cfg.W = int(P), int(V), int(H), int(W)
     cfg.sh_degree, cfg.sh_coeffs = int(sh_degree), int(M)
@@ -121,6 +121,7 @@ def _make_config(P, V, H, W, sh_degree, M, scale_modifier, tanfovx, tanfovy, cap
         cfg.tanfovy[v] = float(tanfovy[v])
     cfg.capacity = int(capacity)
     cfg.exact_lists = 1 if _exact_lists() else 0
+    cfg.forward_only = 1 if forward_only else 0
     return cfg
 
 
@@ -132,11 +133,11 @@ def _check(rc, what):
         raise RuntimeError(msg)
 
 
-def _run_forward(plan, capacity):
+def _run_forward(plan, capacity, forward_only=False):
     lib = _lib.raster_lib()
     dev = plan.means3D.device
     cfg = _make_config(plan.P, plan.V, plan.H, plan.W, plan.sh_degree, plan.M, plan.scale_modifier, plan.tanfovx,
-                       plan.tanfovy, capacity, plan.prefiltered, plan.debug)
+                       plan.tanfovy, capacity, plan.prefiltered, plan.debug, forward_only)
     nbytes = lib.gip_raster_state_bytes(ctypes.byref(cfg))
     if nbytes == 0:
         raise ValueError("invalid rasterizer configuration (P=%d V=%d H=%d W=%d sh_degree=%d)" %
@@ -234,7 +235,9 @@ def settle_pending():
     _drain_pending(block=True)
 
 
-def _forward_with_policy(plan, need_backward):
+def _forward_with_policy(plan, need_backward, forward_only=False):
+    """`forward_only`: the state will never be handed to the backward (a render under torch.no_grad()): the kernel skips what
+    only the backward reads (GipRasterConfig::forward_only).  Not set by forward_with_state, whose callers inspect the state."""
     _drain_pending()
     key = _hint_key(plan.means3D.device, plan.P, plan.V, plan.H, plan.W)
     cap = _pick_capacity(key, plan.P, plan.V)
@@ -242,7 +245,7 @@ def _forward_with_policy(plan, need_backward):
     if cap is None:
         cap = max(_MIN_CAPACITY, 8 * plan.P * plan.V)
     while True:
-        outs = _run_forward(plan, cap)
+        outs = _run_forward(plan, cap, forward_only and os.environ.get("GIP_RASTER_FORWARD_ONLY", "1") != "0")
         ev, host = _read_header_async(plan)
         if not sync_now:
             plan.pending = [ev, host, key, cap]
@@ -373,7 +376,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # `need_bwd` is decided by the caller (grad mode is always off inside Function.forward and
         # ctx.needs_input_grad ignores torch.no_grad()): a backward will follow, so the overflow check may be deferred
         plan = _build_plan(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list)
-        color, radii, depth, alpha = _forward_with_policy(plan, need_bwd)
+        color, radii, depth, alpha = _forward_with_policy(plan, need_bwd, forward_only=not need_bwd)
         ctx.plan = plan
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(color, depth, alpha)

@@ -79,7 +79,11 @@ typedef struct GipRasterConfig {
                              entries that cannot contribute, every output is unchanged.  1: every tile of the fork's
                              3-sigma rectangle gets its instance: tiles_touched, num_rendered, the sorted key / value
                              lists and the tile ranges are bit-for-bit the fork's (parity tests run both). */
-  int32_t reserved;
+  int32_t forward_only;   /* 0 (default): the forward leaves in `state` what gip_raster_backward needs.  1: no backward will
+                             follow (rendering under torch.no_grad(): orbit renders, the refine pass' inputs) — the render
+                             kernel then skips the per-segment blend-state checkpoints and the n_contrib / final_T images
+                             (~100 MB of writes per 4 x 1024^2 launch); outputs are bit-identical, and gip_raster_backward on
+                             such a state returns GIP_ERR_BAD_ARGUMENT.  (This field was `reserved`; the layout is unchanged.) */
 } GipRasterConfig;
 
 /* Device inputs.  Exactly one of (shs, colors_precomp) and one of (scales+rotations, cov3D_precomp)

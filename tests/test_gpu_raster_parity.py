@@ -455,3 +455,42 @@ def test_backward_parity_on_opaque_adversarial_scenes(oracle, seed):
         _check_backward(oracle, "stress", P, H, W, seed, 1, scene=sc, cam=cam, tol=1e-2, tol_e2e=1e-1, geom_tol=5e-2)
     finally:
         oracle.set_threads(1)
+
+
+def test_forward_only_render_is_bit_identical_and_keeps_nothing_for_a_backward(monkeypatch):
+    """GipRasterConfig::forward_only (set for renders under torch.no_grad()): same images and radii bit for bit, long tile
+    lists included (several 64-entry segments per tile = checkpoints skipped), and the C entry point refuses a backward on
+    such a state."""
+    import ctypes
+    from gaussianip_amd import _lib, rasterize_views
+    from gaussianip_amd import rasterizer as rz
+    P, H, W = 20000, 128, 160
+    sc = scenes.make_scene("stress", P, seed=11, sh_degree=1)
+    cams = scenes.train_cameras(3, 4, H, W)
+    sts = [_settings(c, H, W, (0.1, 0.2, 0.3), 1) for c in cams]
+    t = {k: _dev(v) for k, v in sc.items()}
+
+    def render(grad):
+        tt = {k: v.clone().requires_grad_(grad) for k, v in t.items()}
+        ctx = torch.enable_grad() if grad else torch.no_grad()
+        with ctx:
+            return rasterize_views(tt["means3D"], None, tt["opacities"], sts, shs=tt["shs"], scales=tt["scales"], rotations=tt["rotations"])
+    seen = []
+    orig = rz._run_forward
+    monkeypatch.setattr(rz, "_run_forward", lambda plan, cap, fo=False: (seen.append(bool(fo)), orig(plan, cap, fo))[1])
+    with_state = render(True)
+    without = render(False)
+    assert seen[0] is False and seen[-1] is True, seen
+    for a, b in zip(with_state, without):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("GIP_RASTER_FORWARD_ONLY", "0")
+    again = render(False)
+    assert seen[-1] is False and all(torch.equal(a, b) for a, b in zip(with_state, again))
+    # the C-ABI refuses a backward on a state whose forward kept nothing
+    monkeypatch.setattr(rz, "_run_forward", orig)
+    monkeypatch.delenv("GIP_RASTER_FORWARD_ONLY")
+    plan = rz._build_plan(t["means3D"], t["shs"], None, t["opacities"], t["scales"], t["rotations"], None, sts)
+    color, radii, depth, alpha = rz._forward_with_policy(plan, False, forward_only=True)
+    assert plan.cfg.forward_only == 1 and torch.equal(color, with_state[0])
+    with pytest.raises(ValueError):
+        rz._run_backward(plan, (color, depth, alpha), torch.ones_like(color), None, None)
