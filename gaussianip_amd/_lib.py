@@ -201,6 +201,12 @@ def nn_lib():
         lib.gip_conv3x3s2_dgrad_nhwc_f16.argtypes = [_vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp]
         lib.gip_upsample2x_conv3x3_nhwc_f16.restype = ctypes.c_int
         lib.gip_upsample2x_conv3x3_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp]
+        lib.gip_winograd_input_f16.restype = ctypes.c_int
+        lib.gip_winograd_input_f16.argtypes = [_vp, _vp] + [ctypes.c_int32] * 4 + [_vp]
+        lib.gip_winograd_output_f16.restype = ctypes.c_int
+        lib.gip_winograd_output_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]
+        lib.gip_winograd_output_stats_f16.restype = ctypes.c_int
+        lib.gip_winograd_output_stats_f16.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]
         lib.gip_conv3x3_fewch_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_fewch_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 7 + [_vp]
         lib.gip_conv3x3_c3_fwd_nhwc_f16.restype = ctypes.c_int

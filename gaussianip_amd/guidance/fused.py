@@ -336,11 +336,63 @@ class _Conv3x3(torch.autograd.Function):
         return dx, None, None, (dy if ctx.has_res else None), None
 
 
+def _winograd_weight(w):
+    """U [16][Cout][Cin] = (G g G^T)[i][j] of the 3x3 weight, fp32 arithmetic, one rounding to half."""
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32, device=w.device)
+    g = w.detach().float()                                     # [co, ci, 3, 3]
+    U = torch.einsum("ik,ockl,jl->ijoc", G, g, G)             # [4, 4, co, ci]
+    return U.reshape(16, w.shape[0], w.shape[1]).to(w.dtype).contiguous()
+
+
+def _winograd_applies(x, w, residual):
+    """Where F(2x2, 3x3) beats the implicit GEMM (tools/diag/winograd_feasibility.py): >= 1280 input channels on a 16 x 16 grid;
+    at 32 x 32 / 640 channels and at 8 x 8 (weight-bound) the transforms eat the gain.  Frozen weights, no gradient path."""
+    N, C, H, W = x.shape
+    return (os.environ.get("GIP_WINOGRAD", "1") != "0" and fusable(x) and w.dtype == torch.float16 and not w.requires_grad and
+            tuple(w.shape[2:]) == (3, 3) and C >= 1280 and w.shape[0] % 8 == 0 and H == 16 and W == 16 and N * H * W >= 2048 and
+            not (torch.is_grad_enabled() and x.requires_grad) and (residual is None or fusable(residual)))
+
+
+def _winograd_conv(x, w, bias, residual, stats=None):
+    """`stats`: a list that receives the output's chan_stats (see producer_stats) — the output transform takes them."""
+    N, C, H, W = x.shape
+    cout = w.shape[0]
+    T = N * (H // 2) * (W // 2)
+    lib = _lib.nn_lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    V = torch.empty((16, T, C), dtype=x.dtype, device=x.device)
+    rc = lib.gip_winograd_input_f16(_p(x), _p(V), N, H, W, C, stream)
+    if rc != 0:
+        raise RuntimeError("gip_winograd_input_f16 failed with status %d" % rc)
+    M = torch.bmm(V, _wt_cache.get("wino", w, _winograd_weight).transpose(1, 2))          # sixteen GEMMs: one batched library call
+    out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    null = ctypes.c_void_p(None)
+    if W in (16, 32) and (H * W) % 128 == 0:
+        st = None
+        if stats is not None and cout // 32 <= 256 and os.environ.get("GIP_GN_STATS", "1") != "0":
+            st = torch.empty((N * H * W // 128, cout, 2), dtype=torch.float32, device=x.device)
+            stats.append(st)
+        rc = lib.gip_winograd_output_stats_f16(_p(M), null if bias is None else _p(bias), null if residual is None else _p(residual),
+                                               _p(out), null if st is None else _p(st), N, H, W, cout, stream)
+    else:
+        rc = lib.gip_winograd_output_f16(_p(M), null if bias is None else _p(bias), null if residual is None else _p(residual), _p(out),
+                                         N, H, W, cout, stream)
+    if rc != 0:
+        raise RuntimeError("gip_winograd_output_f16 failed with status %d" % rc)
+    return out
+
+
 def conv3x3(x, w, bias=None, residual=None, gn_next=False):
     """F.conv2d(x, w, bias, padding=1) (+ residual) for a 3x3 kernel.  fp16 NHWC activations with Cin % 64 == 0 and
     enough output tiles to fill the chip run on the hand-written MFMA implicit GEMM with bias / residual in its
     epilogue; everything else goes to MIOpen.  `gn_next`: the result feeds a GroupNorm — the kernel's epilogue then also
     takes that GroupNorm's per-channel sums (attached to the returned tensor, see producer_stats)."""
+    if _winograd_applies(x, w, residual) and (bias is None or not bias.requires_grad):
+        if not gn_next:
+            return _winograd_conv(x, w, bias, residual)
+        holder = []
+        out = _winograd_conv(x, w, bias, residual, holder)
+        return attach_stats(out, holder[0] if holder else None)
     if (fusable(x) and x.shape[1] % 64 == 0 and w.shape[0] % 4 == 0 and w.dtype == torch.float16 and
             not w.requires_grad and w.is_contiguous(memory_format=torch.channels_last) and
             (bias is None or not bias.requires_grad) and (residual is None or fusable(residual)) and

@@ -184,6 +184,25 @@ int gip_conv3x3s2_dgrad_nhwc_f16(const void* dy, const void* wt4, void* dx, int3
 int gip_upsample2x_conv3x3_nhwc_f16(const void* x, const void* wt4, const void* bias, void* out, int32_t N, int32_t Hin,
                                     int32_t Win, int32_t Cin, int32_t Cout, void* stream);
 
+/* Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions of the 16 x 16 level (csrc/winograd.hip): the two transforms
+ * around ONE batched library GEMM.  T = N * (H / 2) * (W / 2) output tiles of 2 x 2 pixels; H, W even; C % 8 == 0.
+ *   gip_winograd_input_f16   x [N,H,W,C] half -> V [16][T][C] half, V[4 i + j] = (B^T d B)[i][j] of the 4 x 4 patch at
+ *                            (2 ty - 1, 2 tx - 1) (zeros outside the image);
+ *   (caller)                 M[p] = V[p] U[p]^T for p = 0..15, U [16][Cout][Cin] half = (G g G^T)[i][j] of the weight, made once in
+ *                            fp32 — a batched GEMM [16, T, Cin] x [16, Cin, Cout] -> M [16][T][Cout] half;
+ *   gip_winograd_output_f16  M -> out [N,H,W,Cout] half = A^T M A + bias (+ residual, added to the half-rounded result as the
+ *                            implicit GEMM does).
+ * 4 multiplications per output element and channel pair instead of 9; replaces the same F.conv2d calls as
+ * gip_conv3x3_nhwc_f16 where the GEMMs dominate the transforms (measured: only the 1280 / 1920 / 2560-channel layers at
+ * 16 x 16).  fp16 Winograd adds rounding of V and M: ~2x the implicit GEMM's error against fp32 (tests/test_gpu_conv.py). */
+int gip_winograd_input_f16(const void* x, void* V, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int gip_winograd_output_f16(const void* M, const void* bias, const void* residual, void* out, int32_t N, int32_t H, int32_t W,
+                            int32_t C, void* stream);
+/* gip_winograd_output_f16 that also writes chan_stats [N * H * W / 128][C][2] (may be NULL): the statistics of the GroupNorm
+ * that consumes `out`, per 128 consecutive pixels and channel, as gip_conv3x3_stats_nhwc_f16 does.  W = 16 or 32, H * W % 128 == 0. */
+int gip_winograd_output_stats_f16(const void* M, const void* bias, const void* residual, void* out, float* chan_stats, int32_t N,
+                                  int32_t H, int32_t W, int32_t C, void* stream);
+
 /* nn.Linear on the same MFMA machinery (TAPS = 1): out[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]) (+ residual[m][n]),
  * x [M,K], w [Nout,K] (torch Linear weight), out [M,Nout] half, fp32 accumulation, K % 64 == 0.  geglu != 0: w has
  * 2*Nout rows [value | gate], bias 2*Nout, out = (xWv + bv) * gelu(xWg + bg) — diffusers' GEGLU feed-forward input

@@ -391,3 +391,47 @@ def test_narrow_output_convolutions(cfg):
     (dx,) = torch.autograd.grad(y, xg, dy)
     dxr = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), padding=1)
     assert torch.equal(y, out) and float((dx.float() - dxr).abs().max()) <= 2e-3 * max(1.0, float(dxr.abs().max()))
+
+
+# ---- Winograd F(2x2, 3x3) at the 16 x 16 level (gip_winograd_input_f16 / _output_f16 around one batched GEMM) ----
+@pytest.mark.parametrize("cfg", [(12, 1280, 1280, True), (12, 2560, 1280, False), (8, 1920, 1280, True), (8, 1280, 640, False)])
+def test_winograd_convolution_at_the_16x16_level(cfg, monkeypatch):
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setenv("GIP_WINOGRAD", "1")
+    N, cin, cout, with_res = cfg
+    H = W = 16
+    g = torch.Generator(device="cuda").manual_seed(cin + cout)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, cin, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (3 * cin ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(cout, device="cuda", generator=g).half()
+    r = torch.randn(N, cout, H, W, device="cuda", generator=g).half().contiguous(**cl) if with_res else None
+    ran = lambda: _lib.call_counts.get("gip_winograd_output_f16", 0) + _lib.call_counts.get("gip_winograd_output_stats_f16", 0)  # noqa: E731
+    before = ran()
+    with torch.no_grad():
+        out = fused.conv3x3(x, w, b, r)
+        monkeypatch.setenv("GIP_WINOGRAD", "0")
+        direct = fused.conv3x3(x, w, b, r)
+    assert ran() == before + 1, "the Winograd path did not run"
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + (0 if r is None else r.float())
+    scale = max(1.0, float(ref.abs().max()))
+    e_w, e_d = float((out.float() - ref).abs().max()), float((direct.float() - ref).abs().max())
+    # fp16 Winograd rounds the transformed input and the sixteen products once more: allow 3x the implicit GEMM's bound
+    assert e_d <= 1.5e-3 * scale and e_w <= 4.5e-3 * scale, (e_w / scale, e_d / scale)
+    rms_w = float((out.float() - ref).pow(2).mean().sqrt())
+    rms_d = float((direct.float() - ref).pow(2).mean().sqrt())
+    assert rms_w <= 4.0 * rms_d + 1e-4, (rms_w, rms_d)
+    # borders: the zero padding enters through the input transform's out-of-image taps
+    err = (out.float() - ref).abs()
+    edge = torch.cat([err[:, :, 0].flatten(), err[:, :, -1].flatten(), err[:, :, :, 0].flatten(), err[:, :, :, -1].flatten()])
+    assert float(edge.max()) <= 4.5e-3 * scale
+    # with the following GroupNorm's statistics taken by the output transform: same tensor, sums of what was written
+    monkeypatch.setenv("GIP_WINOGRAD", "1")
+    with torch.no_grad():
+        out2 = fused.conv3x3(x, w, b, r, gn_next=True)
+    st = fused.producer_stats(out2)
+    assert torch.equal(out2, out) and st is not None and st.shape == (N * H * W // 128, cout, 2)
+    rows = out2.permute(0, 2, 3, 1).reshape(-1, 128, cout).double()
+    want = torch.stack([rows.sum(1), (rows * rows).sum(1)], dim=-1)
+    assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
