@@ -344,12 +344,23 @@ def _winograd_weight(w):
     return U.reshape(16, w.shape[0], w.shape[1]).to(w.dtype).contiguous()
 
 
+# (grid size : input channels) measured faster than the implicit GEMM at 12 samples (tools/diag/winograd_shapes.py): the whole
+# 16 x 16 level and the wide skip-concatenation inputs of the 32 x 32 level; 640 / 320 channels at 32 x 32, everything at
+# 64 x 64 (transform traffic) and at 8 x 8 (weight-bound: the transformed weights are 16 / 9 as large) stay on the implicit GEMM
+_WINOGRAD_DEFAULT = "16:640,16:1280,16:1920,16:2560,32:960,32:1280,32:1920"
+
+
+def _winograd_shapes():
+    """{(H, Cin)} the Winograd path takes; GIP_WINOGRAD_SHAPES="H:Cin,..." overrides the measured default (experiments)."""
+    spec = os.environ.get("GIP_WINOGRAD_SHAPES", _WINOGRAD_DEFAULT)
+    return {tuple(int(v) for v in item.split(":")) for item in spec.split(",") if item}
+
+
 def _winograd_applies(x, w, residual):
-    """Where F(2x2, 3x3) beats the implicit GEMM (tools/diag/winograd_feasibility.py): >= 1280 input channels on a 16 x 16 grid;
-    at 32 x 32 / 640 channels and at 8 x 8 (weight-bound) the transforms eat the gain.  Frozen weights, no gradient path."""
+    """Where F(2x2, 3x3) beats the implicit GEMM (_WINOGRAD_DEFAULT above).  Frozen weights, no gradient path."""
     N, C, H, W = x.shape
     return (os.environ.get("GIP_WINOGRAD", "1") != "0" and fusable(x) and w.dtype == torch.float16 and not w.requires_grad and
-            tuple(w.shape[2:]) == (3, 3) and C >= 1280 and w.shape[0] % 8 == 0 and H == 16 and W == 16 and N * H * W >= 2048 and
+            tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 8 == 0 and H == W and (H, C) in _winograd_shapes() and N * H * W >= 2048 and
             not (torch.is_grad_enabled() and x.requires_grad) and (residual is None or fusable(residual)))
 
 
