@@ -17,7 +17,7 @@ FAM = [("raster(gip)", r"gip_"), ("gn_fused", r"gn_reduce|gn_apply|gn_finalize")
        ("linear(gip mfma)", r"conv3x3_kernelILi\d+ELi2ELi1E"),
        ("conv_fwd", r"igemm_fwd|Conv|conv"), ("miopen_aux", r"SubTensorOp|batched_transpose|transpose"),
        ("gemm", r"Cijk|gemm|GEMM"), ("attention", r"attn|fmha|flash|Fmha"), ("layernorm", r"layer_norm|LayerNorm|layernorm"),
-       ("glue(gip)", r"geglu_kernel|cat2_stats|add_bias_residual"),
+       ("glue(gip)", r"geglu_kernel|cat2_stats|add_bias_residual"), ("winograd transforms(gip)", r"winograd_"),
        ("groupnorm_torch", r"RowwiseMoments|GroupNorm|group_norm"), ("softmax", r"softmax"), ("adam", r"adam|Adam|multi_tensor"),
        ("elementwise", r"elementwise|vectorized|CatArray|index|copy|fill|upsample|reduce")]
 tot = sum(r[2] for r in rows)
