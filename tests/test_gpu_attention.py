@@ -244,3 +244,32 @@ def test_fused_qkv_projection_equals_three_projections(monkeypatch):
         plain = att(x, None, res)
     assert _lib.call_counts.get("gip_attention_fwd_strided2_f16", 0) - before == 2
     assert float((fused_out.float() - plain.float()).abs().max()) <= 2e-3 * max(1.0, float(plain.float().abs().max()))
+
+
+def test_denoise_with_the_winograd_layers_equals_the_implicit_gemm_denoise(monkeypatch):
+    """The whole ControlNet + U-Net noise prediction at the training shapes' 16 x 16 / 32 x 32 levels (64 x 64 latents, batch 12)
+    with the Winograd path on and off: the prediction — what the AHDS gradient is made of — agrees to fp16 rounding level."""
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance, ipa_guidance
+    from gaussianip_amd.guidance.ahds import AHDSSchedule
+    monkeypatch.setattr(ipa_guidance, "_GRAPH_DENOISE", False)
+    gd = StableDiffusionGuidance(GuidanceConfig(), schedule=AHDSSchedule(list(range(2400))))
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B = 4
+    lat = torch.randn(B, 4, 64, 64, device="cuda", generator=g)
+    ctrl = torch.rand(B, 3, 512, 512, device="cuda", generator=g)
+    emb = (torch.randn(3 * B, 81, 768, device="cuda", generator=g) * 0.1).half()
+    tt = torch.randint(20, 900, (B,), device="cuda", generator=g)
+    args = (torch.cat([lat] * 3), ctrl, torch.cat([tt] * 3), emb, True)
+    with torch.no_grad():
+        monkeypatch.setenv("GIP_WINOGRAD", "0")
+        gd.forward_unet(*args, replicas=3)
+        direct = gd.forward_unet(*args, replicas=3).float()
+        monkeypatch.setenv("GIP_WINOGRAD", "1")
+        before = _lib.call_counts.get("gip_winograd_input_f16", 0)
+        wino = gd.forward_unet(*args, replicas=3).float()
+    assert _lib.call_counts.get("gip_winograd_input_f16", 0) - before >= 16, "the Winograd layers did not run"      # 18 at these shapes
+    rel = float((wino - direct).norm() / direct.norm())
+    cos = float(torch.nn.functional.cosine_similarity(wino.flatten(), direct.flatten(), dim=0))
+    assert rel <= 5e-3 and cos >= 0.99995, (rel, cos)
+    assert float((wino - direct).abs().max()) <= 1e-2 * max(1.0, float(direct.abs().max()))
