@@ -344,23 +344,29 @@ def _winograd_weight(w):
     return U.reshape(16, w.shape[0], w.shape[1]).to(w.dtype).contiguous()
 
 
-# (grid size : input channels) measured faster than the implicit GEMM at 12 samples (tools/diag/winograd_shapes.py): the whole
-# 16 x 16 level and the wide skip-concatenation inputs of the 32 x 32 level; 640 / 320 channels at 32 x 32, everything at
-# 64 x 64 (transform traffic) and at 8 x 8 (weight-bound: the transformed weights are 16 / 9 as large) stay on the implicit GEMM
-_WINOGRAD_DEFAULT = "16:640,16:1280,16:1920,16:2560,32:960,32:1280,32:1920"
+# grid size : input channels : fewest pixels (N * H * W), measured faster than the implicit GEMM (tools/diag/winograd_shapes.py at
+# 12 samples, tools/diag/winograd_small_batch.py at the 3 / 6 samples of a sharded step): the 16 x 16 level and the wide
+# skip-concatenation inputs of the 32 x 32 level; 640 / 320 channels at 32 x 32, everything at 64 x 64 (transform traffic) and
+# at 8 x 8 (weight-bound: the transformed weights are 16 / 9 as large) stay on the implicit GEMM
+_WINOGRAD_DEFAULT = "16:640:3072,16:1280:1536,16:1920:1536,16:2560:1536,32:960:3072,32:1280:3072,32:1920:3072"
 
 
 def _winograd_shapes():
-    """{(H, Cin)} the Winograd path takes; GIP_WINOGRAD_SHAPES="H:Cin,..." overrides the measured default (experiments)."""
-    spec = os.environ.get("GIP_WINOGRAD_SHAPES", _WINOGRAD_DEFAULT)
-    return {tuple(int(v) for v in item.split(":")) for item in spec.split(",") if item}
+    """{(H, Cin): fewest pixels} the Winograd path takes; GIP_WINOGRAD_SHAPES="H:Cin[:pixels],..." overrides the measured
+    default (experiments)."""
+    out = {}
+    for item in os.environ.get("GIP_WINOGRAD_SHAPES", _WINOGRAD_DEFAULT).split(","):
+        if item:
+            v = [int(t) for t in item.split(":")]
+            out[(v[0], v[1])] = v[2] if len(v) > 2 else 0
+    return out
 
 
 def _winograd_applies(x, w, residual):
     """Where F(2x2, 3x3) beats the implicit GEMM (_WINOGRAD_DEFAULT above).  Frozen weights, no gradient path."""
     N, C, H, W = x.shape
     return (os.environ.get("GIP_WINOGRAD", "1") != "0" and fusable(x) and w.dtype == torch.float16 and not w.requires_grad and
-            tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 8 == 0 and H == W and (H, C) in _winograd_shapes() and N * H * W >= 2048 and
+            tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 8 == 0 and H == W and N * H * W >= _winograd_shapes().get((H, C), 1 << 62) and
             not (torch.is_grad_enabled() and x.requires_grad) and (residual is None or fusable(residual)))
 
 

@@ -395,7 +395,7 @@ def test_narrow_output_convolutions(cfg):
 
 # ---- Winograd F(2x2, 3x3) at the 16 x 16 level (gip_winograd_input_f16 / _output_f16 around one batched GEMM) ----
 @pytest.mark.parametrize("cfg", [(12, 1280, 1280, True), (12, 2560, 1280, False), (8, 1920, 1280, True), (8, 1280, 640, False),
-                                 (8, 640, 1280, True, 16), (4, 960, 640, True, 32), (3, 1920, 640, False, 32)])
+                                 (12, 640, 1280, True, 16), (6, 2560, 1280, False, 16), (4, 960, 640, True, 32), (3, 1920, 640, False, 32)])
 def test_winograd_convolution_at_the_16x16_level(cfg, monkeypatch):
     from gaussianip_amd import _lib
     from gaussianip_amd.guidance import fused
