@@ -74,3 +74,30 @@ def test_gpu_only_entry_points_fall_back_to_the_library_ops_on_cpu():
     c = torch.randn(1, 16, 16, 16, generator=g)
     wc, bc = torch.randn(32, 16, 3, 3, generator=g) * 0.1, torch.randn(32, generator=g)
     assert torch.allclose(fused.conv3x3_fewch(c, wc, bc, 2, act=True), F.silu(F.conv2d(c, wc, bc, stride=2, padding=1)))
+
+
+def test_winograd_weight_block_and_the_two_transforms():
+    """fused._winograd_weight (U = G g G^T, the host's share of Winograd F(2x2, 3x3)) with the input / output transforms the
+    kernels of csrc/winograd.hip apply, written with the matrices: V = B^T d B per 4 x 4 patch at (2 ty - 1, 2 tx - 1), sixteen
+    products M[p] = V[p] U[p]^T, Y = A^T M A — equals conv2d(padding=1) in fp64."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 6, 8, generator=g, dtype=torch.float64)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64)
+    U = fused._winograd_weight(w.float()).double()                      # the builder works in fp32: compare at fp32 accuracy
+    assert U.shape == (16, 4, 5)
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    xp = F.pad(x, (1, 1, 1, 1))
+    out = torch.zeros(2, 4, 6, 8, dtype=torch.float64)
+    for n in range(2):
+        for ty in range(3):
+            for tx in range(4):
+                d = xp[n, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]                    # [ci, 4, 4]
+                V = torch.einsum("ik,ckl,jl->ijc", Bt, d, Bt).reshape(16, 5)            # position p = 4 i + j
+                M = torch.einsum("pc,poc->po", V, U).reshape(4, 4, 4)                   # [i, j, co]
+                out[n, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = torch.einsum("ai,ijo,bj->oab", At, M, At)
+    ref = F.conv2d(x, w, padding=1)
+    assert float((out - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    # the default shape table parses and only names shapes with even grids
+    shapes = fused._winograd_shapes()
+    assert shapes and all(h % 2 == 0 and c % 8 == 0 and rows > 0 for (h, c), rows in shapes.items())
