@@ -39,6 +39,47 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def raster_source_hash():
+    """sha256[:16] over the rasterizer's kernel sources, its internal header, the C-ABI header and the Makefile (flags):
+    what profiles/pmc.json is stamped with.  Identical sources give identical kernels whichever box built them."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "gaussianip_amd", "csrc")
+    for f in ("preprocess.hip", "binning.hip", "api.hip", "render_forward.hip", "render_backward.hip", "gather_backward.hip",
+              "gip_internal.h", os.path.join("..", "..", "include", "gip_raster.h")):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(csrc, "Makefile")) as fh:      # the flag lines the raster objects are compiled with (libgip_nn's rules do not count)
+        for ln in fh:
+            if ln.split("=")[0].strip().split(" ")[0] in ("ARCH", "COMMON", "EXACT", "FAST", "SRCS_EXACT", "SRCS_FAST") or ln.startswith("NOSLP_"):
+                h.update(ln.strip().encode())
+    return h.hexdigest()[:16]
+
+
+def physical_cores():
+    """(physical cores, hardware threads) of this host: distinct (physical id, core id) pairs of /proc/cpuinfo."""
+    threads = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        if pairs:
+            return min(len(pairs), threads), threads
+    except OSError:
+        pass
+    return threads, threads
+
+
 def algorithmic_bytes(P, K, R, T, N):
     """SURVEY.md §8d, per view: forward B_f and backward B_b."""
     b_f = P * (92 + 12 * K) + 88 * R + 8 * T + 24 * N
@@ -57,6 +98,91 @@ def stage_bytes(stage, P, K, R, T, N):
         "render_bwd": 44 * R + 28 * N,
         "gather_bwd": P * (211 + 24 * K),
     }[stage]
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _visible_gpus():
+    """Device count, asked of a CHILD process: the launcher itself must never initialise the GPU runtime (it only starts
+    rank processes and relays their output)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:      # noqa: BLE001
+        return 0
+
+
+def spawn_ranks(n, cmd, env=None, out=None, err=None):
+    """Start `n` fresh rank processes of `cmd` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their
+    environment, the contract torch.distributed.run gives its workers), wait for all of them, and relay ONE line to `out`:
+    the last line of rank 0's stdout that is a JSON object with a "metric" key.  Everything else the ranks print on stdout
+    (library banners such as "[Gloo] Rank ..." included) goes to `err`, prefixed by the rank.  Returns the exit code: 0 only
+    if every rank exited 0 and rank 0 produced its line; the first failing rank's code otherwise (the remaining ranks are
+    terminated by PID).  The calling process never touches the GPU."""
+    import subprocess
+    import threading
+    out = sys.stdout if out is None else out
+    err = sys.stderr if err is None else err
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(_free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base["WORLD_SIZE"] = str(n)
+    procs, lines = [], [[] for _ in range(n)]
+
+    def pump(rank, pipe):
+        for ln in pipe:
+            lines[rank].append(ln.rstrip("\n"))
+    threads = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0")
+        p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, text=True, bufsize=1)
+        t = threading.Thread(target=pump, args=(r, p.stdout), daemon=True)
+        t.start()
+        procs.append(p)
+        threads.append(t)
+    rc, pending = 0, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py launcher: rank %d exited with code %d; stopping the other ranks" % (r, code), file=err)
+                for q in pending:
+                    procs[q].terminate()          # exact PIDs this launcher started
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    line = None
+    for ln in lines[0]:
+        if ln.startswith("{"):
+            try:
+                if "metric" in json.loads(ln):
+                    line = ln
+                    continue
+            except ValueError:
+                pass
+        print("[rank 0] %s" % ln, file=err)
+    for r in range(1, n):
+        for ln in lines[r]:
+            print("[rank %d] %s" % (r, ln), file=err)
+    if rc == 0 and line is None:
+        print("bench.py launcher: rank 0 printed no result line", file=err)
+        rc = 1
+    if rc == 0:
+        print(line, file=out, flush=True)
+    return rc
 
 
 def main():
@@ -78,6 +204,19 @@ def main():
     ap.add_argument("--no-trained", action="store_true", help="skip the secondary raster measurement on a trained-looking state")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver types it, outside torch.distributed.run: THIS process becomes the
+        # launcher — it starts N fresh rank processes of this file (one per GPU, RCCL), never initialises the GPU itself
+        # (no re-exec of a process that has touched the GPU), relays rank 0's one JSON line and fails if any rank fails
+        env = dict(os.environ)
+        ndev = _visible_gpus()
+        env["GIP_BENCH_VISIBLE_GPUS"] = str(ndev)
+        if ndev < args.gpus and "GIP_DIST_BACKEND" not in env:
+            # fewer GPUs than ranks (a functional check on a 1-GPU box): RCCL cannot put two ranks on one device, gloo can;
+            # the line says so (config.gpus_visible / config.backend) — it is not an N-GPU measurement
+            env["GIP_DIST_BACKEND"] = "gloo"
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -93,6 +232,7 @@ def main():
     local_rank %= max(torch.cuda.device_count(), 1)     # (a 2-rank functional check can share one GPU over gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("GIP_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
@@ -308,18 +448,18 @@ def main():
         ppath = os.path.join(ROOT, "profiles", "pmc.json")
         if os.path.exists(ppath):
             try:
-                import hashlib
                 pmc = json.load(open(ppath))
-                lib_sha = hashlib.sha256(open(os.path.join(ROOT, "gaussianip_amd", "lib", "libgip_raster.so"), "rb").read()).hexdigest()[:16]
+                lib_sha = raster_source_hash()
                 stamp = pmc.get("_build", {})
                 c = pmc.get(dom, {})
                 if Vl != 4:
                     # the passes were taken on the 4-view launch of N = 1; a rank of an N-GPU run launches fewer views
                     pmc_note = "profiles/pmc.json holds counters of the 4-view launch; this rank launches %d view(s): counters withheld" % Vl
-                elif stamp.get("libgip_raster_sha16") != lib_sha:
-                    # counters of ANOTHER build of the kernels: not this line's business (they went stale silently)
-                    pmc_note = "profiles/pmc.json was collected on libgip_raster %s, this run uses %s: counters withheld" % (
-                        stamp.get("libgip_raster_sha16"), lib_sha)
+                elif stamp.get("raster_source_sha16") != lib_sha:
+                    # counters of OTHER kernel sources: not this line's business (they went stale silently).  The stamp
+                    # is a hash of the SOURCES + Makefile (a rebuilt binary of identical sources hashes differently: VERDICT r3)
+                    pmc_note = "profiles/pmc.json was collected on raster sources %s, this run is built from %s: counters withheld" % (
+                        stamp.get("raster_source_sha16"), lib_sha)
                 else:
                     pmc_note = "profiles/pmc.json (rocprofv3 --pmc passes of this build, git %s)" % stamp.get("git", "?")
                     traffic = int(c["hbm_fetch_bytes"] + c["hbm_write_bytes"])
@@ -363,7 +503,7 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             orc.build()
-            ncores = os.cpu_count() or 1
+            ncores, nthreads = physical_cores()          # one OpenMP thread per PHYSICAL core
             orc.set_threads(ncores)
             c0 = cams[0]
             ro = orc.RasterOracle()
@@ -392,7 +532,7 @@ def main():
                     model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
             except OSError:
                 pass
-            cpu = {"value": round(reps * H * W / tt / 1e6, 3), "unit": "Mpix/s", "cores": ncores, "cpu_model": model, "kind": "port",
+            cpu = {"value": round(reps * H * W / tt / 1e6, 3), "unit": "Mpix/s", "cores": ncores, "threads": nthreads, "cpu_model": model, "kind": "port",
                    "forward_only_value": round(H * W / t_fwd[2] / 1e6, 3),
                    "sample": "median of 5 x (1 view forward, then backward; P=%d, %dx%d) after one warm-up, on the C oracle "
                              "(oracle/raster_oracle.c, OpenMP over tiles, %d threads); value = forward+backward" % (P, H, W, ncores)}
@@ -405,6 +545,9 @@ def main():
                           "gaussians": P, "height": H, "width": W, "views_per_step": V, "views_per_step_per_gpu": Vl,
                           "prewarm_steps": args.prewarm, "repeats": len(windows), "value_is": "median window",
                           "num_rendered_per_view": int(Rv), "sh_degree": 0,
+                          "backend": None if world == 1 else ("rccl" if backend == "nccl" else backend),
+                          "dist_world_size": 1 if world == 1 else dist.get_world_size(),
+                          "gpus_visible": int(os.environ.get("GIP_BENCH_VISIBLE_GPUS", torch.cuda.device_count())),
                           "parallelism": "1 GPU" if world == 1 else "BASELINE configs[3]: %d views sharded over %d GPU(s) x %d seed group(s)" % (
                               V, shard.group_size, shard.n_seed_groups)},
                "window_ms_per_step": [round(w_ / args.steps * 1e3, 4) for w_ in windows],
@@ -418,6 +561,9 @@ def main():
                "roofline": roofline, "roofline_valu": valu, "cpu_baseline": cpu}
     if rank == 0:
         out["ahds"] = ahds
+        # BASELINE.json's metric names the AHDS training-step rate first: first-class beside the raster rate
+        out["ahds_steps_per_s"] = ahds.get("value") if isinstance(ahds, dict) else None
+        out["ahds_ms_per_step"] = ahds.get("ms_per_step") if isinstance(ahds, dict) else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

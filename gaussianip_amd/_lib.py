@@ -156,7 +156,7 @@ def model_lib():
         lib.gip_gather_rows.restype = ctypes.c_int
         lib.gip_gather_rows.argtypes = [ctypes.POINTER(GipGatherTensor), ctypes.c_int32, _vp, ctypes.c_int64, ctypes.c_int64, _vp]
         lib.gip_adam_step.restype = ctypes.c_int
-        lib.gip_adam_step.argtypes = [ctypes.POINTER(GipAdamGroup), ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]
+        lib.gip_adam_step.argtypes = [ctypes.POINTER(GipAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp]
         lib.gip_openpose_draw.restype = ctypes.c_int
         lib.gip_openpose_draw.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]
         lib.gip_openpose_workspace_bytes.restype = ctypes.c_size_t

@@ -424,7 +424,10 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         if (co >= Cout) continue;
         f32x4 v = acc[ni][mi];
         if (bias) add4(v, bias + co);
-        if (residual) add4(v, residual + m * Cout + co);
+        if (residual) {       // fp16(fp16(conv + bias) + residual), like the LDS epilogue and the split-K reduce kernels
+          v[0] = (float)(_Float16)v[0]; v[1] = (float)(_Float16)v[1]; v[2] = (float)(_Float16)v[2]; v[3] = (float)(_Float16)v[3];
+          add4(v, residual + m * Cout + co);
+        }
         f16x4 o;
         o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
         *(f16x4*)(out + out_row(m) * Cout + co) = o;
@@ -747,8 +750,11 @@ conv_splitk_reduce_kernel(const float* __restrict__ partial, const _Float16* __r
     v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
   }
   if (residual) {
+    // fp16(fp16(conv + bias) + residual): the LDS epilogue of the whole-K tiles rounds the convolution output to half before
+    // it adds the residual (diffusers' own arithmetic), so the same layer must not round differently when it runs split-K
     const f16x4 r = *(const f16x4*)(residual + (size_t)i * 4);
-    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = (float)(_Float16)v[j] + (float)r[j];
   }
   f16x4 o;
   o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
@@ -783,9 +789,10 @@ conv_splitk_reduce_stats_kernel(const float* __restrict__ partial, const _Float1
         v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
       }
       v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-      if (residual) {
+      if (residual) {       // two roundings like the whole-K LDS epilogue (see conv_splitk_reduce_kernel)
         const f16x4 r = *(const f16x4*)(residual + i);
-        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = (float)(_Float16)v[j] + (float)r[j];
       }
       f16x4 o;
       o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];

@@ -120,9 +120,9 @@ template <int MODE>
 __global__ void __launch_bounds__(GN_BLOCK)
 gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const __half* __restrict__ gamma,
                 const __half* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
-                const float* __restrict__ partial, half8* __restrict__ out, long long HW, int C, int G, int splits,
+                const float* __restrict__ partial, half8* out, long long HW, int C, int G, int splits,
                 int out_splits, float eps, int silu, const __half* __restrict__ addend, int addend_stride,
-                const half8* __restrict__ accum) {
+                const half8* accum) {          // NOT __restrict__: gip_nn.h allows dx (= out) to alias accum
   extern __shared__ float s_g[];   // [G][2]: forward mean, rstd ; backward S1/m, S2/m
   const int n = blockIdx.y, split = blockIdx.x;
   const GnGeom gm = geom(C);

@@ -236,15 +236,15 @@ __global__ void gip_adam_count_kernel(AdamArgs a, const float* __restrict__ foun
   if (threadIdx.x < a.n_groups) *a.g[threadIdx.x].step += 1.f;
 }
 
-extern "C" int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, const float* found_inf,
+extern "C" int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps, const float* found_inf,
                              void* stream) {
   if (!groups || n_groups < 1 || n_groups > GIP_ADAM_MAX_GROUPS) return 1;
+  if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0)) return 1;
   AdamArgs a;
-  a.n_groups = n_groups; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-  a.beta1d = (double)beta1; a.beta2d = (double)beta2;
-  // the caller's betas arrive as floats; 0.9f / 0.999f are not 0.9 / 0.999: recover the decimal the float was rounded from
-  // (6 significant digits) so that 1 - beta matches the double arithmetic of torch's Python-side constants
-  a.beta1d = (double)((long long)(a.beta1d * 1e6 + 0.5)) / 1e6; a.beta2d = (double)((long long)(a.beta2d * 1e6 + 0.5)) / 1e6;
+  // betas / eps arrive as the caller's DOUBLES (Python floats): 1 - beta and the bias corrections are formed in double
+  // exactly like torch's host-side constants, whatever the number of significant digits of the betas
+  a.n_groups = n_groups; a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
+  a.beta1d = beta1; a.beta2d = beta2;
   a.w1 = (float)(1.0 - a.beta1d); a.w2 = (float)(1.0 - a.beta2d);
   long long off = 0;
   for (int i = 0; i < n_groups; i++) {

@@ -74,4 +74,5 @@ class AHDSSchedule:
 
     def sample(self, step, batch_size, device, generator=None):
         lo, hi = self.window(step)
-        return torch.randint(lo, hi, [batch_size], dtype=torch.long, device=device, generator=generator)
+        from .sds import per_sample
+        return per_sample(lambda k, g: torch.randint(lo, hi, [k], dtype=torch.long, device=device, generator=g), batch_size, generator)

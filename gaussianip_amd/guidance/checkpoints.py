@@ -86,6 +86,8 @@ _VAE_OLD = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_a
 def load_diffusers_state_dict(module: torch.nn.Module, state_dict: Dict[str, torch.Tensor], kind: str, strict: bool = True):
     """Copy a diffusers-format `state_dict` into `module` (one of this repo's networks, WITHOUT LoRA / IP branches in
     its own key set: they come from load_ip_adapter_faceid).  Returns the list of our keys that were not found."""
+    from . import fused
+    fused.bump_weights_epoch()          # captured HIP graphs hold derived copies of the old weights
     own = module.state_dict()
     missing, loaded = [], {}
     for ours, dst in own.items():
@@ -143,6 +145,8 @@ def ip_adapter_key_map(unet: UNet) -> Dict[str, str]:
 
 def load_ip_adapter_faceid(unet: UNet, ip_state: Dict[str, torch.Tensor], strict: bool = True):
     """`ip_state` = torch.load(ip-adapter-faceid-*.bin)["ip_adapter"].  Call before UNet.fold_lora()."""
+    from . import fused
+    fused.bump_weights_epoch()
     own = unet.state_dict()
     table = ip_adapter_key_map(unet)
     loaded = {}

@@ -97,6 +97,26 @@ class GroupNormAct(nn.GroupNorm):
 _DISABLED = False
 _STATS_ATTR = "_gip_chan_stats"
 
+# Captured HIP graphs (ipa_guidance._forward_unet_graph / _encode_graphed) freeze what they saw at capture: weight values
+# are read in place, but DERIVED copies (Winograd U, q|k|v concatenations, packed time-embedding / context projections),
+# scalar kernel arguments (Attention.ip_scale) and the A/B environment switches are baked in.  Everything that changes one
+# of those bumps this counter; it is part of the graph keys, so a stale graph is never replayed.
+_weights_epoch = 0
+_ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_GN_STATS", "GIP_SPLITK_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
+              "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
+              "GIP_CONV_C3", "GIP_LN_FOLD", "GIP_ATTN_V2", "GIP_OWN_GEMM")
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+    return _weights_epoch
+
+
+def graph_signature():
+    """What a captured graph depends on besides its input shapes: the weights epoch and the A/B switches."""
+    return (_weights_epoch, bool(_DISABLED)) + tuple(os.environ.get(k) for k in _ENV_KNOBS)
+
 
 def producer_stats(x):
     """chan_stats [N * HW / R, C, 2] float32 (R = 128 rows per block, or 64 at the 8 x 8 level) that the kernel which
@@ -252,29 +272,45 @@ class _WeightCache:
     Every entry keeps a STRONG reference to the source tensor: while the entry lives the source's storage cannot be freed,
     so the allocator cannot hand the same address (at version 0, same shape) to a different weight and make the entry
     stale.  Least-recently-used entries beyond _WT_CACHE_MAX are dropped (a rebuilt network does not pin the old one's
-    weights forever)."""
+    weights forever) — EXCEPT entries that were created or read while a HIP graph was being captured: the graph bakes
+    their device addresses into its kernel arguments, so they stay (pinned) until the graphs that use them are dropped
+    (`unpin_all`, called by StableDiffusionGuidance.invalidate_graphs)."""
 
     def __init__(self):
         from collections import OrderedDict
         self._d = OrderedDict()
+        self._pinned = set()
 
     def get(self, tag, w, make):
         key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+        capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
         hit = self._d.get(key)
         if hit is not None:
             self._d.move_to_end(key)
+            if capturing:
+                self._pinned.add(key)
             return hit[1]
-        wt = make(w)
+        wt = make(w)         # (inside a capture: the copy kernels become part of the graph and the tensor lives in its pool — still correct)
         self._d[key] = (w, wt)
-        while len(self._d) > _WT_CACHE_MAX:
-            self._d.popitem(last=False)
+        if capturing:
+            self._pinned.add(key)
+        if len(self._d) > _WT_CACHE_MAX:
+            for k in [k for k in self._d if k not in self._pinned][:len(self._d) - _WT_CACHE_MAX]:
+                del self._d[k]
         return wt
 
     def __len__(self):
         return len(self._d)
 
+    def pinned(self):
+        return len(self._pinned)
+
+    def unpin_all(self):
+        self._pinned.clear()
+
     def clear(self):
         self._d.clear()
+        self._pinned.clear()
 
 
 _wt_cache = _WeightCache()

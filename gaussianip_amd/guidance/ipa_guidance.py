@@ -146,8 +146,28 @@ class StableDiffusionGuidance:
         z = torch.zeros(1, IP_TOKENS, 768, device=self.device, dtype=self.weights_dtype)
         self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = z, z, z
 
+    def invalidate_graphs(self):
+        """Drop every captured HIP graph (denoise and VAE) and release the derived-weight cache entries they pinned.  Called
+        by whatever changes something a graph froze at capture: load_checkpoints, fold_lora, prepare_inference, an ip_scale
+        change (those also bump fused._weights_epoch, which is part of the graph keys — a stale graph can never be replayed
+        even when this method is not reached, e.g. when a caller edits the modules directly)."""
+        self._graphs = None
+        self._vae_graphs = None
+        self._vae_live = None
+        fused._wt_cache.unpin_all()
+        fused.bump_weights_epoch()
+
+    def set_ip_scale(self, scale):
+        """IPAdapter.set_scale (ip_adapter_faceid.py:330-333): the image-prompt weight of every cross-attention."""
+        from .networks import Attention
+        for m in self.unet.modules():
+            if isinstance(m, Attention) and m.ip:
+                m.ip_scale = float(scale)
+        self.invalidate_graphs()
+
     def load_checkpoints(self, unet=None, controlnet=None, vae=None, ip_adapter=None):
         from . import checkpoints as ck
+        self.invalidate_graphs()
 
         def read(path):
             return ck.load_safetensors(path) if str(path).endswith(".safetensors") else torch.load(path, map_location="cpu")
@@ -226,7 +246,7 @@ class StableDiffusionGuidance:
         if self._graphs is None:
             self._graphs = {}
         key = (tuple(noisy_latents.shape), noisy_latents.dtype, tuple(control_img.shape), control_img.dtype, tuple(t.shape), t.dtype,
-               tuple(ctx.shape), ctx.dtype, bool(use_pose), int(replicas), noisy_latents.device.index, bool(fused._DISABLED))
+               tuple(ctx.shape), ctx.dtype, bool(use_pose), int(replicas), noisy_latents.device.index, fused.graph_signature())
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs[key] = "warm"
@@ -299,6 +319,7 @@ class StableDiffusionGuidance:
             return self.vae.encode(x, generator).to(imgs.dtype)
 
     _vae_graphs = None
+    _vae_live = None
 
     def _encode_graphed(self, x, generator):
         """The differentiable VAE encoder (fixed shape, frozen weights: ~350 launches forward, ~400 backward) as two HIP-graph
@@ -307,7 +328,7 @@ class StableDiffusionGuidance:
         one-time initialisations must not be captured), the second captures."""
         if self._vae_graphs is None:
             self._vae_graphs = {}
-        key = (tuple(x.shape), x.dtype, x.device.index, bool(fused._DISABLED))
+        key = (tuple(x.shape), x.dtype, x.device.index, fused.graph_signature())
         ent = self._vae_graphs.get(key)
         if ent is None:
             self._vae_graphs[key] = "warm"
@@ -315,7 +336,20 @@ class StableDiffusionGuidance:
         if ent == "warm":
             sample = torch.zeros_like(x, memory_format=torch.channels_last).requires_grad_(True)
             ent = self._vae_graphs[key] = torch.cuda.make_graphed_callables(lambda t_: self.vae.moments(t_), (sample,), num_warmup_iters=2)
-        return self.vae.sample(ent(x), generator)
+        # make_graphed_callables keeps ONE set of static activations: a second forward before the first one's backward would
+        # overwrite what that backward reads.  While an earlier output of this graph is still alive and has not been
+        # back-propagated, the call runs eagerly instead (same kernels, same values).
+        if self._vae_live is None:
+            self._vae_live = {}
+        live = self._vae_live.get(key)
+        if live is not None and live[0]() is not None and not live[1][0]:
+            return self.vae.encode(x, generator)
+        import weakref
+        moments = ent(x)
+        done = [False]
+        moments.register_hook(lambda g_, d_=done: d_.__setitem__(0, True))
+        self._vae_live[key] = (weakref.ref(moments), done)
+        return self.vae.sample(moments, generator)
 
     # ------------------------------------------------------------------ gradients
     def _prompt_embeds(self, prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, n_sets):
@@ -337,7 +371,8 @@ class StableDiffusionGuidance:
         embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 3)
         assert embeds.shape[1] == TEXT_TOKENS + IP_TOKENS
         with torch.no_grad():
-            noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
+            noise = sds.per_sample(lambda k, g: torch.randn((k,) + tuple(latents.shape[1:]), device=latents.device, dtype=latents.dtype,
+                                                          generator=g), latents.shape[0], generator)
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
             # the three branches share their pose maps: the ControlNet hint stem runs on the B distinct maps and tiles
             noise_pred = self.forward_unet(torch.cat([latents_noisy] * 3, dim=0), control_img,
@@ -353,7 +388,8 @@ class StableDiffusionGuidance:
                          azimuth, center, camera_distances, generator=None, control_embedding=None):
         embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 2)
         with torch.no_grad():
-            noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
+            noise = sds.per_sample(lambda k, g: torch.randn((k,) + tuple(latents.shape[1:]), device=latents.device, dtype=latents.dtype,
+                                                          generator=g), latents.shape[0], generator)
             latents_noisy = sds.add_noise(latents, noise, t, self.alphas)
             noise_pred = self.forward_unet(torch.cat([latents_noisy] * 2, dim=0), control_img,
                                            torch.cat([t] * 2), embeds, use_pose_controlnet, replicas=2,

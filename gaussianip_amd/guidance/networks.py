@@ -105,7 +105,7 @@ class Attention(nn.Module):
         self.to_k = nn.Linear(ctx_dim, dim, bias=False)
         self.to_v = nn.Linear(ctx_dim, dim, bias=False)
         self.to_out = nn.Linear(dim, dim)
-        self.ip, self.ip_scale = ip, ip_scale
+        self.ip, self._ip_scale = ip, ip_scale
         if ip:
             self.to_k_ip = nn.Linear(ctx_dim, dim, bias=False)
             self.to_v_ip = nn.Linear(ctx_dim, dim, bias=False)
@@ -114,11 +114,22 @@ class Attention(nn.Module):
             mk = lambda i, o: nn.Sequential(nn.Linear(i, lora_rank, bias=False), nn.Linear(lora_rank, o, bias=False))  # noqa: E731
             self.lora_q, self.lora_k, self.lora_v, self.lora_out = mk(dim, dim), mk(ctx_dim, dim), mk(ctx_dim, dim), mk(dim, dim)
 
+    @property
+    def ip_scale(self):
+        return self._ip_scale
+
+    @ip_scale.setter
+    def ip_scale(self, value):
+        if value != self._ip_scale:
+            fused.bump_weights_epoch()       # a captured graph holds the old value as a kernel argument
+        self._ip_scale = value
+
     @torch.no_grad()
     def fold_lora(self, scale=1.0):
         """W' = W + scale * up @ down for q/k/v/out; removes the LoRA modules (inference-time identity)."""
         if not self.lora_rank:
             return
+        fused.bump_weights_epoch()
         for base, lora in ((self.to_q, self.lora_q), (self.to_k, self.lora_k), (self.to_v, self.lora_v), (self.to_out, self.lora_out)):
             base.weight.add_(scale * (lora[1].weight.float() @ lora[0].weight.float()).to(base.weight.dtype))
         del self.lora_q, self.lora_k, self.lora_v, self.lora_out
@@ -342,6 +353,7 @@ class _Encoder(nn.Module):
     def prepare_inference(self):
         """Call once the (frozen) weights are final: packs every ResnetBlock2D's time_emb_proj into ONE [sum(C), 1280]
         projection whose bias also carries conv1's bias, so a forward runs a single GEMM for all the blocks' addends."""
+        fused.bump_weights_epoch()
         blocks = [m for m in self.modules() if isinstance(m, ResBlock) and m.time_emb_proj is not None]
         W = torch.cat([b.time_emb_proj.weight for b in blocks]).contiguous()
         bias = torch.cat([b.time_emb_proj.bias + b.conv1.bias for b in blocks]).contiguous()
@@ -552,7 +564,9 @@ class VAEEncoder(nn.Module):
     def sample(self, moments, generator=None):
         mean, logvar = moments.chunk(2, dim=1)
         std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
-        noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        from .sds import per_sample
+        noise = per_sample(lambda k, g: torch.randn((k,) + tuple(mean.shape[1:]), device=mean.device, dtype=mean.dtype, generator=g),
+                           mean.shape[0], generator)
         return (mean + std * noise) * self.scaling_factor
 
 

@@ -9,6 +9,18 @@ import torch
 import torch.nn.functional as F
 
 
+def per_sample(draw, n, generator):
+    """`draw(k, g)` -> a tensor of k samples from generator g.  `generator` may be one torch.Generator (or None: the global
+    one) — the reference's behaviour, one stream for the whole batch — or a LIST of n generators, one per batch row: every
+    view then draws from its own stream, so a view's noise / timestep does not depend on which other views share its batch
+    (the view-sharded step of BASELINE configs[3] draws, per view, what the unsharded 4-view step draws)."""
+    if isinstance(generator, (list, tuple)):
+        if len(generator) != n:
+            raise ValueError("need one generator per batch row: %d for %d rows" % (len(generator), n))
+        return torch.cat([draw(1, g) for g in generator], dim=0)
+    return draw(n, generator)
+
+
 def alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, device=None):
     """cumprod(1 - beta) for the "scaled_linear" schedule (linear in sqrt(beta)), float32 like diffusers."""
     betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2

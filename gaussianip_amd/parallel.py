@@ -206,15 +206,23 @@ def shard_views(n_views: int, rank: int, world_size: int):
 class _GroupMax(torch.autograd.Function):
     """max over the ranks of a group of a non-negative 0-d float32 tensor, differentiable like torch.max over the
     concatenated data: the gradient of everything that used the maximum (on EVERY rank) flows to ONE element — the one on
-    the rank that holds the maximum; when several ranks tie (identical views, a saturated depth) the lowest rank of the
-    group wins, as torch.max picks a single element.  One collective: the ranks MAX-reduce the int64 key
+    the rank that holds the maximum.  TIES: the backward of the full reduction torch.max() / amax() spreads the gradient
+    EVENLY among tied elements, so a single-process step splits it between the tied pixels; here, when several RANKS tie
+    (identical views, a saturated depth), the whole gradient goes to the lowest rank of the group (which splits it among
+    its own tied pixels as usual) — a documented deviation that matters only for exactly equal float maxima on different
+    ranks (tests/test_distributed_cpu.py pins it).  The key's ordering needs a non-negative, non-NaN value (depths of
+    Gaussians beyond the near plane; an empty render gives 0): checked.  One collective: the ranks MAX-reduce the int64 key
     (float bits << 32) | (world - rank); non-negative IEEE floats order like their bit patterns, so the winning key
     carries the maximum in its high word and the winner's rank in its low word."""
 
     @staticmethod
     def forward(ctx, local_max, group):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        bits = local_max.detach().to(torch.float32).reshape(1).view(torch.int32).to(torch.int64)
+        lm = local_max.detach().to(torch.float32).reshape(1)
+        if not lm.is_cuda and not bool(lm >= 0):       # (on the GPU the check would be a host synchronisation: clamp instead)
+            raise ValueError("group maximum of a negative / NaN value: the bit-pattern ordering needs a non-negative float")
+        lm = torch.nan_to_num(lm, nan=0.0).clamp_min(0.0)
+        bits = lm.view(torch.int32).to(torch.int64)
         key = (bits << 32) | (world - rank)
         dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
         gmax = (key >> 32).to(torch.int32).view(torch.float32).reshape(local_max.shape).to(local_max.dtype)

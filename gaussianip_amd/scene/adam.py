@@ -16,6 +16,23 @@ class GipAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps)
         self._step_supports_amp_scaling = True
 
+    @staticmethod
+    def _migrate_state(st, p):
+        """State that came through load_state_dict() of a reference / plain torch.optim.Adam checkpoint: `step` is then a CPU
+        tensor (or a Python number) and the moments may have another dtype / layout.  The kernel takes raw device pointers, so
+        bring them into the form it walks: `step` a 0-d float32 tensor on p's device, moments float32 and dense in p's layout."""
+        stp = st.get("step")
+        if not (torch.is_tensor(stp) and stp.device == p.device and stp.dtype == torch.float32 and stp.dim() == 0):
+            st["step"] = torch.as_tensor(float(stp) if stp is not None else 0.0, dtype=torch.float32).to(p.device).reshape(())
+        for k in ("exp_avg", "exp_avg_sq"):
+            m = st.get(k)
+            if m is None:
+                st[k] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif not (m.device == p.device and m.dtype == torch.float32 and m.shape == p.shape and m.stride() == p.stride()):
+                if m.shape != p.shape:
+                    raise ValueError("GipAdam: state %r has shape %s, parameter %s" % (k, tuple(m.shape), tuple(p.shape)))
+                st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(m)
+
     @torch.no_grad()
     def step(self, closure=None):
         from .. import _lib
@@ -38,8 +55,11 @@ class GipAdam(torch.optim.Adam):
             for p in g["params"]:
                 if p.grad is None or p.numel() == 0:          # (f_rest is [P, 0, 3] at the shipped sh_degree 0)
                     continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.grad.device == p.device):
+                    raise ValueError("GipAdam: float32 CUDA parameters and gradients only (group %r: %s %s %s, grad %s %s)" % (
+                        g.get("name"), p.device, p.dtype, tuple(p.shape), p.grad.device, p.grad.dtype))
                 permuted = False
-                if not p.is_contiguous() and p.is_cuda:
+                if not p.is_contiguous():
                     # a dense but permuted parameter (e.g. built from a transposed array): the flat kernel walks memory, so the
                     # gradient is brought into the parameter's own layout (zeros_like below gives the moments that layout too)
                     lay = torch.empty_like(p, memory_format=torch.preserve_format)
@@ -47,9 +67,6 @@ class GipAdam(torch.optim.Adam):
                         raise ValueError("GipAdam: parameter of group %r is not dense (strides %s)" % (g.get("name"), p.stride()))
                     p.grad = lay.copy_(p.grad)
                     permuted = True
-                elif not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
-                    raise ValueError("GipAdam: contiguous float32 CUDA parameters only (group %r: %s %s %s strides %s, grad %s)" % (
-                        g.get("name"), p.device, p.dtype, tuple(p.shape), p.stride(), p.grad.dtype))
                 dev = p.device
                 grad = p.grad if (permuted or p.grad.is_contiguous()) else p.grad.contiguous()
                 if grad_scale is not None:              # scaler.step() without a preceding unscale_(): unscale here
@@ -59,6 +76,8 @@ class GipAdam(torch.optim.Adam):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                else:
+                    self._migrate_state(st, p)
                 keep.append(grad)
                 groups.append(_lib.GipAdamGroup(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                                 st["step"].data_ptr(), p.numel(), float(g["lr"]), 0))
@@ -66,9 +85,11 @@ class GipAdam(torch.optim.Adam):
             return loss
         lib = _lib.model_lib()
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        fi = ctypes.c_void_p(None) if found_inf is None else ctypes.c_void_p(found_inf.to(torch.float32).data_ptr())
+        fi = ctypes.c_void_p(None)
         if found_inf is not None:
-            keep.append(found_inf)
+            fi32 = found_inf.to(device=dev, dtype=torch.float32)       # (a converted temporary must outlive the launch)
+            keep.append(fi32)
+            fi = ctypes.c_void_p(fi32.data_ptr())
         for i in range(0, len(groups), 8):
             chunk = groups[i:i + 8]
             arr = (_lib.GipAdamGroup * len(chunk))(*chunk)

@@ -71,8 +71,8 @@ typedef struct {
   float lr;
   int32_t reserved;
 } GipAdamGroup;
-int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, float beta1, float beta2, float eps, const float* found_inf,
-                  void* stream);
+int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps, const float* found_inf,
+                  void* stream);   /* betas / eps as doubles: the caller's Python floats, no re-rounding (0 <= beta < 1, else status 1) */
 #ifdef __cplusplus
 }
 #endif

@@ -109,8 +109,19 @@ def _dump():
             json.dump(_report, f, indent=1)
 
 
-@pytest.mark.parametrize("look", ["init", "trained"])
-def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look):
+@pytest.fixture
+def list_mode(request, monkeypatch):
+    """"culled" = the default lists (the fork's minus provably dead entries); "exact" = GipRasterConfig::exact_lists through
+    GIP_RASTER_EXACT_LISTS=1: tiles_touched / num_rendered / key-value lists / ranges / n_contrib are the oracle's bit for
+    bit (north_star: "tile/index buffers bit-exact") — driver-tested here at the headline size, not only at 10k / 256^2."""
+    mode = getattr(request, "param", "culled")
+    monkeypatch.setenv("GIP_RASTER_EXACT_LISTS", "1" if mode == "exact" else "0")
+    return mode
+
+
+@pytest.mark.parametrize("look,list_mode", [("init", "culled"), ("trained", "culled"), ("init", "exact"), ("trained", "exact")],
+                         indirect=["list_mode"])
+def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look, list_mode):
     from gaussianip_amd import GaussianRasterizer
     oracle.set_threads(oracle.max_threads())
     try:
@@ -131,7 +142,7 @@ def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look):
         knife, n_knife_pixels, behind = ro.knife_edge_gaussians(sharing=True)
     finally:
         oracle.set_threads(1)
-    tag = "1 view / " + look
+    tag = "1 view / " + look + ("" if list_mode == "culled" else " / exact lists")
     print("%s: %d knife-edge pixels, %d Gaussians are the subject of a knife-edge test" % (tag, n_knife_pixels, int(knife.sum())))
     assert n_knife_pixels <= 5e-4 * H * W and knife.sum() <= 5e-3 * P, (n_knife_pixels, int(knife.sum()))
     print("%s: %d rows behind a knife-edge subject (REL_TOL_DOWNSTREAM class)" % (tag, int(behind.sum())))
@@ -147,10 +158,12 @@ def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look):
     _dump()
 
 
-def test_four_view_launch_set_at_100k_1024(oracle):
+@pytest.mark.parametrize("list_mode", ["culled", "exact"], indirect=True)
+def test_four_view_launch_set_at_100k_1024(oracle, list_mode):
     """The training call: rasterize_views with the 4 cameras of one step.  Images per view against the oracle; parameter
     gradients against the float64 sum of the four oracle backwards; means2D gradients per view."""
     from gaussianip_amd import rasterize_views
+    tag4 = "4 views" if list_mode == "culled" else "4 views / exact lists"
     sc = _look("init")
     cams = scenes.train_cameras(4, 42, H, W)
     bg = (0.0, 0.0, 0.0)
@@ -185,8 +198,8 @@ def test_four_view_launch_set_at_100k_1024(oracle):
         o_color, o_radii, o_depth, o_alpha = imgs[v]
         assert np.array_equal(radii[v].cpu().numpy(), o_radii), "radii of view %d" % v
         _assert_images(ros[v], color[v], depth[v], alpha[v], o_color, o_depth, o_alpha)
-        _compare("4 views", "means2D[%d]" % v, m2.grad[v], grads[v]["means2D"], skip_rows=knife[v], loose_rows=behind[v])
-        rec = _report["4 views"]["means2D[%d]" % v]
+        _compare(tag4, "means2D[%d]" % v, m2.grad[v], grads[v]["means2D"], skip_rows=knife[v], loose_rows=behind[v])
+        rec = _report[tag4]["means2D[%d]" % v]
         if "worst_row" in rec:          # is the worst element-wise entry a NEAR knife-edge Gaussian (margin 2e-5 .. 1e-3)?
             rec["worst_row_near_knife_edge_1e-3"] = bool(knife_wide[v][rec["worst_row"]])
             rec["worst_row_shares_a_knife_edge_pixel"] = bool(behind[v][rec["worst_row"]])
@@ -195,6 +208,6 @@ def test_four_view_launch_set_at_100k_1024(oracle):
     tot = {k: sum(g[k].astype(np.float64) for g in grads) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     rot_floor = float(np.abs(tot["scales"] * sc["scales"]).max())
     for k in ("means3D", "opacities", "shs", "scales"):
-        _compare("4 views", k, t[k].grad, tot[k], skip_rows=knife_any, loose_rows=behind_any)
-    _compare("4 views", "rotations", t["rotations"].grad, tot["rotations"], floor=rot_floor, skip_rows=knife_any, loose_rows=behind_any)
+        _compare(tag4, k, t[k].grad, tot[k], skip_rows=knife_any, loose_rows=behind_any)
+    _compare(tag4, "rotations", t["rotations"].grad, tot["rotations"], floor=rot_floor, skip_rows=knife_any, loose_rows=behind_any)
     _dump()

@@ -107,10 +107,30 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         batch = scenes.train_batch(cam_rng, B, H, W, device=None if os.environ.get("GIP_HOST_BATCH", "1") == "1" else dev)
         loss, out, gout = stage.training_step(i, batch, guidance, prompt_utils, True)
         stage.optimizer_step(loss, i, scaler=scaler, exchange=(shard.exchange if shard is not None else exchange) if (world > 1 or proxy_group) else None)
+        step.last_loss = loss.detach()
         return loss
 
     for i in range(warmup):
         step(i)
+    # GradScaler bookkeeping: a step whose scaled gradients overflow is SKIPPED by scaler.step() and halves
+    # the scale.  The default initial scale (65536, what Lightning's 16-mixed uses) overflows the fp16 VAE backward of these
+    # random-initialised networks, so the first steps after start-up are skipped steps: warm up until the scale has settled,
+    # then count the skipped steps INSIDE the timed region from the scale before / after it (growth interval 2000 steps)
+    extra_warm = 0
+    scale_trace = []
+    if scaler is not None:
+        prev = scaler.get_scale()
+        scale_trace.append(prev)
+        while extra_warm < 24:
+            step(warmup + extra_warm)
+            extra_warm += 1
+            cur = scaler.get_scale()
+            scale_trace.append(cur)
+            if cur == prev:
+                break
+            prev = cur
+    warmup += extra_warm
+    scale_before = scaler.get_scale() if scaler is not None else None
     timeline = {}
     if os.environ.get("GIP_HOST_TIMELINE"):
         # where does the HOST spend the step?  perf_counter / thread_time around the phase boundaries, no synchronisation added:
@@ -165,6 +185,13 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    last_loss = float(step.last_loss) if getattr(step, "last_loss", None) is not None else None
+    amp_info = None
+    if scaler is not None:
+        scale_after = scaler.get_scale()
+        amp_info = {"init_scale": scale_trace[0] * (2 ** 0), "scale_at_timed_region": scale_before, "scale_after": scale_after,
+                    "skipped_steps_in_timed_region": (0 if scale_after >= scale_before else int(round(math.log2(scale_before / scale_after)))),
+                    "settling_warmup_steps": extra_warm, "scale_trace_during_warmup": scale_trace}
     host_ms = host_s / steps * 1e3
     for label in sorted(timeline):
         d = timeline[label]
@@ -189,7 +216,8 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
 
     if not pieces:
         return {"value": round((shard.n_seed_groups if shard is not None and not proxy_group else 1) / dt, 3), "ms_per_step": round(dt * 1e3, 2),
-                "host_enqueue_ms_per_step": round(host_ms, 2), "host_cpu_ms_per_step": round(host_cpu_ms, 2)}
+                "host_enqueue_ms_per_step": round(host_ms, 2), "host_cpu_ms_per_step": round(host_cpu_ms, 2),
+                "grad_scaler": amp_info, "final_loss": last_loss}
     lat = torch.randn(B, 4, 64, 64, device=dev)
     ctrl = pose.permute(0, 3, 1, 2)
     emb = torch.randn(3 * B, 81, 768, device=dev, dtype=torch.float16) * 0.1
@@ -217,7 +245,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
         lay = "single GPU" if world == 1 else "replicas: %d ranks x 4 cameras, one averaged optimizer step" % world
     out = {"metric": "ahds_train_steps_per_s", "value": round(opt_steps / dt, 3), "unit": "optimizer steps/s", "ms_per_step": round(dt * 1e3, 2),
            "views_per_s": round(opt_steps * views_per_step / dt, 2), "views_per_optimizer_step": views_per_step, "n_gpus": world,
-           "layout": lay, "amp_gradscaler": bool(amp), "fused_adam": bool(fused_adam),
+           "layout": lay, "amp_gradscaler": bool(amp), "grad_scaler": amp_info, "final_loss": last_loss, "fused_adam": bool(fused_adam),
            "timed_step": "lr update + render 4 views + GPU pose maps + prompt lookup + VAE/ControlNet/U-Net ANPG + loss + backward + densification stats + Adam", "config": {"workload": "BASELINE.json configs[2]: 100k Gaussians, 1024^2, bs 4, SD1.5+ControlNet ANPG (batch 12, fp16), random-init weights", "gaussians": P},
            "host_enqueue_ms_per_step": round(host_ms, 2), "host_cpu_ms_per_step": round(host_cpu_ms, 2), "denoise_ms": round(den_ms, 2), "vae_enc_fwd_bwd_ms": round(vae_ms, 2), "setup_s": round(setup_s, 1),
            "denoise_flops": flops, "denoise_tflops_per_s": None if not flops else round(flops / (den_ms * 1e-3) / 1e12, 1),

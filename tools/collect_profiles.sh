@@ -30,12 +30,14 @@ for k in sorted(agg):
     traffic[stage] = int(fetch + write)
     pmc[stage] = dict(c, hbm_fetch_bytes=int(fetch), hbm_write_bytes=int(write))
     lines.append("%-34s HBM bytes/launch ~ %12d (fetch x2 %12d + write %12d)  " % (k, fetch + write, fetch, write) + "  ".join("%s=%.4g" % kv for kv in sorted(c.items())))
-import hashlib
+import sys
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
-sha = hashlib.sha256(open(root + "/gaussianip_amd/lib/libgip_raster.so", "rb").read()).hexdigest()[:16]
-pmc["_build"] = {"libgip_raster_sha16": sha, "git": os.environ.get("GIP_GIT", "unknown"),
-                 "note": "bench.py emits roofline.traffic / roofline_valu only when this hash equals the library it runs"}
-lines.insert(0, "# counters of libgip_raster.so sha256[:16] = %s, git %s" % (sha, os.environ.get("GIP_GIT", "unknown")))
+sys.path.insert(0, root)
+import bench
+sha = bench.raster_source_hash()
+pmc["_build"] = {"raster_source_sha16": sha, "git": os.environ.get("GIP_GIT", "unknown"),
+                 "note": "sha256[:16] of the rasterizer's kernel sources + headers + Makefile (bench.raster_source_hash); bench.py emits roofline.traffic / roofline_valu only when it equals the sources it was built from"}
+lines.insert(0, "# counters of raster sources sha256[:16] = %s, git %s" % (sha, os.environ.get("GIP_GIT", "unknown")))
 open(out + "/pmc_summary.txt", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
 json.dump(pmc, open(out + "/pmc.json", "w"), indent=1)
