@@ -532,7 +532,35 @@ def main():
                     model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
             except OSError:
                 pass
+            # the vectorised PyTorch-CPU leg — the dense float64 formulation of tests/dense_reference.py
+            # (every Gaussian at every pixel, culling as masks; shares no code with the C oracle) on a bounded sample: its
+            # memory is P x H x W doubles per temporary, so 2 000 Gaussians at 128 x 128, forward only
+            torch_leg = None
+            try:
+                import dense_reference as dr
+                old_threads = torch.get_num_threads()
+                torch.set_num_threads(ncores)
+                Pd, Hd = 2000, 128
+                sd = dr.random_scene(Pd, 42)
+                view, full, campos, tanx, tany = dr.look_at_camera(5.0, 90.0, 1.8, 70.0, Hd, Hd)
+                kwd = dict(viewmatrix=view, projmatrix=full, campos=campos, bg=torch.zeros(3, dtype=torch.float64), H=Hd, W=Hd,
+                           tanfovx=tanx, tanfovy=tany, sh_degree=0, **sd)
+                with torch.no_grad():
+                    dr.dense_render(**kwd)
+                    td = []
+                    for _ in range(5):
+                        c1 = time.perf_counter()
+                        dr.dense_render(**kwd)
+                        td.append(time.perf_counter() - c1)
+                td.sort()
+                torch.set_num_threads(old_threads)
+                torch_leg = {"value": round(Hd * Hd / td[2] / 1e6, 4), "unit": "Mpix/s", "pair_evals_per_s": round(Pd * Hd * Hd / td[2], 0),
+                             "threads": ncores, "sample": "median of 5 forward renders of %d random Gaussians at %dx%d, dense float64 PyTorch "
+                                                          "formulation (tests/dense_reference.py), torch.set_num_threads(%d)" % (Pd, Hd, Hd, ncores)}
+            except Exception as e:      # noqa: BLE001
+                torch_leg = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             cpu = {"value": round(reps * H * W / tt / 1e6, 3), "unit": "Mpix/s", "cores": ncores, "threads": nthreads, "cpu_model": model, "kind": "port",
+                   "pytorch_cpu_vectorised": torch_leg,
                    "forward_only_value": round(H * W / t_fwd[2] / 1e6, 3),
                    "sample": "median of 5 x (1 view forward, then backward; P=%d, %dx%d) after one warm-up, on the C oracle "
                              "(oracle/raster_oracle.c, OpenMP over tiles, %d threads); value = forward+backward" % (P, H, W, ncores)}

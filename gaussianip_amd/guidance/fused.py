@@ -262,7 +262,13 @@ class LayerNorm(nn.LayerNorm):
 # 3x3 / stride 1 / pad 1 convolution on the matrix cores (csrc/conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------------
 _GN_SUMS_MIN_TILES = 256    # below it the data gradient runs split-K, whose reduce kernel does not make the sums
-_MIN_CONV_TILES = 32         # tile counts below 256 run split-K (fp32 slabs in the shared workspace); tiny problems stay on MIOpen
+# Tile counts below 256 run split-K (fp32 slabs in the shared workspace).  The floor was 32 until round 4: below it the layer
+# went to MIOpen — which is what the 8 x 8 level of a 2-view shard (batch 6: 30 tiles) and the 16 x 16 / 8 x 8 levels of a
+# 1-view shard (batch 3) did, and MIOpen's small-problem kernels there are atomic split-K ones: the denoise of a sharded
+# step was NOT reproducible run to run (tools/diag/denoise_bisect.py: first differing module down_sample.2 at batch 6,
+# down_sample.1 at batch 3; 2.4e-3 of the output) and slow.  The MFMA kernel with split-K 16 takes them all (bitwise
+# reproducible: fixed summation order); only single-tile problems stay on the library.
+_MIN_CONV_TILES = int(os.environ.get("GIP_MIN_CONV_TILES", "2"))
 _SPLITK_WS_BYTES = 64 << 20
 _WT_CACHE_MAX = 512
 
