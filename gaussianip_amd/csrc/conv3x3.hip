@@ -98,7 +98,15 @@ __device__ __forceinline__ void gnb_accumulate(const GnBwdArgs& a, const GnBwdLa
 // TAPS = 9: the 3x3 convolution.  TAPS = 1: the same machinery as a plain GEMM out[m][co] = sum_k x[m][k] w[co][k]
 // (nn.Linear / 1x1 convolution on the NHWC token view; H = 1, W = M).  GEGLU (TAPS = 1 only): w has 2 * Cout rows
 // [value | gate]; a workgroup computes 64 value and the matching 64 gate columns and writes value * gelu(gate).
-template <int BN, int STAGES, int TAPS, bool GEGLU>
+// HALO (TAPS = 9, Cin = 128, stride 1, pad 1, all nine taps, no split-K, H % 8 == 0, W % 16 == 0): the pixel tile is a 16 x 8
+// BLOCK of the image instead of 128 consecutive pixels, and its 18 x 10 x 128-channel halo is brought into LDS ONCE (46 KB);
+// the nine taps then read their fragments from that one image at shifted rows.  The K loop only streams the weights: 16 KB of
+// LDS-DMA per K step instead of 32, plus 46 KB once instead of 9 x 32 KB of pixels.  Why: at Cin = 128 (the VAE encoder's first
+// level, 4 x 512^2: 8 of its convolutions, 4.1 ms of the training step at 675 TFLOP/s) the K loop is only 18 steps and the
+// kernel is bound by its L2 -> LDS traffic (tools/exp_conv_ablate.py: the DMA stream alone = 70 % of the kernel).
+#define CVH_ROWS 184                      // halo rows held per channel block (180 used: 10 x 18; waves 0-2 of the sixth round)
+#define CVH_KC_BYTES (CVH_ROWS * 128)
+template <int BN, int STAGES, int TAPS, bool GEGLU, bool HALO = false>
 __global__ void __launch_bounds__(CV_THREADS, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
@@ -124,9 +132,11 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   }
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int A_BYTES = CV_BM * 128;          // pixel tile: 128 rows x 64 halves
+  constexpr int A_BYTES = HALO ? 0 : CV_BM * 128;   // pixel tile: 128 rows x 64 halves (HALO: the pixels live in the halo image)
   constexpr int B_BYTES = BN * 128;             // weight tile: BN rows x 64 halves
   constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int HALO_BYTES = HALO ? 2 * CVH_KC_BYTES : 0;       // [2 channel blocks][184 halo rows][128 B], in front of the stages
+  static_assert(!HALO || (TAPS == 9 && !GEGLU), "halo mode: 3x3 convolution");
   constexpr int B_ROUNDS = BN / 32;
   constexpr int NI = BN / 32;                   // 16-channel MFMA tiles per wave (its half of BN)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -146,6 +156,19 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   const int mt = nmajor ? t % m_tiles : t / n_tiles, nt = nmajor ? t / m_tiles : t - (t / n_tiles) * n_tiles;
   const unsigned M = (unsigned)N * H * W;          // < 2^31 (checked on the host): 32-bit index arithmetic throughout
   const unsigned m0 = (unsigned)mt * CV_BM;
+  // HALO: tile mt = block (n, by, bx) of 8 rows x 16 columns; tile row r = pixel (by * 8 + (r >> 4), bx * 16 + (r & 15)).
+  // Tiles stay sample-major (mt / (HW / 128) = n), so the per-128-row statistics blocks still never straddle two samples.
+  unsigned h_n = 0, h_y0 = 0, h_x0 = 0;
+  if constexpr (HALO) {
+    const unsigned tiles_x = (unsigned)W >> 4, per_img = tiles_x * ((unsigned)H >> 3);
+    h_n = (unsigned)mt / per_img;
+    const unsigned rem = (unsigned)mt - h_n * per_img, by = rem / tiles_x;
+    h_y0 = by * 8u; h_x0 = (rem - by * tiles_x) * 16u;
+  }
+  auto row_m = [&](int row) -> unsigned {          // linear NHWC pixel index of tile row `row`
+    if constexpr (HALO) return (h_n * (unsigned)H + h_y0 + ((unsigned)row >> 4)) * (unsigned)W + h_x0 + ((unsigned)row & 15u);
+    else return m0 + (unsigned)row;
+  };
   const int co0 = nt * (GEGLU ? BN / 2 : BN);      // first OUTPUT channel of the tile
   const int HW = H * W;
 
@@ -155,7 +178,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   unsigned a_off[4];                                     // byte offset of the centre pixel's channel 0 (+ swizzled chunk)
   unsigned a_mask[4];                                    // 9 validity bits, one per tap
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < (HALO ? 0 : 4); i++) {
     const int row = i * 32 + sub_row;
     const unsigned m = m0 + row;
     const int lchunk = pchunk ^ ((row >> 1) & 7);
@@ -212,12 +235,14 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     const int dy = tap / 3, dx = tap - dy * 3;
     const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * Win + dx) * Cin : 0) + cb * CV_BK) * 2u;   // relative to the shifted base
     const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
-    unsigned char* sa = smem + buf * STAGE + wave * 1024;
-    if (!((geom >> 26) & 1)) {
+    if constexpr (!HALO) {
+      unsigned char* sa = smem + buf * STAGE + wave * 1024;
+      if (!((geom >> 26) & 1)) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 4096);
+        for (int i = 0; i < 4; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 4096);
+      }
     }
-    unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * 1024;
+    unsigned char* sb = smem + HALO_BYTES + buf * STAGE + A_BYTES + wave * 1024;
     if (!((geom >> 27) & 1)) {
 #pragma unroll
       for (int i = 0; i < B_ROUNDS; i++) dma16(wr, b_off[i], wtap_off, sb + i * 4096);
@@ -234,14 +259,30 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   const int frag_row = lane & 15, swz = (lane >> 1) & 7, kq = lane >> 4;
   const int pix_base = (wm * 64 + frag_row) * 128;
   const int ch_base = A_BYTES + (wn * (BN / 2) + frag_row) * 128;
+  // HALO: halo row of this lane's pixel of fragment tile mi at the (0, 0) tap: (wm * 4 + mi) * 18 + (lane & 15); tap (dy, dx)
+  // adds dy * 18 + dx.  The chunk swizzle is that of the halo row the fragment row sits in.
+  const int hrow0 = wm * 4 * 18 + frag_row;
 
-  auto compute = [&](const unsigned char* sbuf) {
+  auto compute = [&](const unsigned char* sbuf, int tap_c, int cb_c) {
+    int hoff[4], hswz[4];
+    if constexpr (HALO) {
+      const int shift_rows = (tap_c / 3) * 18 + (tap_c - (tap_c / 3) * 3);
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) {
+        const int hr = hrow0 + mi * 18 + shift_rows;
+        hoff[mi] = cb_c * CVH_KC_BYTES + hr * 128;
+        hswz[mi] = (hr >> 1) & 7;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const int pc = ((ks * 4 + kq) ^ swz) * 16;
       f16x8 pix[4], wt[NI];
 #pragma unroll
-      for (int mi = 0; mi < 4; mi++) pix[mi] = *(const f16x8*)(sbuf + pix_base + mi * 2048 + pc);
+      for (int mi = 0; mi < 4; mi++) {
+        if constexpr (HALO) pix[mi] = *(const f16x8*)(smem + hoff[mi] + (((ks * 4 + kq) ^ hswz[mi]) << 4));
+        else pix[mi] = *(const f16x8*)(sbuf + pix_base + mi * 2048 + pc);
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ni++) wt[ni] = *(const f16x8*)(sbuf + ch_base + ni * 2048 + pc);
 #pragma unroll
@@ -267,14 +308,35 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   // three-stage single-workgroup-per-CU variant and BK = 32 variants with 3 / 4 stages and counted vmcnt were measured
   // slower: tools/experiments/conv3x3_bk32_multistage.hip.txt holds both.)
   static_assert(STAGES == 2, "one pipeline depth is built");
+  if constexpr (HALO) {
+    // the halo image, once: 6 rounds of 32 rows per channel block (round 5: waves 0-2 only, rows 160..183; rows >= 180 and
+    // pixels outside the image read zeros from an out-of-range offset).  Row r = halo pixel (r / 18, r % 18) = image pixel
+    // (y0 - 1 + r / 18, x0 - 1 + r % 18); chunk swizzle (r >> 1) & 7 on the source address as in the stage images.
+    const __amdgpu_buffer_rsrc_t xh = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(M * (unsigned)Cin * 2u), CV_RSRC_FLAGS);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (i == 5 && wave == 3) break;
+      const int hr = i * 32 + sub_row;
+      const int hy = hr / 18, hx = hr - hy * 18;
+      const int iy = (int)h_y0 - 1 + hy, ix = (int)h_x0 - 1 + hx;
+      const int lchunk = pchunk ^ ((hr >> 1) & 7);
+      const bool ok = hr < 180 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const unsigned off = ok ? (((h_n * (unsigned)H + (unsigned)iy) * (unsigned)W + (unsigned)ix) * (unsigned)Cin + lchunk * 8) * 2u : CV_OOB;
+      dma16(xh, off, 0u, smem + i * 4096 + wave * 1024);
+      dma16(xh, off, 128u, smem + CVH_KC_BYTES + i * 4096 + wave * 1024);
+    }
+  }
+  int tap_c = tap, cb_c = cb;                      // (tap, channel block) of the step being COMPUTED (stage() runs one ahead)
   stage(tap, cb, 0);
   advance();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < KT; kt++) {
     const int buf = kt & 1;
+    const int tap_n = tap, cb_n = cb;
     if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
-    if (!((geom >> 28) & 1)) compute(smem + buf * STAGE);
+    if (!((geom >> 28) & 1)) compute(smem + HALO_BYTES + buf * STAGE, tap_c, cb_c);
+    tap_c = tap_n; cb_c = cb_n;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -331,7 +393,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
           const int row = r0 + k * RPP;
-          const unsigned m = m0 + row;
+          const unsigned m = row_m(row);
           rres[k] = (row < CV_BM && m < M) ? *(const f16x8*)(early_src + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
       }
@@ -357,11 +419,11 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       for (int j = 0; j < 8; j++) { s8[j] = 0.f; q8[j] = 0.f; }
       if (mine) {
         GnBwdLane gl;
-        if (chan_stats && gnb.x) gnb_load(gnb, (int)(m0 / (unsigned)gnb.HW), co, Cout, gl);
+        if (chan_stats && gnb.x) gnb_load(gnb, (int)(HALO ? h_n : m0 / (unsigned)gnb.HW), co, Cout, gl);
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
           const int row = r0 + k * RPP;
-          const unsigned m = m0 + row;
+          const unsigned m = row_m(row);
           if (row >= CV_BM || m >= M) break;
           f16x8 v = *(const f16x8*)(smem + row * ROWB + chunk * 16);
           if (residual) {
@@ -878,6 +940,30 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
     }
   }
   const int m_tiles = (int)((M + CV_BM - 1) / CV_BM), n_tiles = (Cout + (GEGLU ? BN / 2 : BN) - 1) / (GEGLU ? BN / 2 : BN);
+  if constexpr (BN == 128 && TAPS == 9 && !GEGLU) {
+    // halo-resident pixel tile (see conv3x3_kernel): Cin = 128, plain 3x3 / stride 1 / pad 1, whole-K tiles that fill the chip
+    static const int env_halo = env_int("GIP_CONV_HALO", 1);
+    static const int env_epi_h = env_int("GIP_CONV_EPILOGUE", 1);
+    if (env_halo && env_epi_h && gip_dbg_conv_epilogue != 0 && gip_dbg_conv_ksplit <= 0 && Cin == 128 && (geom & 0xffffff) == (1 | (1 << 8) | (1 << 16)) &&
+        tapsel == 0x1ff && !(H & 7) && !(W & 15) && Hin == H && Win == W && !(Cout & 7) && stats_rows == 128 &&
+        (long long)m_tiles * n_tiles >= 256 && !(gnb.x && gnb.HW != H * W)) {
+      constexpr size_t lds_h = 2 * (size_t)CVH_KC_BYTES + STAGES * (size_t)BN * 128;
+      static_assert((size_t)CV_BM * (BN * 2 + 16) + (size_t)(CV_THREADS / (BN / 8)) * BN * 8 <= lds_h, "epilogue image must fit");
+      static bool attr_h = false;
+      if (!attr_h) {
+        if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN, STAGES, TAPS, GEGLU, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_h) != hipSuccess)
+          return 3;
+        attr_h = true;
+      }
+      static const int env_res_h = env_int("GIP_CONV_RES_EARLY", 1);
+      const int geom_h = geom | (1 << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (env_res_h << 29);
+      hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU, true>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds_h, s,
+                         (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
+                         N, H, W, Cin, Cout, m_tiles, n_tiles, 1, (float*)nullptr, Hin, Win, geom_h, chan_stats, gnb, tapsel);
+      return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
+  }
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
   static_assert((size_t)CV_BM * (BN * 2 + 16) + (size_t)(CV_THREADS / (BN / 8)) * BN * 8 <= STAGES * (size_t)(CV_BM + BN) * 128,
                 "epilogue tile image + statistics partials must fit in the stage buffers");

@@ -119,8 +119,9 @@ def graph_signature():
 
 
 def producer_stats(x):
-    """chan_stats [N * HW / R, C, 2] float32 (R = 128 rows per block, or 64 at the 8 x 8 level) that the kernel which
-    produced `x` wrote in its epilogue (attached to the tensor OBJECT by conv3x3 / linear below; any view / copy of x drops
+    """chan_stats [N * HW / R, C, 2] float32 (R = 128 pixels per block — 128 consecutive pixels, or one 16 x 8 image block
+    when the halo-resident convolution kernel produced x; a block never straddles two samples and the consumers only sum a
+    sample's blocks — or 64 at the 8 x 8 level) that the kernel which produced `x` wrote in its epilogue (attached to the tensor OBJECT by conv3x3 / linear below; any view / copy of x drops
     it and the GroupNorm takes its own statistics pass), or None."""
     st = getattr(x, _STATS_ATTR, None)
     if st is None or x.dim() != 4:

@@ -253,22 +253,30 @@ class ViewSharding:
       * depth normaliser          = MAX over the group   (:225)
     densify / prune then runs on every rank from identical statistics with an identically seeded generator."""
 
-    def __init__(self, n_views: int = 4, rank: Optional[int] = None, world: Optional[int] = None, make_groups: bool = True):
+    def __init__(self, n_views: int = 4, rank: Optional[int] = None, world: Optional[int] = None, make_groups: bool = True,
+                 group_size: Optional[int] = None):
+        """`group_size` (default min(world, n_views): BASELINE configs[3]'s 4 views x 2 seeds at 8 GPUs): ranks per seed group.
+        A smaller divisor of n_views trades view sharding for seed replication — 8 GPUs as 4 seed groups of 2 ranks x 2 views
+        keep every rank's networks at batch 6 instead of 3 (the one-GPU proxy of bench.py prices both)."""
         on = dist.is_available() and dist.is_initialized()
         self.world = world if world is not None else (dist.get_world_size() if on else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if on else 0)
         self.n_views = n_views
-        if self.world > n_views and self.world % n_views != 0:
-            # e.g. 6 ranks x 4 views: ranks 4 and 5 would re-render views 0 and 1 inside the one group and count twice
-            raise ValueError("ViewSharding: world size %d is neither <= n_views nor a multiple of n_views = %d" % (self.world, n_views))
-        self.group_size = min(self.world, n_views)
+        if group_size is None:
+            if self.world > n_views and self.world % n_views != 0:
+                # e.g. 6 ranks x 4 views: ranks 4 and 5 would re-render views 0 and 1 inside the one group and count twice
+                raise ValueError("ViewSharding: world size %d is neither <= n_views nor a multiple of n_views = %d" % (self.world, n_views))
+            group_size = min(self.world, n_views)
+        if group_size < 1 or group_size > n_views or self.world % group_size:
+            raise ValueError("ViewSharding: group_size %d must be <= n_views = %d and divide the world size %d" % (group_size, n_views, self.world))
+        self.group_size = group_size
         self.n_seed_groups = max(1, self.world // self.group_size)
         self.seed_id = self.rank // self.group_size
         self.local_rank = self.rank % self.group_size
         self.views = shard_views(n_views, self.local_rank, self.group_size)
         self.share = len(self.views) / float(n_views)
         self.group = None
-        if on and make_groups and self.n_seed_groups > 1:
+        if on and make_groups and self.n_seed_groups > 1 and self.group_size > 1:
             for g in range(self.n_seed_groups):          # every rank creates every group (torch.distributed contract)
                 ranks = list(range(g * self.group_size, (g + 1) * self.group_size))
                 grp = dist.new_group(ranks)

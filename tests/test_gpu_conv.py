@@ -190,7 +190,11 @@ def test_conv_big_tile_kernel(shape):
                 holder = []
                 ys = fused._conv_call(x, w, co, b, r, holder)
                 assert holder and torch.equal(ys, outs[big][1])
-                rows = ys.permute(0, 2, 3, 1).reshape(-1, 128, co).double()
+                if ci == 128 and not big and H % 8 == 0 and W % 16 == 0:
+                    # the halo-resident kernel (Cin = 128): a statistics block is a 16 x 8 image block, not 128 consecutive pixels
+                    rows = ys.reshape(N, co, H // 8, 8, W // 16, 16).permute(0, 2, 4, 3, 5, 1).reshape(-1, 128, co).double()
+                else:
+                    rows = ys.permute(0, 2, 3, 1).reshape(-1, 128, co).double()
                 want = torch.stack([rows.sum(1), (rows * rows).sum(1)], dim=-1)
                 assert float((holder[0].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     finally:
@@ -458,3 +462,77 @@ def test_winograd_convolution_at_the_16x16_level(cfg, monkeypatch):
     rows = out2.permute(0, 2, 3, 1).reshape(-1, 128, cout).double()
     want = torch.stack([rows.sum(1), (rows * rows).sum(1)], dim=-1)
     assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+HALO_SHAPES = [(2, 128, 128, 128), (3, 512, 48, 64), (1, 128, 8, 4096), (4, 128, 64, 128)]      # N, Cout, H, W (Cin = 128)
+
+
+@pytest.mark.parametrize("shape", HALO_SHAPES)
+@pytest.mark.parametrize("mode", ["plain", "bias_residual_stats"])
+def test_halo_resident_tile_of_the_128_channel_convolution(shape, mode):
+    """Cin = 128 (the VAE encoder's first level): the pixel tile is a 16 x 8 image block whose halo sits in LDS once and the K
+    loop streams only weights (conv3x3_kernel<..., HALO>).  Against F.conv2d in fp32, bitwise against the streaming kernel (same
+    K order: tap-major, then channel block — same MFMA sequence), with the per-channel statistics of its epilogue; image borders,
+    several samples, two channel tiles."""
+    import ctypes
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    N, co, H, W = shape
+    assert fused._conv_tiles(N, H, W, co) >= 256 and H % 8 == 0 and W % 16 == 0
+    g = torch.Generator(device="cuda").manual_seed(co + H + W)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, 128, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(co, 128, 3, 3, device="cuda", generator=g) / 34.0).half().contiguous(**cl)
+    full = mode != "plain"
+    b = torch.randn(co, device="cuda", generator=g).half() if full else None
+    r = torch.randn(N, co, H, W, device="cuda", generator=g).half().contiguous(**cl) if full else None
+    holder = [] if full else None
+    out = fused._conv_call(x, w, co, b, r, holder)
+    knob = ctypes.c_int.in_dll(_lib.nn_lib(), "gip_dbg_conv_epilogue")
+    knob.value = 0                                   # per-lane epilogue: the halo path needs the LDS one, so this is the streaming kernel
+    try:
+        base = fused._conv_call(x, w, co, b, r, None)
+    finally:
+        knob.value = -1
+    ref = F.conv2d(x.float(), w.float(), None if b is None else b.float(), padding=1)
+    if full:
+        ref = ref.half().float() + r.float()        # fp16(fp16(conv + bias) + residual)
+    err = float((out.float() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-3, err
+    assert torch.equal(out, base), "halo and streaming kernels differ: %g" % float((out.float() - base.float()).abs().max())
+    if full:
+        st = holder[0]
+        rows = out.permute(0, 2, 3, 1).float()
+        tot = torch.stack([rows.reshape(N, -1, co).double().sum(1), (rows.reshape(N, -1, co).double() ** 2).sum(1)], dim=-1)   # per sample
+        got = st.reshape(N, -1, co, 2).double().sum(1)
+        assert float((got - tot).abs().max()) <= 2e-5 * float(tot.abs().max())
+        # a statistics block = the 128 pixels of ONE 16 x 8 image block of one sample
+        blk = out.float().reshape(N, co, H // 8, 8, W // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(N * (H // 8) * (W // 16), co, 128)
+        want = torch.stack([blk.double().sum(-1), (blk.double() ** 2).sum(-1)], dim=-1)
+        assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_halo_kernel_as_data_gradient_with_groupnorm_backward_sums():
+    """The same kernel as the data gradient of conv1 / conv2 of the VAE's first ResnetBlock2D, with the GroupNorm-backward
+    reductions in its epilogue (gip_conv3x3_gnbwd_nhwc_f16): output and sums against the streaming kernel."""
+    import ctypes
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    N, C, H, W = 2, 128, 128, 128
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cl = dict(memory_format=torch.channels_last)
+    dy = (torch.randn(N, C, H, W, device="cuda", generator=g) * 0.1).half().contiguous(**cl)
+    xg = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(C, C, 3, 3, device="cuda", generator=g) / 34.0).half().contiguous(**cl)
+    gn = fused.GroupNormAct(32, C, eps=1e-6, act=True).cuda().half().requires_grad_(False)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, device="cuda", generator=g) * 0.5 + 1.0)
+        gn.bias.copy_(torch.randn(C, device="cuda", generator=g) * 0.2)
+    _, mean, rstd = fused._gn_fwd_raw(xg, gn, None, None)
+    out, sums = fused._dgrad_with_gn_sums(dy, w, xg, gn, mean, rstd, None)
+    assert sums is not None
+    dx = fused._gn_bwd_raw(xg, out, gn, mean, rstd, None, chan_sums=sums)
+    plain = fused._conv_call(dy, fused._transposed_weight(w), C)
+    assert torch.equal(out, plain)
+    dx_ref = fused._gn_bwd_raw(xg, plain, gn, mean, rstd, None)          # its own reduction pass
+    assert float((dx.float() - dx_ref.float()).abs().max()) <= 2e-3 * float(dx_ref.float().abs().max())

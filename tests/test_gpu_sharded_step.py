@@ -106,3 +106,8 @@ def test_view_sharding_layouts():
     assert lay(4) == [(0, [0]), (0, [1]), (0, [2]), (0, [3])]
     assert lay(8) == [(0, [0]), (0, [1]), (0, [2]), (0, [3]), (1, [0]), (1, [1]), (1, [2]), (1, [3])]      # 4 views x 2 seeds
     assert ViewSharding(4, 5, 8, make_groups=False).share == 0.25
+    # 8 GPUs as 4 seed groups of 2 ranks x 2 views
+    lay2 = [(v.seed_id, v.views, v.n_seed_groups) for v in (ViewSharding(4, r, 8, make_groups=False, group_size=2) for r in range(8))]
+    assert lay2 == [(0, [0, 2], 4), (0, [1, 3], 4), (1, [0, 2], 4), (1, [1, 3], 4), (2, [0, 2], 4), (2, [1, 3], 4), (3, [0, 2], 4), (3, [1, 3], 4)]
+    with pytest.raises(ValueError):
+        ViewSharding(4, 0, 8, make_groups=False, group_size=3)      # 3 does not divide the world size

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None, amp=True,
-            fused_adam=True, layout="views", trained=False, proxy_group=0, pieces=True):
+            fused_adam=True, layout="views", trained=False, proxy_group=0, pieces=True, group_size=None):
     """Runs the step `warmup + steps` times and returns the result dict.  The timed step is the reference's
     training_step + optimizer step as the system runs them (system.StageOneStep.training_step / optimizer_step):
     learning-rate update, render of the 4 cameras, OpenPose pose maps drawn on the GPU from the batch's mvp matrices,
@@ -50,7 +50,7 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     dev = torch.device("cuda") if device is None else device
     torch.manual_seed(42)
     rng = np.random.default_rng(42)
-    shard = parallel.ViewSharding(4) if (world > 1 and layout == "views") else None
+    shard = parallel.ViewSharding(4, group_size=group_size) if (world > 1 and layout == "views") else None
     if proxy_group:
         shard = parallel.ViewSharding(4, rank=0, world=proxy_group, make_groups=False)       # inactive: no process group -> no collectives
     # views layout: every rank of a seed group draws the SAME 4 cameras (seed offset per seed group, launch.py:80) and
