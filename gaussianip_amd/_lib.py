@@ -129,6 +129,10 @@ def knn_lib():
         lib.gip_knn_workspace_bytes.argtypes = [ctypes.c_int32]
         lib.gip_knn_mean_dist2.restype = ctypes.c_int
         lib.gip_knn_mean_dist2.argtypes = [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_size_t, _vp]
+        lib.gip_knn_workspace_bytes_mode.restype = ctypes.c_size_t
+        lib.gip_knn_workspace_bytes_mode.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        lib.gip_knn_mean_dist2_mode.restype = ctypes.c_int
+        lib.gip_knn_mean_dist2_mode.argtypes = [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int32, _vp]
         _knn = _Counted(lib)
     return _knn
 

@@ -1,22 +1,45 @@
 // knn.hip — mean squared distance to the 3 nearest neighbours (distCUDA2 replacement) for gfx950.
 //
-// Reference: gaussiansplatting/submodules/simple-knn/simple_knn.cu — updateKBest<3> :131-145,
-// boxMeanDist :147-183, SimpleKNN::knn :185-221 (Morton sort + 1024-point boxes used only to prune).
+// Reference: gaussiansplatting/submodules/simple-knn/simple_knn.cu — coord2Morton :45-71, boxMinMax :79-119, distBoxPoint
+// :121-131, updateKBest<3> :133-147, boxMeanDist :149-185 (Morton sort + 1024-point boxes used only to PRUNE the exact
+// search), SimpleKNN::knn :187-221.
 //
-// MI355X formulation: exact tiled all-pairs.  A workgroup owns 256 query points (one per lane, best-3 kept
-// in registers) and streams the whole cloud through LDS in tiles of 1024 points stored as SoA float arrays;
-// every LDS read is a wave-wide broadcast, the global loads are perfectly coalesced, and there is no sort, no
-// host read-back and no data-dependent control flow.  P = 100k (the shipped init) is 1e10 pair evaluations
-// ~ 5 ms on one MI355X, run once per training job.  (For P >> 1M a cell-pruned variant is the next step.)
-// Compiled with -ffp-contract=off so dx*dx + dy*dy + dz*dz rounds exactly like the CPU oracle.
+// Two exact formulations, the same result bit for bit (out[i] = (d1 + d2 + d3) / 3 of the three smallest squared distances,
+// each d = dx*dx + dy*dy + dz*dz, compiled with -ffp-contract=off so it rounds exactly like the CPU oracle):
+//
+//  * all-pairs (small clouds): a workgroup owns 256 query points (one per lane, best-3 in registers) and streams the whole
+//    cloud through LDS in 1024-point SoA tiles; every LDS read is a wave-wide broadcast, no sort, no data-dependent control
+//    flow.  1e10 pair evaluations at the shipped 100k points ~ 5 ms, once per training job.
+//
+//  * box-pruned (P > GIP_KNN_PRUNE_FROM): the reference's scheme, laid out for wave64 — points are sorted by a 30-bit Morton
+//    code (rocPRIM device radix sort on (code << 32 | index) keys: unique keys, deterministic order), copied once into
+//    Morton order as SoA, and every run of 1024 sorted points gets its bounding box.  A workgroup then owns 256 CONSECUTIVE
+//    sorted queries — spatial neighbours — so its lanes want nearly the same boxes: a box is staged into LDS (contiguous,
+//    coalesced: no per-candidate index gather as in the reference's per-thread loop) when ANY lane of the workgroup cannot
+//    reject it, and scanned by the waves that need it with the all-pairs inner loop.  A lane rejects a box when the box is
+//    farther than its current third-best distance or than the third-best among its +-3 neighbours in Morton order (the
+//    reference's `reject`): both are upper bounds of the true third-nearest distance, so the pruning is exact.  1M points:
+//    ~1e12 pair evaluations all-pairs vs a few 1e9 here.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 #include "../../include/gip_knn.h"
 
 #define KNN_BLOCK 256
 #define KNN_TILE 1024
+#define KNN_BOX 1024                      // simple_knn.cu: BOX_SIZE
+
+__device__ __forceinline__ void best3(float d, float& b0, float& b1, float& b2) {
+  // keep the three smallest in ascending order (branch-free insertion)
+  const float n0 = fminf(b0, d), m0 = fmaxf(b0, d);
+  const float n1 = fminf(b1, m0), m1 = fmaxf(b1, m0);
+  b0 = n0; b1 = n1; b2 = fminf(b2, m1);
+}
 
 __global__ void __launch_bounds__(KNN_BLOCK)
 gip_knn_kernel(int P, const float* __restrict__ pts, float* __restrict__ out) {
@@ -37,23 +60,225 @@ gip_knn_kernel(int P, const float* __restrict__ pts, float* __restrict__ out) {
       const float dx = sx[t] - rx, dy = sy[t] - ry, dz = sz[t] - rz;
       float d = dx * dx + dy * dy + dz * dz;
       if (base + t == i) d = FLT_MAX;                 // self excluded
-      // keep the three smallest in ascending order (branch-free insertion)
-      const float n0 = fminf(b0, d), m0 = fmaxf(b0, d);
-      const float n1 = fminf(b1, m0), m1 = fmaxf(b1, m0);
-      b0 = n0; b1 = n1; b2 = fminf(b2, m1);
+      best3(d, b0, b1, b2);
     }
   }
   if (i < P) out[i] = (b0 + b1 + b2) / 3.0f;
 }
 
-extern "C" size_t gip_knn_workspace_bytes(int32_t P) { (void)P; return 256; }
+// ---------------------------------------------------------------------------------------------------------------------
+// box-pruned path
+// ---------------------------------------------------------------------------------------------------------------------
+// order-preserving float <-> uint map, so that min / max over the cloud are integer atomics (order-independent: deterministic)
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+struct KnnBounds { unsigned lo[3], hi[3]; };
+
+__global__ void knn_bounds_init_kernel(KnnBounds* b) {
+  // the reference's reductions start from (0, 0, 0) (simple_knn.cu:193-201: `init`): the origin is inside the bounds
+  if (threadIdx.x < 3) { b->lo[threadIdx.x] = f2ord(0.f); b->hi[threadIdx.x] = f2ord(0.f); }
+}
+
+__global__ void __launch_bounds__(KNN_BLOCK)
+knn_bounds_kernel(int P, const float* __restrict__ pts, KnnBounds* b) {
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = blockIdx.x * KNN_BLOCK + threadIdx.x; i < P; i += gridDim.x * KNN_BLOCK)
+#pragma unroll
+    for (int a = 0; a < 3; a++) { const float v = pts[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&b->lo[a], f2ord(lo[a])); atomicMax(&b->hi[a], f2ord(hi[a])); }
+  }
+}
+
+__device__ __forceinline__ unsigned spread10(unsigned x) {          // 10 bits -> every third bit
+  x = (x | (x << 16)) & 0x030000FFu;
+  x = (x | (x << 8)) & 0x0300F00Fu;
+  x = (x | (x << 4)) & 0x030C30C3u;
+  x = (x | (x << 2)) & 0x09249249u;
+  return x;
+}
+
+__global__ void __launch_bounds__(KNN_BLOCK)
+knn_keys_kernel(int P, const float* __restrict__ pts, const KnnBounds* __restrict__ b, unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  unsigned code = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float lo = ord2f(b->lo[a]), hi = ord2f(b->hi[a]);
+    const float ext = hi - lo;
+    const float t = ext > 0.f ? (pts[3 * i + a] - lo) / ext : 0.f;       // (a degenerate axis sorts as one cell)
+    unsigned q = (unsigned)(t * 1023.0f);
+    if (q > 1023u) q = 1023u;
+    code |= spread10(q) << a;
+  }
+  keys[i] = ((unsigned long long)code << 32) | (unsigned)i;             // unique keys: the sorted order is deterministic
+}
+
+struct KnnBox { float lo[3], hi[3]; };
+
+// sorted SoA copy of the points + one bounding box per run of KNN_BOX sorted points (one workgroup per box)
+__global__ void __launch_bounds__(KNN_BLOCK)
+knn_gather_boxes_kernel(int P, const float* __restrict__ pts, const unsigned long long* __restrict__ sorted, float* __restrict__ sx,
+                        float* __restrict__ sy, float* __restrict__ sz, unsigned* __restrict__ sidx, KnnBox* __restrict__ boxes) {
+  __shared__ float red[6][KNN_BLOCK / 64];
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int t = threadIdx.x; t < KNN_BOX; t += KNN_BLOCK) {
+    const int j = blockIdx.x * KNN_BOX + t;
+    if (j < P) {
+      const unsigned src = (unsigned)sorted[j];
+      const float x = pts[3 * (size_t)src], y = pts[3 * (size_t)src + 1], z = pts[3 * (size_t)src + 2];
+      sx[j] = x; sy[j] = y; sz[j] = z; sidx[j] = src;
+      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+    if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float l = red[threadIdx.x][0], h = red[3 + threadIdx.x][0];
+    for (int w = 1; w < KNN_BLOCK / 64; w++) { l = fminf(l, red[threadIdx.x][w]); h = fmaxf(h, red[3 + threadIdx.x][w]); }
+    boxes[blockIdx.x].lo[threadIdx.x] = l;
+    boxes[blockIdx.x].hi[threadIdx.x] = h;
+  }
+}
+
+// squared distance from p to the box (0 inside): simple_knn.cu:121-131
+__device__ __forceinline__ float box_dist2(const KnnBox& b, float x, float y, float z) {
+  const float dx = fmaxf(fmaxf(b.lo[0] - x, x - b.hi[0]), 0.f);
+  const float dy = fmaxf(fmaxf(b.lo[1] - y, y - b.hi[1]), 0.f);
+  const float dz = fmaxf(fmaxf(b.lo[2] - z, z - b.hi[2]), 0.f);
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__global__ void __launch_bounds__(KNN_BLOCK)
+knn_pruned_kernel(int P, int n_boxes, const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                  const unsigned* __restrict__ sidx, const KnnBox* __restrict__ boxes, float* __restrict__ out) {
+  __shared__ float tx[KNN_BOX], ty[KNN_BOX], tz[KNN_BOX];
+  __shared__ int s_need[2];
+  const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;          // position in Morton order
+  const bool live = i < P;
+  float rx = 0.f, ry = 0.f, rz = 0.f;
+  if (live) { rx = sx[i]; ry = sy[i]; rz = sz[i]; }
+  // the reference's first bound: third-best among the +-3 neighbours in sorted order (simple_knn.cu:158-166)
+  float reject = FLT_MAX;
+  if (live) {
+    float a0 = FLT_MAX, a1 = FLT_MAX, a2 = FLT_MAX;
+    for (int j = max(0, i - 3); j <= min(P - 1, i + 3); j++) {
+      if (j == i) continue;
+      const float dx = sx[j] - rx, dy = sy[j] - ry, dz = sz[j] - rz;
+      best3(dx * dx + dy * dy + dz * dz, a0, a1, a2);
+    }
+    reject = a2;
+  }
+  float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+  for (int b = 0; b < n_boxes; b++) {
+    const KnnBox box = boxes[b];                               // uniform address: scalar loads
+    const float d = box_dist2(box, rx, ry, rz);
+    const bool want = live && !(d > reject || d > b2);         // the reference's test (:171-173), per lane
+    // two alternating flags: flag b & 1 was last READ in iteration b - 2, and iteration b - 1's two barriers lie in between;
+    // the same two barriers separate a wave's scan of the staged box of an earlier iteration from the next staging
+    if (threadIdx.x == 0) s_need[b & 1] = 0;
+    __syncthreads();
+    if (__any(want) && (threadIdx.x & 63) == 0) s_need[b & 1] = 1;     // benign race: every writer stores 1
+    __syncthreads();
+    if (!s_need[b & 1]) continue;                              // uniform over the workgroup
+    const int base = b * KNN_BOX, cnt = min(KNN_BOX, P - base);
+    for (int t = threadIdx.x; t < cnt; t += KNN_BLOCK) { tx[t] = sx[base + t]; ty[t] = sy[base + t]; tz[t] = sz[base + t]; }
+    __syncthreads();
+    if (__any(want)) {                                          // waves whose lanes all reject the box skip the scan
+      for (int t = 0; t < cnt; t++) {
+        const float dx = tx[t] - rx, dy = ty[t] - ry, dz = tz[t] - rz;
+        float dd = dx * dx + dy * dy + dz * dz;
+        if (!want || base + t == i) dd = FLT_MAX;               // lanes that rejected the box keep their state; self excluded
+        best3(dd, b0, b1, b2);
+      }
+    }
+  }
+  if (live) out[sidx[i]] = (b0 + b1 + b2) / 3.0f;
+}
+
+extern "C" { int gip_knn_prune_from = 32768; }               // clouds above this size take the box-pruned path (mode 0)
+
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct KnnLayout { size_t keys, sorted, sx, sy, sz, sidx, boxes, bounds, temp, total, temp_bytes; };
+
+static KnnLayout knn_layout(int32_t P) {
+  KnnLayout L;
+  const size_t n = (size_t)(P > 0 ? P : 1), nb = (n + KNN_BOX - 1) / KNN_BOX;
+  size_t temp = 0;
+  // rocPRIM's own requirement when a device is there to ask; a generous bound otherwise (the real call checks again)
+  if (rocprim::radix_sort_keys((void*)nullptr, temp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0u, 62u, (hipStream_t)0) !=
+      hipSuccess || temp == 0)
+    temp = 16 * n + (4u << 20);
+  (void)hipGetLastError();
+  size_t o = 0;
+  L.keys = o; o += align256(8 * n);
+  L.sorted = o; o += align256(8 * n);
+  L.sx = o; o += align256(4 * n);
+  L.sy = o; o += align256(4 * n);
+  L.sz = o; o += align256(4 * n);
+  L.sidx = o; o += align256(4 * n);
+  L.boxes = o; o += align256(sizeof(KnnBox) * nb);
+  L.bounds = o; o += 256;
+  L.temp = o; L.temp_bytes = temp; o += align256(temp);
+  L.total = o;
+  return L;
+}
+
+extern "C" size_t gip_knn_workspace_bytes(int32_t P) { return P > gip_knn_prune_from || P < 0 ? knn_layout(P).total : 256; }
+extern "C" size_t gip_knn_workspace_bytes_mode(int32_t P, int32_t mode) {
+  return mode == 2 || (mode == 0 && P > gip_knn_prune_from) ? knn_layout(P).total : 256;
+}
+
+extern "C" int gip_knn_mean_dist2_mode(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,
+                                       int32_t mode, void* stream) {
+  if (P < 0 || mode < 0 || mode > 2 || (P > 0 && (!points || !out))) return 1;
+  if (P == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const bool pruned = mode == 2 || (mode == 0 && P > gip_knn_prune_from);
+  if (!pruned) {
+    hipLaunchKernelGGL(gip_knn_kernel, dim3((P + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), 0, s, P, points, out);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
+  const KnnLayout L = knn_layout(P);
+  if (!workspace || workspace_bytes < L.total) return 2;
+  char* ws = (char*)workspace;
+  unsigned long long* keys = (unsigned long long*)(ws + L.keys);
+  unsigned long long* sorted = (unsigned long long*)(ws + L.sorted);
+  float *sx = (float*)(ws + L.sx), *sy = (float*)(ws + L.sy), *sz = (float*)(ws + L.sz);
+  unsigned* sidx = (unsigned*)(ws + L.sidx);
+  KnnBox* boxes = (KnnBox*)(ws + L.boxes);
+  KnnBounds* bounds = (KnnBounds*)(ws + L.bounds);
+  const int nb = (P + KNN_BOX - 1) / KNN_BOX, blocks = (P + KNN_BLOCK - 1) / KNN_BLOCK;
+  hipLaunchKernelGGL(knn_bounds_init_kernel, dim3(1), dim3(64), 0, s, bounds);
+  hipLaunchKernelGGL(knn_bounds_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(KNN_BLOCK), 0, s, P, points, bounds);
+  hipLaunchKernelGGL(knn_keys_kernel, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, points, (const KnnBounds*)bounds, keys);
+  size_t temp = L.temp_bytes;
+  if (rocprim::radix_sort_keys((void*)(ws + L.temp), temp, keys, sorted, (size_t)P, 0u, 62u, s) != hipSuccess) return 3;
+  hipLaunchKernelGGL(knn_gather_boxes_kernel, dim3(nb), dim3(KNN_BLOCK), 0, s, P, points, (const unsigned long long*)sorted, sx, sy, sz,
+                     sidx, boxes);
+  hipLaunchKernelGGL(knn_pruned_kernel, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, nb, (const float*)sx, (const float*)sy,
+                     (const float*)sz, (const unsigned*)sidx, (const KnnBox*)boxes, out);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
 
 extern "C" int gip_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,
                                   void* stream) {
-  if (P < 0 || (P > 0 && (!points || !out))) return 1;
-  (void)workspace; (void)workspace_bytes;
-  if (P == 0) return 0;
-  hipLaunchKernelGGL(gip_knn_kernel, dim3((P + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), 0, (hipStream_t)stream, P,
-                     points, out);
-  return hipGetLastError() == hipSuccess ? 0 : 3;
+  return gip_knn_mean_dist2_mode(P, points, out, workspace, workspace_bytes, 0, stream);
 }

@@ -104,7 +104,7 @@ _STATS_ATTR = "_gip_chan_stats"
 _weights_epoch = 0
 _ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_GN_STATS", "GIP_SPLITK_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
               "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
-              "GIP_CONV_C3", "GIP_LN_FOLD", "GIP_ATTN_V2", "GIP_OWN_GEMM")
+              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_MIN_CONV_TILES")
 
 
 def bump_weights_epoch():
@@ -474,7 +474,7 @@ def conv1x1(x, w, bias=None):
     with the bias in its epilogue (the library path for plain GEMMs) instead of MIOpen's conv + fill + bias kernels."""
     if fusable(x) and w.is_contiguous(memory_format=torch.channels_last):
         N, C, H, W = x.shape
-        y = F.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w.reshape(w.shape[0], C), bias)
+        y = linear_auto(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w.reshape(w.shape[0], C), bias)
         return y.view(N, H, W, w.shape[0]).permute(0, 3, 1, 2)
     return F.conv2d(x, w, bias)
 
@@ -543,6 +543,32 @@ def linear_supported(x, w):
             w.is_contiguous() and x.shape[-1] % 64 == 0 and x.shape[-1] >= 64 and
             not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and
             x.numel() * 2 < (1 << 31) and (x.numel() // x.shape[-1]) * w.shape[0] * 2 < (1 << 31))
+
+
+def linear_prefers_own(M, K, N):
+    """Which dense GEMM shapes run on this repo's MFMA linear (conv3x3_kernel<TAPS = 1>) and which stay on hipBLASLt — by
+    measurement, shape by shape (profiles/r04_gemm_own_vs_hipblaslt.txt = tools/exp_gemm_table.py: every GEMM of the denoise at
+    batch 12 / 6 / 3, same process, alternating).  The own kernel (128-row tiles, K steps of 64, bias / residual in its
+    epilogue, no split-K) wins the short-K, narrow-N layers — proj_in, to_q, q|k|v at 64^2, the out-projections, the 1x1
+    shortcuts and zero convolutions: 0.48-0.86 of the library's time — and loses the weight-heavy ones (wide N at few rows:
+    ff_in below 64^2, q|k|v at 16^2, K >= 2560 at <= 6144 rows: 1.1-2.2x), where the library's 256 x 256 tiles and split-K win.
+    GIP_OWN_GEMM=0 sends everything that has no fused epilogue to the library, =2 everything supported to the own kernel."""
+    mode = os.environ.get("GIP_OWN_GEMM", "1")
+    if mode == "0":
+        return False
+    if mode == "2":
+        return True
+    return M >= 49152 or (K <= 1280 and N <= 1280) or (K <= 2560 and N <= 640 and M >= 12288)
+
+
+def linear_auto(x, w, bias=None, residual=None):
+    """F.linear(x, w, bias) (+ residual) on whichever of the two GEMM paths is faster for the shape (linear_prefers_own)."""
+    M = x.numel() // x.shape[-1]
+    if linear_supported(x, w) and w.shape[0] % 4 == 0 and (residual is None or residual.is_contiguous()) and \
+            linear_prefers_own(M, x.shape[-1], w.shape[0]):
+        return linear(x, w, bias, residual)
+    y = F.linear(x, w, bias)
+    return y if residual is None else y + residual
 
 
 def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None):

@@ -29,7 +29,8 @@ from . import fused
 from .fused import GroupNormAct, add_bias_residual, conv1x1, conv3x3, fusable, geglu
 
 TEXT_TOKENS = 77
-_GEGLU_FUSE_MIN_ROWS = 32768     # measured: the fused GEGLU projection wins at the 64x64 level, hipBLASLt + geglu below
+# measured: the fused GEGLU projection wins at the 64x64 level, hipBLASLt + geglu below (GIP_GEGLU_MIN_ROWS: A/B knob)
+_GEGLU_FUSE_MIN_ROWS = int(__import__("os").environ.get("GIP_GEGLU_MIN_ROWS", "32768"))
 IP_TOKENS = 4
 
 
@@ -195,8 +196,8 @@ class Attention(nn.Module):
         if self.lora_rank:
             out = self.to_out(h) + self.lora_out(h)
             return out if residual is None else residual + out
-        if residual is not None and fused.linear_supported(h, self.to_out.weight) and residual.is_contiguous():
-            return fused.linear(h, self.to_out.weight, self.to_out.bias, residual)
+        if fused.linear_supported(h, self.to_out.weight) and (residual is None or residual.is_contiguous()):
+            return fused.linear_auto(h, self.to_out.weight, self.to_out.bias, residual)
         out = self.to_out(h)
         return out if residual is None else residual + out
 
@@ -212,7 +213,7 @@ class Attention(nn.Module):
         staged, self.staged_kv = self.staged_kv, None
         if staged is not None and staged[0].shape[0] == x.shape[0] and not self.lora_rank:
             # key / value projections of the prompt tokens, made for all layers at once by _Encoder.stage_context
-            q = self.to_q(x)
+            q = fused.linear_auto(x, self.to_q.weight, self.to_q.bias)
             k, v, k_ip, v_ip = staged
             if fused.attention_supported(q, k, self.heads):
                 if k_ip is None:
@@ -222,7 +223,7 @@ class Attention(nn.Module):
             # self-attention with frozen, folded weights: ONE [3C, C] projection (the tokens are read once, not three times);
             # q, k, v are column ranges of its output and the attention kernel reads them in place through row strides
             C = x.shape[-1]
-            qkv = F.linear(x, fused.qkv_weight(self.to_q.weight, self.to_k.weight, self.to_v.weight))
+            qkv = fused.linear_auto(x, fused.qkv_weight(self.to_q.weight, self.to_k.weight, self.to_v.weight))
             q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
             if fused.attention_supported(q, k, self.heads):
                 return self._out(fused.attention(q, k, v, self.heads), residual)
@@ -271,7 +272,7 @@ class TransformerBlock(nn.Module):
         else:
             h = geglu(self.ff_in(h))
         if fused.linear_supported(h, self.ff_out.weight) and x.is_contiguous():
-            return fused.linear(h, self.ff_out.weight, self.ff_out.bias, x)
+            return fused.linear_auto(h, self.ff_out.weight, self.ff_out.bias, x)
         return x + self.ff_out(h)
 
 
@@ -289,7 +290,7 @@ class SpatialTransformer(nn.Module):
         copy and the result is tiled before attn2 — the same values, 1/replicas of the work."""
         B, C, H, W = x.shape
         if fusable(x):      # NHWC: the 1x1 projections are GEMMs on the token view, no layout change anywhere
-            t = F.linear(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
+            t = fused.linear_auto(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
             res = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
             if replicas > 1:
                 res = res.repeat(replicas, 1, 1)

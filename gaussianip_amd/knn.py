@@ -9,7 +9,12 @@ import torch
 from . import _lib
 
 
-def distCUDA2(points: torch.Tensor) -> torch.Tensor:
+MODES = {"auto": 0, "all_pairs": 1, "box_pruned": 2}
+
+
+def distCUDA2(points: torch.Tensor, mode: str = "auto") -> torch.Tensor:
+    """`mode`: "auto" (all pairs up to 32 768 points, Morton-sorted box pruning above — simple_knn.cu:45-185), "all_pairs" or
+    "box_pruned"; every mode returns the identical float per point (exact 3-NN, the same arithmetic)."""
     if not points.is_cuda:
         raise ValueError("distCUDA2: points must be a GPU tensor (no CPU path in the product)")
     pts = points.detach().float().contiguous()
@@ -18,11 +23,13 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     if P == 0:
         return out
     lib = _lib.knn_lib()
-    ws_bytes = lib.gip_knn_workspace_bytes(P)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
-    rc = lib.gip_knn_mean_dist2(P, ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                ctypes.c_void_p(ws.data_ptr()), ws_bytes,
-                                ctypes.c_void_p(torch.cuda.current_stream(pts.device).cuda_stream))
+    m = MODES[mode]
+    with torch.cuda.device(pts.device):
+        ws_bytes = lib.gip_knn_workspace_bytes_mode(P, m)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
+        rc = lib.gip_knn_mean_dist2_mode(P, ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_void_p(ws.data_ptr()), ws_bytes, m,
+                                         ctypes.c_void_p(torch.cuda.current_stream(pts.device).cuda_stream))
     if rc != 0:
-        raise RuntimeError("gip_knn_mean_dist2 failed with status %d" % rc)
+        raise RuntimeError("gip_knn_mean_dist2_mode failed with status %d" % rc)
     return out

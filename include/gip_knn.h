@@ -20,6 +20,13 @@ extern "C" {
 size_t gip_knn_workspace_bytes(int32_t P);
 int gip_knn_mean_dist2(int32_t P, const float* points /* [P,3] device */, float* out /* [P] device */,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same result by a chosen algorithm: mode 0 = by size (what gip_knn_mean_dist2 does: all pairs up to gip_knn_prune_from
+ * points, box-pruned above), 1 = exact tiled all-pairs, 2 = Morton sort + 1024-point boxes that prune the exact search
+ * (simple_knn.cu:45-185: coord2Morton, boxMinMax, distBoxPoint, boxMeanDist).  Both give the identical float per point.
+ * gip_knn_workspace_bytes_mode: the workspace that mode needs for P points. */
+size_t gip_knn_workspace_bytes_mode(int32_t P, int32_t mode);
+int gip_knn_mean_dist2_mode(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, int32_t mode,
+                            void* stream);
 #ifdef __cplusplus
 }
 #endif

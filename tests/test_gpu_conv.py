@@ -488,7 +488,7 @@ def test_halo_resident_tile_of_the_128_channel_convolution(shape, mode):
     r = torch.randn(N, co, H, W, device="cuda", generator=g).half().contiguous(**cl) if full else None
     holder = [] if full else None
     out = fused._conv_call(x, w, co, b, r, holder)
-    knob = ctypes.c_int.in_dll(_lib.nn_lib(), "gip_dbg_conv_epilogue")
+    knob = ctypes.c_int.in_dll(_lib.nn_lib()._lib, "gip_dbg_conv_epilogue")
     knob.value = 0                                   # per-lane epilogue: the halo path needs the LDS one, so this is the streaming kernel
     try:
         base = fused._conv_call(x, w, co, b, r, None)

@@ -31,6 +31,46 @@ def test_knn_matches_oracle_bit_exact(oracle):
     assert float(distCUDA2(torch.from_numpy(dup).cuda()).abs().max()) == 0.0
 
 
+def test_box_pruned_knn_equals_all_pairs_bit_for_bit(oracle):
+    """simple_knn's scheme (Morton sort, 1024-point boxes that prune the exact search: simple_knn.cu:45-185) against the tiled
+    all-pairs kernel and the CPU oracle: the identical float per point — small ragged clouds, coincident points, a degenerate
+    (planar) cloud, the shipped 100k human surface, and 1M points (the size of BASELINE configs[4]) against sampled brute force."""
+    import time
+    from gaussianip_amd.knn import distCUDA2
+    import scenes
+    rng = np.random.default_rng(5)
+    big = rng.normal(size=(20011, 3)).astype(np.float32)
+    oracle.set_threads(8)
+    ref = oracle.knn_mean_dist2(big)
+    oracle.set_threads(1)
+    for mode in ("all_pairs", "box_pruned"):
+        assert np.array_equal(distCUDA2(torch.from_numpy(big).cuda(), mode).cpu().numpy(), ref), mode
+    for pts in (np.zeros((5, 3), np.float32), rng.normal(size=(3, 3)).astype(np.float32), rng.normal(size=(1025, 3)).astype(np.float32),
+                np.concatenate([rng.normal(size=(3000, 2)), np.zeros((3000, 1))], axis=1).astype(np.float32),       # planar: one Morton axis degenerate
+                np.repeat(rng.normal(size=(700, 3)), 3, axis=0).astype(np.float32)):                                 # every point three times
+        t = torch.from_numpy(pts).cuda()
+        assert torch.equal(distCUDA2(t, "box_pruned"), distCUDA2(t, "all_pairs")), pts.shape
+    human = torch.from_numpy(scenes.human_points(100000, np.random.default_rng(42)).astype(np.float32)).cuda()
+    a = distCUDA2(human, "all_pairs")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = distCUDA2(human, "box_pruned")
+    torch.cuda.synchronize()
+    t_pruned = time.perf_counter() - t0
+    assert torch.equal(a, b) and torch.equal(distCUDA2(human), b)             # "auto" takes the pruned path above 32 768 points
+    million = torch.from_numpy(scenes.human_points(1000000, np.random.default_rng(43)).astype(np.float32)).cuda()
+    t0 = time.perf_counter()
+    c = distCUDA2(million)
+    torch.cuda.synchronize()
+    t_million = time.perf_counter() - t0
+    sel = torch.from_numpy(np.random.default_rng(1).choice(1000000, 2048, replace=False)).cuda()
+    d2 = torch.cdist(million[sel].double(), million.double()) ** 2
+    d2[torch.arange(2048, device="cuda"), sel] = float("inf")
+    brute = d2.topk(3, largest=False).values.float().mean(1)
+    assert float(((c[sel] - brute).abs() / brute.clamp_min(1e-12)).max()) < 1e-4
+    print("box-pruned k-NN: 100k points %.1f ms, 1M points %.1f ms" % (t_pruned * 1e3, t_million * 1e3))
+
+
 def _model(P=5000, seed=7, sh_degree=0):
     from gaussianip_amd.arguments import OptimizationParams
     from gaussianip_amd.scene import GaussianModel
