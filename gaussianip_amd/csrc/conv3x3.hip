@@ -43,6 +43,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7; the same function as csrc/groupnorm.hip's GEGLU kernel uses): the GEGLU
+// epilogue evaluates 32 gelu per thread and tile, and libm's erff (~40 vector instructions each) made it longer than the K loop
+// of the K = 320 projection it ends
+__device__ __forceinline__ float cv_erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+  return copysignf(fmaf(-p * t, e, 1.f), x);
+}
+
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset, void* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
@@ -86,7 +100,7 @@ __device__ __forceinline__ void gnb_accumulate(const GnBwdArgs& a, const GnBwdLa
     float g = (float)dy[j];
     if (a.silu) {
       const float v = L.ga[j] * xh + L.be[j];
-      const float sg = 1.f / (1.f + __expf(-v));
+      const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v));      // v_rcp_f32, not the IEEE division sequence
       g *= sg * (1.f + v * (1.f - sg));
     }
     const float dxh = g * L.ga[j];
@@ -476,7 +490,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         if (bias) { add4(v, bias + co); add4(g, bias + Cout + co); }
         f16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = (_Float16)(v[j] * (0.5f * g[j] * (1.f + erff(g[j] * 0.70710678118654752f))));
+        for (int j = 0; j < 4; j++) o[j] = (_Float16)(v[j] * (0.5f * g[j] * (1.f + cv_erf_fast(g[j] * 0.70710678118654752f))));
         *(f16x4*)(out + out_row(m) * Cout + co) = o;
       }
     } else {

@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ _Float16 silu_h(_Float16 h) {      // torch's half SiLU: fp32 on the half-rounded value, one more rounding
   const float v = (float)h;
-  return (_Float16)(v / (1.f + __expf(-v)));
+  return (_Float16)(v * __builtin_amdgcn_rcpf(1.f + __expf(-v)));      // v_rcp_f32 instead of the IEEE division sequence
 }
 
 template <int CO, bool ACT>

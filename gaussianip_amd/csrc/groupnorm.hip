@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gip_nn.h"
 
@@ -25,8 +26,13 @@ __device__ __forceinline__ half8 pack8(const float* f) {
   h.c = __floats2half2_rn(f[4], f[5]); h.d = __floats2half2_rn(f[6], f[7]);
   return h;
 }
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
-__device__ __forceinline__ float dsilu_f(float v) { const float s = 1.f / (1.f + __expf(-v)); return s * (1.f + v * (1.f - s)); }
+// sigmoid through v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE `/` compiles to v_div_scale x2 + v_rcp + four fma + v_div_fmas +
+// v_div_fixup — the apply kernel carried 264 of those instructions for its 64 divisions per trip, half of its vector work
+// (round 4: the forward apply pass of a 268 MB tensor took 0.129 ms against 0.097 ms for a plain copy); the result is rounded
+// to half anyway
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return v * sigmoid_f(v); }
+__device__ __forceinline__ float dsilu_f(float v) { const float s = sigmoid_f(v); return s * (1.f + v * (1.f - s)); }
 
 // geometry shared by all kernels: lanes are laid out as (chunk, row-lane); tpr = C / 8 chunks per row
 struct GnGeom { int tpr, chunks_per_thread, rows_per_iter; };
@@ -133,7 +139,42 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
   const float inv_m = 1.f / ((float)HW * (float)cg);
   // per-group totals from the per-split partials: all 256 threads take part (group = t % G, split slice = t / G),
   // fixed summation order.  splits == 0 (forward): mean / rstd were made by gn_finalize_stats_kernel, nothing to reduce
-  if (MODE == 0 && splits == 0) {
+  if (MODE == 0 && splits < 0) {
+    // statistics straight from the producer's per-(128-row block, channel) sums (`partial` = chan_stats [N * bps][C][2], bps =
+    // -splits blocks per sample): the small tensors of the denoiser (bps * C <= 16384 pairs = 128 KB per sample, L2-resident,
+    // just written) do not get a gn_finalize_stats launch of their own — every workgroup folds its sample's sums itself, in a
+    // fixed order (thread = (group, slice); a slice walks its share of the group's (block, channel) pairs; slices summed in order)
+    const int bps = -splits;
+    const float rows = (float)HW / (float)bps;
+    float* s_part = s_g + 2 * G;
+    const int slices = GN_BLOCK / G > 0 ? GN_BLOCK / G : 1;
+    const int g = threadIdx.x % G, sl = threadIdx.x / G;
+    if (sl < slices) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int e = sl; e < bps * cg; e += slices) {
+        const int b = e / cg, c = g * cg + (e - b * cg);
+        const float* p = partial + (((size_t)n * bps + b) * C + c) * 2;
+        float S = p[0], Q = p[1];
+        if (addend) {               // sum(x + a) = S + R a, sum((x + a)^2) = Q + 2 a S + R a^2 over the block's R rows
+          const float a = __half2float(addend[(long long)n * addend_stride + c]);
+          Q += 2.f * a * S + rows * a * a;
+          S += rows * a;
+        }
+        s0 += S; s1 += Q;
+      }
+      s_part[(sl * G + g) * 2] = s0; s_part[(sl * G + g) * 2 + 1] = s1;
+    }
+    __syncthreads();
+    for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int k = 0; k < slices; k++) { s0 += s_part[(k * G + gg) * 2]; s1 += s_part[(k * G + gg) * 2 + 1]; }
+      const float mu = s0 * inv_m;
+      const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
+      const float rs = rsqrtf(var + eps);
+      s_g[2 * gg] = mu; s_g[2 * gg + 1] = rs;
+      if (split == 0) { mean[n * G + gg] = mu; rstd[n * G + gg] = rs; }
+    }
+  } else if (MODE == 0 && splits == 0) {
     for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) { s_g[2 * gg] = mean[n * G + gg]; s_g[2 * gg + 1] = rstd[n * G + gg]; }
   } else if (MODE == 1 && splits == 0) {      // S1 / m, S2 / m made by gn_finalize_bwd_kernel from the data-gradient kernel's sums
     for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) { s_g[2 * gg] = partial[((long long)n * G + gg) * 2]; s_g[2 * gg + 1] = partial[((long long)n * G + gg) * 2 + 1]; }
@@ -358,9 +399,20 @@ extern "C" int gip_gn_silu_forward_stats(const void* x, const void* gamma, const
   if (rc) return rc;
   if (!gamma || !beta || !mean || !rstd || !chan_stats || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
   hipStream_t s = (hipStream_t)stream;
+  const int splits = pick_splits(N, HW, C);
+  // measured and NOT adopted (round 4, same-box: AHDS step 34.4 ms without, 34.9-35.0 with): every one of the ~1000 apply
+  // workgroups re-reading its sample's sums (up to 128 KB) costs more than the 5 us finalize launch it saves; opt-in
+  static const int fold = [] { const char* v = getenv("GIP_GN_FOLD_FINALIZE"); return v && *v ? atoi(v) : 0; }();
+  if (fold && (long long)blocks_per_sample * C <= 16384 && HW % blocks_per_sample == 0 && G <= GN_BLOCK) {
+    // one launch: the apply kernel's prologue folds the producer's sums itself (see gn_apply_kernel, splits < 0)
+    hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
+                       (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
+                       chan_stats, (half8*)y, (long long)HW, C, G, -blocks_per_sample, splits, eps, apply_silu,
+                       (const __half*)addend, addend_stride, (const half8*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
   hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(G, N), dim3(GN_BLOCK), 0, s, chan_stats, blocks_per_sample, (long long)HW, C, G,
                      eps, (const __half*)addend, addend_stride, mean, rstd);
-  const int splits = pick_splits(N, HW, C);
   hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
                      (const float*)nullptr, (half8*)y, (long long)HW, C, G, 0, splits, eps, apply_silu,
@@ -444,7 +496,19 @@ add_bias_residual_kernel(const half8* __restrict__ a, const half8* __restrict__ 
   }
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the half rounding of the result): one v_rcp, one v_exp and
+// six fma instead of libm's erff (~40 vector instructions per value: the GEGLU kernels were bound by it, not by memory)
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+  return copysignf(fmaf(-p * t, e, 1.f), x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_fast(v * 0.70710678118654752f)); }
 
 __global__ void __launch_bounds__(256)
 geglu_kernel(const half8* __restrict__ in /* [M, 2D] */, half8* __restrict__ out /* [M, D] */, long long M, int d8) {

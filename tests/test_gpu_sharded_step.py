@@ -50,10 +50,11 @@ def test_config3_real_guidance_sharded_step_at_100k_1024(tmp_path):
     logs = [p.communicate(timeout=1500)[0].decode(errors="replace") for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
-    report = []
-    for path in outs:
-        r = json.load(open(path))
-        report.append(r)
+    report = [json.load(open(path)) for path in outs]
+    d = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(d):                      # written BEFORE the assertions: a failing run leaves its numbers behind
+        json.dump(report, open(os.path.join(d, "config3_sharded_guidance.json"), "w"), indent=1)
+    for r in report:
         print(json.dumps(r))
         assert r["views_ref"] == 4 and r["views_local"] == 2
         assert r["radii_equal"] and r["denom_equal"] and r["ranks_agree_after_adam"], r
@@ -74,9 +75,6 @@ def test_config3_real_guidance_sharded_step_at_100k_1024(tmp_path):
             if g_["ref_norm"] > 1e-6 * big:
                 assert g_["rel_l2"] < 0.15 and g_["cosine"] > 0.99, (name, g_)
         assert r["accum_vs_one_call"]["cosine"] > 0.99, r
-    d = os.path.join(os.path.dirname(HERE), "gpurun_out")
-    if os.path.isdir(d):
-        json.dump(report, open(os.path.join(d, "config3_sharded_guidance.json"), "w"), indent=1)
 
 
 def test_bench_py_gpus_2_launches_two_ranks_itself(tmp_path):
