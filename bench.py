@@ -233,7 +233,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
+    result_out = sys.stdout
     if world > 1:
+        # stdout carries the ONE result line and nothing else: communication libraries announce themselves on file descriptor 1
+        # ("[Gloo] Rank 0 is connected to 1 peer ranks"), so from here on descriptor 1 is stderr and the line goes to a duplicate
+        # of the original stdout
+        sys.stdout.flush()
+        result_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("GIP_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -601,7 +608,7 @@ def main():
         # BASELINE.json's metric names the AHDS training-step rate first: first-class beside the raster rate
         out["ahds_steps_per_s"] = ahds.get("value") if isinstance(ahds, dict) else None
         out["ahds_ms_per_step"] = ahds.get("ms_per_step") if isinstance(ahds, dict) else None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

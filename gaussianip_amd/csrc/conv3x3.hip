@@ -74,6 +74,16 @@ struct GnBwdArgs {
   const float* mean;        // [N, G]
   const float* rstd;
   int G, silu, addend_stride, HW;
+  // --- LayerNorm folded into a TAPS = 1 GEMM (gip_linear_ln_f16): out = LN(x) W^T + b computed as
+  //       out[m][n] = rstd_m (x_m . (W gamma)_n) - rstd_m mu_m s_n + t_n,   s_n = sum_k (W gamma)[n][k],  t_n = sum_k W[n][k] beta_k + b_n
+  //     with x read RAW (the LayerNorm kernel and its round trip through memory disappear); mu_m / rstd_m come from the per-row
+  //     partial sums [M][ln_parts][2] = (sum, sum of squares) that the kernel which PRODUCED x left in its epilogue (rows_out)
+  const float* ln_rows;     // NULL = no LayerNorm fold
+  const float* ln_s;        // [Nout] (GEGLU: [2 Nout]) float32
+  const float* ln_t;
+  float* rows_out;          // [M][n_tiles][2] per-row (sum, sum of squares) of this kernel's final output over its channel tile; NULL = none
+  int ln_parts;
+  float ln_inv_c, ln_eps;
 };
 
 struct GnBwdLane {          // one lane's eight channels
@@ -355,6 +365,28 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     __syncthreads();
   }
 
+  // ---- LayerNorm fold: (rstd, -rstd * mu) of the tile's 128 rows from the producer's per-row partial sums, kept in the last KB
+  //      of the (now free) stage buffers — behind everything the epilogues below stage there
+  const bool ln_fold = TAPS == 1 && gnb.ln_rows != nullptr;
+  float* lnbuf = (float*)(smem + HALO_BYTES + STAGES * STAGE - 1024);
+  if (ln_fold) {
+    if (tid < CV_BM) {
+      const unsigned m = row_m(tid);
+      float rs = 0.f, a = 0.f;
+      if (m < M) {
+        float S = 0.f, Q = 0.f;
+        const float* pr = gnb.ln_rows + (size_t)m * gnb.ln_parts * 2;
+        for (int pp = 0; pp < gnb.ln_parts; pp++) { S += pr[2 * pp]; Q += pr[2 * pp + 1]; }      // fixed order
+        const float mu = S * gnb.ln_inv_c;
+        const float var = fmaxf(Q * gnb.ln_inv_c - mu * mu, 0.f);
+        rs = rsqrtf(var + gnb.ln_eps);
+        a = -rs * mu;
+      }
+      lnbuf[2 * tid] = rs; lnbuf[2 * tid + 1] = a;
+    }
+    __syncthreads();
+  }
+
   // ---- epilogue: lane holds out[pixel = lane & 15][co = (lane >> 4) * 4 + 0..3] of each 16x16 tile ----
   const bool scatter = TAPS == 9 && ((tapsel >> 11) & 1);
   auto out_row = [&](unsigned m) -> size_t {      // row of `out` that output pixel m is written to
@@ -416,12 +448,20 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         const int cl = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
         f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (bias && co0 + cl < Cout) add4(b4, bias + co0 + cl);
+        f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f}, t4 = s4;
+        if (ln_fold && co0 + cl < Cout) { s4 = *(const f32x4*)(gnb.ln_s + co0 + cl); t4 = *(const f32x4*)(gnb.ln_t + co0 + cl); }
 #pragma unroll
         for (int mi = 0; mi < 4; mi++) {
           const int p = wm * 64 + mi * 16 + (lane & 15);
           const f32x4 v = acc[ni][mi];
           f16x4 o;
-          o[0] = (_Float16)(v[0] + b4[0]); o[1] = (_Float16)(v[1] + b4[1]); o[2] = (_Float16)(v[2] + b4[2]); o[3] = (_Float16)(v[3] + b4[3]);
+          if (ln_fold) {       // rstd (x . W') - rstd mu s + t  (uniform branch; the plain path below is unchanged bit for bit)
+            const float rs = lnbuf[2 * p], a = lnbuf[2 * p + 1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (_Float16)fmaf(rs, v[j], fmaf(a, s4[j], t4[j]));
+          } else {
+            o[0] = (_Float16)(v[0] + b4[0]); o[1] = (_Float16)(v[1] + b4[1]); o[2] = (_Float16)(v[2] + b4[2]); o[3] = (_Float16)(v[3] + b4[3]);
+          }
           *(f16x4*)(smem + p * ROWB + cl * 2) = o;
         }
       }
@@ -431,6 +471,18 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       float s8[8], q8[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) { s8[j] = 0.f; q8[j] = 0.f; }
+      // per-ROW sums of the final output over this tile's channels (rows_out: the LayerNorm that consumes this tensor is folded
+      // into its consumer GEMM): each thread leaves the sums of its 8 channels per row in LDS [row][chunk] (the region the
+      // per-channel statistics would use: the two are never requested together), 128 threads then add a row's chunks in order
+      float* rowpart = (float*)(smem + CV_BM * ROWB);
+      const bool rows_wanted = gnb.rows_out != nullptr && !chan_stats;
+      if (rows_wanted && tid < RPP * CH && !mine) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int row = r0 + k * RPP;
+          if (row < CV_BM) { rowpart[(row * CH + chunk) * 2] = 0.f; rowpart[(row * CH + chunk) * 2 + 1] = 0.f; }
+        }
+      }
       if (mine) {
         GnBwdLane gl;
         if (chan_stats && gnb.x) gnb_load(gnb, (int)(HALO ? h_n : m0 / (unsigned)gnb.HW), co, Cout, gl);
@@ -446,6 +498,12 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
             for (int j = 0; j < 8; j++) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
           }
           *(f16x8*)(out + out_row(m) * Cout + co) = v;
+          if (rows_wanted) {
+            float ps = 0.f, pq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float f = (float)v[j]; ps += f; pq = fmaf(f, f, pq); }
+            rowpart[(row * CH + chunk) * 2] = ps; rowpart[(row * CH + chunk) * 2 + 1] = pq;
+          }
           if (chan_stats) {
             if (gnb.x) {
               gnb_accumulate(gnb, gl, v, res_early ? rres[k] : *(const f16x8*)(gnb.x + (size_t)m * Cout + co), s8, q8);
@@ -453,6 +511,26 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #pragma unroll
               for (int j = 0; j < 8; j++) { const float f = (float)v[j]; s8[j] += f; q8[j] = fmaf(f, f, q8[j]); }
             }
+          }
+        }
+      }
+      if (rows_wanted) {                                     // kernel argument: uniform over the workgroup
+        if (mine) {                                          // rows past M in a ragged last tile: zeros (the loop above broke before them)
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            const int row = r0 + k * RPP;
+            if (row < CV_BM && row_m(row) >= M) { rowpart[(row * CH + chunk) * 2] = 0.f; rowpart[(row * CH + chunk) * 2 + 1] = 0.f; }
+          }
+        }
+        __syncthreads();
+        if (tid < CV_BM) {
+          const unsigned m = row_m(tid);
+          if (m < M) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; c++) { S += rowpart[(tid * CH + c) * 2]; Q += rowpart[(tid * CH + c) * 2 + 1]; }      // fixed order
+            float* o = gnb.rows_out + ((size_t)m * n_tiles + nt) * 2;
+            o[0] = S; o[1] = Q;
           }
         }
       }
@@ -487,7 +565,14 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         const int co = co0 + wn * (BN / 4) + ni * 16 + (lane >> 4) * 4;
         if (co >= Cout) continue;
         f32x4 v = acc[ni][mi], g = acc[ni + NI / 2][mi];
-        if (bias) { add4(v, bias + co); add4(g, bias + Cout + co); }
+        if (ln_fold) {
+          const int p = wm * 64 + mi * 16 + (lane & 15);
+          const float rs = lnbuf[2 * p], a = lnbuf[2 * p + 1];
+          const f32x4 sv = *(const f32x4*)(gnb.ln_s + co), tv = *(const f32x4*)(gnb.ln_t + co);
+          const f32x4 sg = *(const f32x4*)(gnb.ln_s + Cout + co), tg = *(const f32x4*)(gnb.ln_t + Cout + co);
+#pragma unroll
+          for (int j = 0; j < 4; j++) { v[j] = fmaf(rs, v[j], fmaf(a, sv[j], tv[j])); g[j] = fmaf(rs, g[j], fmaf(a, sg[j], tg[j])); }
+        } else if (bias) { add4(v, bias + co); add4(g, bias + Cout + co); }
         f16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; j++) o[j] = (_Float16)(v[j] * (0.5f * g[j] * (1.f + cv_erf_fast(g[j] * 0.70710678118654752f))));
@@ -949,7 +1034,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   if constexpr (!GEGLU) {
     if (!(Cout & 7)) {
       const int bw = big_tile_width(M, Cout);
-      if (bw == 256 && !(gnb.x && gnb.HW % CVB_BM) && tapsel == 0x1ff)
+      if (bw == 256 && !(gnb.x && gnb.HW % CVB_BM) && tapsel == 0x1ff && !gnb.ln_rows && !gnb.rows_out)
         return launch_big<256, TAPS>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, Hin, Win, geom, chan_stats, gnb);
     }
   }
@@ -1016,6 +1101,10 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   if (chan_stats && !stats_in_reduce) {            // statistics come out of the LDS epilogue of whole-K tiles (128-row blocks)
     if (GEGLU || (Cout & 7) || stats_rows != 128) return 1;
     ksplit = 1;
+    lds_epi = 1;
+  }
+  if (gnb.ln_rows || gnb.rows_out) {               // LayerNorm fold / row statistics: whole-K tiles with the LDS epilogue
+    if (TAPS != 1 || ksplit != 1 || (!GEGLU && (Cout & 7)) || (gnb.rows_out && (GEGLU || chan_stats))) return 1;
     lds_epi = 1;
   }
   static const int env_res = env_int("GIP_CONV_RES_EARLY", 1);
@@ -1094,7 +1183,7 @@ extern "C" int gip_conv3x3_gnbwd_nhwc_f16(const void* dy_in, const void* w, void
       Cin % CV_BK || Cout < 8 || (Cout & 7) || G < 1 || Cout % G || ((long long)H * W) % CV_BM)
     return 1;
   if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;
-  GnBwdArgs g;
+  GnBwdArgs g = {};
   g.x = (const _Float16*)gn_x; g.gamma = (const _Float16*)gamma; g.beta = (const _Float16*)beta; g.addend = (const _Float16*)addend;
   g.mean = mean; g.rstd = rstd; g.G = G; g.silu = apply_silu; g.addend_stride = addend_stride; g.HW = H * W;
   hipStream_t s = (hipStream_t)stream;
@@ -1113,6 +1202,47 @@ extern "C" int gip_linear_stats_f16(const void* x, const void* w, const void* bi
   const int geom = 1 | (1 << 8) | (1 << 16);
   return wide ? launch<160, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, chan_stats)
               : launch<128, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, chan_stats);
+}
+
+// Number of per-row partial sums a [M, Nout] output of the linear kernel carries in rows_out (= its channel tiles).
+extern "C" int32_t gip_linear_row_parts(int32_t Nout) {
+  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
+  return (Nout + (wide ? 160 : 128) - 1) / (wide ? 160 : 128);
+}
+
+// gip_linear_f16 (no GEGLU) that also leaves, per output row, the (sum, sum of squares) of the final half-rounded output over
+// each channel tile: rows_out [M][gip_linear_row_parts(Nout)][2] float32 — what the LayerNorm of that row needs.
+extern "C" int gip_linear_rows_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
+                                   int32_t K, int32_t Nout, float* rows_out, void* stream) {
+  if (!x || !w || !out || !rows_out || M < 1 || M >= (1ll << 31) || K < CV_BK || K % CV_BK || Nout < 8 || (Nout & 7)) return 1;
+  if (!fits32(M, K, Nout, Nout, 1)) return 1;
+  GnBwdArgs g = {};
+  g.rows_out = rows_out;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  return wide ? launch<160, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g)
+              : launch<128, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
+}
+
+// LayerNorm(x) W^T + b (optionally GEGLU of it) WITHOUT a LayerNorm pass: x is read raw, `wg` = W * gamma (half), s_n = sum_k wg[n][k],
+// t_n = sum_k W[n][k] beta_k + b_n (float32; [Nout], GEGLU: [2 Nout] = [value | gate] like the weight), and the per-row statistics
+// come from ln_rows [M][ln_parts][2], the partial sums its producer left (gip_linear_rows_f16): see GnBwdArgs.
+extern "C" int gip_linear_ln_f16(const void* x, const void* wg, const float* s_vec, const float* t_vec, void* out, int64_t M, int32_t K,
+                                 int32_t Nout, int32_t geglu, const float* ln_rows, int32_t ln_parts, float eps, void* stream) {
+  if (!x || !wg || !s_vec || !t_vec || !out || !ln_rows || ln_parts < 1 || M < 1 || M >= (1ll << 31) || K < CV_BK || K % CV_BK || Nout < 8 ||
+      (Nout & 7))
+    return 1;
+  if (geglu && (Nout % 64)) return 1;
+  if (!fits32(M, K, geglu ? 2 * Nout : Nout, geglu ? 2 * Nout : Nout, 1)) return 1;
+  GnBwdArgs g = {};
+  g.ln_rows = ln_rows; g.ln_s = s_vec; g.ln_t = t_vec; g.ln_parts = ln_parts; g.ln_inv_c = 1.0f / (float)K; g.ln_eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  if (geglu) return launch<128, 2, 1, true>(x, wg, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
+  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
+  return wide ? launch<160, 2, 1, false>(x, wg, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g)
+              : launch<128, 2, 1, false>(x, wg, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
 }
 
 extern "C" int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin,

@@ -104,7 +104,7 @@ _STATS_ATTR = "_gip_chan_stats"
 _weights_epoch = 0
 _ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_GN_STATS", "GIP_SPLITK_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
               "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
-              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_MIN_CONV_TILES")
+              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD")
 
 
 def bump_weights_epoch():
@@ -545,6 +545,72 @@ def linear_supported(x, w):
             x.numel() * 2 < (1 << 31) and (x.numel() // x.shape[-1]) * w.shape[0] * 2 < (1 << 31))
 
 
+_ROWS_ATTR = "_gip_row_stats"
+
+
+def row_stats(x):
+    """[M, parts, 2] float32 per-row (sum, sum of squares) partials that the MFMA linear which produced `x` left in its epilogue
+    (attached to the tensor OBJECT: any view / copy drops it), or None."""
+    rs = getattr(x, _ROWS_ATTR, None)
+    if rs is None or rs.dim() != 3 or rs.shape[0] != x.numel() // x.shape[-1] or os.environ.get("GIP_LN_FOLD", "1") == "0":
+        return None
+    return rs
+
+
+def _ln_fold_weights(norm, w, bias):
+    """(W * gamma as half, s = row sums of that matrix, t = W beta + b) of LayerNorm `norm` folded into the projection (w, bias):
+    LN(x) W^T + b = rstd (x (W gamma)^T) - rstd mu s + t.  Frozen weights: cached with the derived convolution weights."""
+    tag = "lnf:%d:%d:%d:%d:%d" % (norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version,
+                                 0 if bias is None else bias.data_ptr())
+
+    def make(wt):
+        wf = wt.detach().float()
+        wg = (wf * norm.weight.detach().float()[None, :]).to(wt.dtype).contiguous()
+        s_vec = wg.float().sum(dim=1).contiguous()
+        t_vec = wf @ norm.bias.detach().float()
+        if bias is not None:
+            t_vec = t_vec + bias.detach().float()
+        return wg, s_vec, t_vec.contiguous()
+    return _wt_cache.get(tag, w, make)
+
+
+def linear_ln(x, norm, w, bias=None, geglu_act=False):
+    """F.linear(norm(x), w, bias) — or GEGLU of it — with the LayerNorm FOLDED into the GEMM (gip_linear_ln_f16): x is read raw,
+    its row statistics come from the partial sums its producer attached (row_stats).  Returns None when the fold does not apply
+    (no row statistics, a shape the own kernel does not take or loses to hipBLASLt): the caller then runs norm + projection."""
+    rows = row_stats(x)
+    n_out = w.shape[0] // 2 if geglu_act else w.shape[0]
+    M, K = x.numel() // x.shape[-1], x.shape[-1]
+    if (rows is None or not linear_supported(x, w) or K != norm.normalized_shape[0] or norm.weight is None or norm.bias is None or
+            norm.weight.dtype != torch.float16 or n_out % (64 if geglu_act else 8) or
+            not (geglu_act or linear_prefers_own(M, K, n_out))):
+        return None
+    wg, s_vec, t_vec = _ln_fold_weights(norm, w, bias)
+    out = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
+    rc = _lib.nn_lib().gip_linear_ln_f16(_p(x), _p(wg), _p(s_vec), _p(t_vec), _p(out), M, K, n_out, int(geglu_act), _p(rows), rows.shape[1],
+                                         float(norm.eps), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("gip_linear_ln_f16 failed with status %d" % rc)
+    return out
+
+
+class LNInput:
+    """`norm(x)` not yet computed: a projection that can fold the LayerNorm takes (x, norm) as they are (linear_ln), everything
+    else calls materialize() — the LayerNorm kernel, once."""
+
+    def __init__(self, x, norm):
+        self.x, self.norm, self._y = x, norm, None
+
+    def materialize(self):
+        if self._y is None:
+            self._y = self.norm(self.x)
+        return self._y
+
+    def linear(self, w, bias=None):
+        y = linear_ln(self.x, self.norm, w, bias)
+        return y if y is not None else linear_auto(self.materialize(), w, bias)
+
+
 def linear_prefers_own(M, K, N):
     """Which dense GEMM shapes run on this repo's MFMA linear (conv3x3_kernel<TAPS = 1>) and which stay on hipBLASLt — by
     measurement, shape by shape (profiles/r04_gemm_own_vs_hipblaslt.txt = tools/exp_gemm_table.py: every GEMM of the denoise at
@@ -561,17 +627,25 @@ def linear_prefers_own(M, K, N):
     return M >= 49152 or (K <= 1280 and N <= 1280) or (K <= 2560 and N <= 640 and M >= 12288)
 
 
-def linear_auto(x, w, bias=None, residual=None):
-    """F.linear(x, w, bias) (+ residual) on whichever of the two GEMM paths is faster for the shape (linear_prefers_own)."""
+def linear_auto(x, w, bias=None, residual=None, want_rows=False):
+    """F.linear(x, w, bias) (+ residual) on whichever of the two GEMM paths is faster for the shape (linear_prefers_own).
+    `want_rows`: the result feeds a LayerNorm — on the own kernel its epilogue also leaves the per-row sums that let the consumer
+    GEMM fold that LayerNorm (attached to the result: row_stats)."""
     M = x.numel() // x.shape[-1]
     if linear_supported(x, w) and w.shape[0] % 4 == 0 and (residual is None or residual.is_contiguous()) and \
             linear_prefers_own(M, x.shape[-1], w.shape[0]):
+        if want_rows and w.shape[0] % 8 == 0 and os.environ.get("GIP_LN_FOLD", "1") != "0":
+            holder = []
+            out = linear(x, w, bias, residual, rows=holder)
+            if holder:
+                setattr(out, _ROWS_ATTR, holder[0])
+            return out
         return linear(x, w, bias, residual)
     y = F.linear(x, w, bias)
     return y if residual is None else y + residual
 
 
-def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None):
+def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None, rows=None):
     """F.linear(x, w, bias) (+ residual) or, with geglu_act, GEGLU(F.linear(x, w, bias)) — one MFMA kernel with the bias /
     residual / activation in its epilogue (csrc/conv3x3.hip, TAPS = 1).  Inference only (frozen denoiser under no_grad);
     anything else goes to hipBLASLt through F.linear."""
@@ -580,6 +654,16 @@ def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None):
         M = x.numel() // x.shape[-1]
         out = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
         null = ctypes.c_void_p(None)
+        if rows is not None and not geglu_act and stats is None and n_out % 8 == 0:
+            # `rows`: a list that receives the per-row (sum, sum of squares) partials of the output [M, parts, 2]
+            lib = _lib.nn_lib()
+            rt = torch.empty((M, lib.gip_linear_row_parts(n_out), 2), dtype=torch.float32, device=x.device)
+            rc = lib.gip_linear_rows_f16(_p(x), _p(w), null if bias is None else _p(bias), null if residual is None else _p(residual), _p(out),
+                                         M, x.shape[-1], n_out, _p(rt), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("gip_linear_rows_f16 failed with status %d" % rc)
+            rows.append(rt)
+            return out
         if stats is not None and not geglu_act and M % 128 == 0 and n_out % 8 == 0 and os.environ.get("GIP_GN_STATS", "1") != "0":
             st = torch.empty((M // 128, n_out, 2), dtype=torch.float32, device=x.device)
             rc = _lib.nn_lib().gip_linear_stats_f16(_p(x), _p(w), null if bias is None else _p(bias),

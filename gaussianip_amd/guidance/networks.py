@@ -197,11 +197,24 @@ class Attention(nn.Module):
             out = self.to_out(h) + self.lora_out(h)
             return out if residual is None else residual + out
         if fused.linear_supported(h, self.to_out.weight) and (residual is None or residual.is_contiguous()):
-            return fused.linear_auto(h, self.to_out.weight, self.to_out.bias, residual)
+            # with the block's residual the result is the next LayerNorm's input: leave its row sums (LayerNorm fold)
+            return fused.linear_auto(h, self.to_out.weight, self.to_out.bias, residual, want_rows=residual is not None)
         out = self.to_out(h)
         return out if residual is None else residual + out
 
     def forward(self, x, ctx=None, residual=None):
+        """`x` may be a fused.LNInput (the block's LayerNorm not yet applied): the q | k | v projection of the self-attention and
+        the to_q projection of the cross-attention fold it into their GEMM; every other path materialises it first."""
+        lnin = x if isinstance(x, fused.LNInput) else None
+        if lnin is not None:
+            hot_self = (ctx is None and not (self.refine is not None and self.refine.ctl.state == "refine") and not self.lora_rank and
+                        self.to_q.bias is None and fused.qkv_fusable(lnin.x, self.to_q.weight))
+            hot_cross = (ctx is not None and self.staged_kv is not None and self.staged_kv[0].shape[0] == lnin.x.shape[0] and
+                         not self.lora_rank)
+            if not (hot_self or hot_cross):
+                x, lnin = lnin.materialize(), None
+            else:
+                x = lnin.x            # (shape / identity tests below; the projections take `lnin`)
         ip_ctx = None
         if ctx is None:
             if self.refine is not None and self.refine.ctl.state == "refine":
@@ -213,20 +226,28 @@ class Attention(nn.Module):
         staged, self.staged_kv = self.staged_kv, None
         if staged is not None and staged[0].shape[0] == x.shape[0] and not self.lora_rank:
             # key / value projections of the prompt tokens, made for all layers at once by _Encoder.stage_context
-            q = fused.linear_auto(x, self.to_q.weight, self.to_q.bias)
+            q = lnin.linear(self.to_q.weight, self.to_q.bias) if lnin is not None else fused.linear_auto(x, self.to_q.weight, self.to_q.bias)
             k, v, k_ip, v_ip = staged
             if fused.attention_supported(q, k, self.heads):
                 if k_ip is None:
                     return self._out(fused.attention(q, k, v, self.heads), residual)
                 return self._out(fused.attention(q, k, v, self.heads, k_ip, v_ip, self.ip_scale), residual)
+            if lnin is not None:
+                x, lnin = lnin.materialize(), None
         if ctx is x and not self.lora_rank and self.to_q.bias is None and fused.qkv_fusable(x, self.to_q.weight):
             # self-attention with frozen, folded weights: ONE [3C, C] projection (the tokens are read once, not three times);
             # q, k, v are column ranges of its output and the attention kernel reads them in place through row strides
             C = x.shape[-1]
-            qkv = fused.linear_auto(x, fused.qkv_weight(self.to_q.weight, self.to_k.weight, self.to_v.weight))
+            wqkv = fused.qkv_weight(self.to_q.weight, self.to_k.weight, self.to_v.weight)
+            qkv = lnin.linear(wqkv) if lnin is not None else fused.linear_auto(x, wqkv)
             q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
             if fused.attention_supported(q, k, self.heads):
                 return self._out(fused.attention(q, k, v, self.heads), residual)
+        if lnin is not None:             # no folding path applied after all: the LayerNorm kernel, and self-attention attends to ITS output
+            self_attn = ctx is x
+            x, lnin = lnin.materialize(), None
+            if self_attn:
+                ctx = x
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if self.lora_rank:
             q, k, v = q + self.lora_q(x), k + self.lora_k(ctx), v + self.lora_v(ctx)
@@ -262,15 +283,21 @@ class TransformerBlock(nn.Module):
         self.ff_out = nn.Linear(dim * 4, dim)
 
     def forward(self, x, ctx, replicas=1):
-        x = self.attn1(self.norm1(x), None, x)                 # residual adds ride in the out-projection's epilogue
+        # the three LayerNorms are handed to their consumers un-applied (fused.LNInput): where the consuming projection runs on
+        # this repo's MFMA linear and x carries its producer's row sums, the normalisation is folded into that GEMM's epilogue
+        x = self.attn1(fused.LNInput(x, self.norm1), None, x)  # residual adds ride in the out-projection's epilogue
         if replicas > 1:                                       # x held one copy of `replicas` identical samples so far
             x = x.repeat(replicas, 1, 1)
-        x = self.attn2(self.norm2(x), ctx, x)
-        h = self.norm3(x)
-        if h.shape[0] * h.shape[1] >= _GEGLU_FUSE_MIN_ROWS and fused.linear_supported(h, self.ff_in.weight):
-            h = fused.linear(h, self.ff_in.weight, self.ff_in.bias, None, True)        # GEGLU in the GEMM epilogue
+        x = self.attn2(fused.LNInput(x, self.norm2), ctx, x)
+        h = None
+        if x.shape[0] * x.shape[1] >= _GEGLU_FUSE_MIN_ROWS:
+            h = fused.linear_ln(x, self.norm3, self.ff_in.weight, self.ff_in.bias, True)      # LayerNorm AND GEGLU in the GEMM's epilogue
+        if h is not None:
+            pass
+        elif x.shape[0] * x.shape[1] >= _GEGLU_FUSE_MIN_ROWS and fused.linear_supported(x, self.ff_in.weight):
+            h = fused.linear(self.norm3(x), self.ff_in.weight, self.ff_in.bias, None, True)        # GEGLU in the GEMM epilogue
         else:
-            h = geglu(self.ff_in(h))
+            h = geglu(self.ff_in(self.norm3(x)))
         if fused.linear_supported(h, self.ff_out.weight) and x.is_contiguous():
             return fused.linear_auto(h, self.ff_out.weight, self.ff_out.bias, x)
         return x + self.ff_out(h)
@@ -290,7 +317,8 @@ class SpatialTransformer(nn.Module):
         copy and the result is tiled before attn2 — the same values, 1/replicas of the work."""
         B, C, H, W = x.shape
         if fusable(x):      # NHWC: the 1x1 projections are GEMMs on the token view, no layout change anywhere
-            t = fused.linear_auto(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
+            t = fused.linear_auto(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias,
+                                  want_rows=True)      # norm1 of the block reads this tensor: its row sums come out of the epilogue
             res = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
             if replicas > 1:
                 res = res.repeat(replicas, 1, 1)

@@ -211,6 +211,19 @@ int gip_winograd_output_stats_f16(const void* M, const void* bias, const void* r
 int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int32_t K,
                    int32_t Nout, int32_t geglu, void* stream);
 
+/* LayerNorm folded into the projection that consumes it (BasicTransformerBlock: norm1 -> q|k|v, norm2 -> to_q, norm3 -> GEGLU ff_in;
+ * reference: diffusers BasicTransformerBlock as run by threestudio/models/guidance/ipa_guidance.py:311-358).
+ *   out = LN(x) W^T + b  =  rstd_m (x_m . (W gamma)_n) - rstd_m mu_m s_n + t_n,   s_n = sum_k (W gamma)[n][k],  t_n = sum_k W[n][k] beta_k + b_n
+ * gip_linear_rows_f16: gip_linear_f16 (no GEGLU) whose epilogue also leaves, per output row, the (sum, sum of squares) of the final
+ *   half-rounded output over each channel tile: rows_out [M][gip_linear_row_parts(Nout)][2] float32.
+ * gip_linear_ln_f16: x raw [M, K]; wg = W * gamma (half; GEGLU: [2 Nout, K] = [value | gate]); s, t float32 [Nout] ([2 Nout]);
+ *   ln_rows [M][ln_parts][2] = the partial sums the producer of x left; eps = the LayerNorm's.  No LayerNorm kernel, no normalised copy. */
+int32_t gip_linear_row_parts(int32_t Nout);
+int gip_linear_rows_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int32_t K,
+                        int32_t Nout, float* rows_out, void* stream);
+int gip_linear_ln_f16(const void* x, const void* wg, const float* s, const float* t, void* out, int64_t M, int32_t K, int32_t Nout,
+                      int32_t geglu, const float* ln_rows, int32_t ln_parts, float eps, void* stream);
+
 /* Attention forward o = softmax(q k^T * scale) v  [+ weight2 * softmax(q k2^T * scale) v2]  (csrc/attention.hip):
  * q, o [B, Nq, H*D], k, v [B, Nkv, H*D], k2, v2 [B, Nkv2, H*D] half — the projection outputs / to_out input, heads
  * interleaved along the last axis (no head transposes).  fp32 softmax and accumulation.  No mask, no gradient (the

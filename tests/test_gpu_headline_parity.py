@@ -146,7 +146,7 @@ def test_single_view_forward_and_all_gradients_at_100k_1024(oracle, look, list_m
     print("%s: %d knife-edge pixels, %d Gaussians are the subject of a knife-edge test" % (tag, n_knife_pixels, int(knife.sum())))
     assert n_knife_pixels <= 5e-4 * H * W and knife.sum() <= 5e-3 * P, (n_knife_pixels, int(knife.sum()))
     print("%s: %d rows behind a knife-edge subject (REL_TOL_DOWNSTREAM class)" % (tag, int(behind.sum())))
-    assert behind.sum() <= 0.15 * P, int(behind.sum())          # a large class; the guard is MAX_LOOSE_ENTRIES in _compare
+    assert behind.sum() <= 0.10 * P, int(behind.sum())          # measured 6.0 % (init) / 8.6 % (trained); the guard is MAX_LOOSE_ENTRIES in _compare
     rot_floor = float(np.abs(go["scales"] * sc["scales"]).max())      # rotation of an isotropic splat: analytically 0
     for name, ours in (("means3D", t["means3D"].grad), ("means2D", m2.grad), ("opacities", t["opacities"].grad),
                        ("shs", t["shs"].grad), ("scales", t["scales"].grad), ("rotations", t["rotations"].grad)):
@@ -193,7 +193,8 @@ def test_four_view_launch_set_at_100k_1024(oracle, list_mode):
     assert knife_any.sum() <= 1e-2 * P, int(knife_any.sum())       # ~1e-3 of the Gaussians per view
     # the looser REL_TOL_DOWNSTREAM class (rows blended behind a knife-edge subject) is bounded too
     print("4 views: rows behind a knife-edge subject per view %s, union %d" % ([int(b.sum()) for b in behind], int(behind_any.sum())))
-    assert all(b.sum() <= 0.2 * P for b in behind) and behind_any.sum() <= 0.5 * P, [int(b.sum()) for b in behind]
+    # measured: 6.0 / 12.4 / 13.2 / 14.3 % per view, 36.9 % in the union of the four views
+    assert all(b.sum() <= 0.16 * P for b in behind) and behind_any.sum() <= 0.40 * P, [int(b.sum()) for b in behind]
     for v in range(4):
         o_color, o_radii, o_depth, o_alpha = imgs[v]
         assert np.array_equal(radii[v].cpu().numpy(), o_radii), "radii of view %d" % v

@@ -34,4 +34,12 @@ def test_refine_pass_hip_path_matches_torch_path(monkeypatch):
         ref, _ = vcr.refine_rgb(rgb, ctrl, lambda n: (cond, uncond), views=views, generator=torch.Generator(device="cuda").manual_seed(3))
     assert len(calls) == n_calls, "fused.disabled() must keep the pass on plain PyTorch ops"
     d = (out - ref).abs()
+    q = torch.quantile(d.flatten()[::7].float(), torch.tensor([0.5, 0.99, 0.9999], device=d.device))
+    print("refine HIP vs torch-op path on [0,1] images: mean %.2e median %.2e p99 %.2e p99.99 %.2e max %.2e" % (
+        float(d.mean()), float(q[0]), float(q[1]), float(q[2]), float(d.max())))
+    import json, os
+    gout = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(gout):
+        json.dump(dict(mean=float(d.mean()), median=float(q[0]), p99=float(q[1]), p9999=float(q[2]), max=float(d.max())),
+                  open(os.path.join(gout, "refine_parity.json"), "w"))
     assert float(d.mean()) < 4e-3 and float(d.max()) < 0.15, (float(d.mean()), float(d.max()))
