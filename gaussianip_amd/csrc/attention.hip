@@ -18,6 +18,7 @@
 // almost all accumulator rescales; probabilities stay <= 256, well inside half range.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gip_nn.h"
 
@@ -43,7 +44,11 @@ union Frag8 {
   uint4 u;
 };
 
-template <int D, bool TWO>
+// SPLIT: the online softmax advances per 32-key TILE instead of per 64-key block (maximum, deferred-raise test, exp2 and the PV
+// product of tile 0 before those of tile 1).  The S^T MFMAs of both tiles are still issued first; tile 0's maximum / exp2 then
+// depend on its own three MFMAs only, so they run while tile 1's are in the matrix pipe, and tile 1's vector work runs under
+// tile 0's PV MFMAs — the block-wide maximum made every exp2 wait for all six.  Same arithmetic per key (one more raise test).
+template <int D, bool TWO, bool SPLIT>
 __global__ void __launch_bounds__(256, D > 128 ? 1 : 2)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
@@ -207,6 +212,43 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
             if (blk * AT_BKV + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= n_keys) S[t][i] = -INFINITY;
       }
 
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          // ---- online softmax of this 32-key tile on the lane's query column ----
+          float mloc = S[t][0];
+#pragma unroll
+          for (int i = 1; i < 16; i++) mloc = fmaxf(mloc, S[t][i]);
+          mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+          const bool raise = (mloc - m_run) * c > AT_DEFER;     // true on the first tile (m_run = -inf)
+          if (__any(raise)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            if constexpr (!L_FROM_MFMA) l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+              for (int i = 0; i < 16; i++) O[dt][i] *= alpha;
+            m_run = m_new;
+          }
+          const float mc = m_run * c;
+          Frag8 P[2];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
+              if constexpr (!L_FROM_MFMA) l_run += p;
+              P[s2].v[j] = (_Float16)p;
+            }
+          // ---- O^T += V^T P^T for this tile ----
+#pragma unroll
+          for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+              O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[s2].v, O[dt], 0, 0, 0);
+        }
+      } else {
       // ---- online softmax on the lane's query column ----
       float mloc = S[0][0];
 #pragma unroll
@@ -246,6 +288,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
           for (int s2 = 0; s2 < 2; s2++)
             O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
+      }
 
       if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
       __syncthreads();
@@ -291,15 +334,25 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     }
 }
 
+template <int D, bool SPLIT>
+static void launch_attn2(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
+                         float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
+  if (k2)
+    hipLaunchKernelGGL((attn_fwd_kernel<D, true, SPLIT>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<D, false, SPLIT>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv, ld_kv, ld_q);
+}
+
 template <int D>
 static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
                         float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
-  if (k2)
-    hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
-                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
-                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv, ld_kv, ld_q);
+  // GIP_ATTN_SPLIT: per-tile online softmax (see attn_fwd_kernel); same-box A/B switch, read once
+  // measured and NOT adopted (round 4, two alternating runs: D = 40, N = 4096, B = 12: 0.438 ms plain, 0.446 ms split; every shape 1-2 % slower)
+  static const int split = [] { const char* e = getenv("GIP_ATTN_SPLIT"); return e && *e ? atoi(e) : 0; }();
+  if (split && D <= 80) launch_attn2<D, true>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
+  else launch_attn2<D, false>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
 }
 
 extern "C" int gip_attention_fwd_strided2_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
