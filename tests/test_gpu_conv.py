@@ -464,7 +464,8 @@ def test_winograd_convolution_at_the_16x16_level(cfg, monkeypatch):
     assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
-HALO_SHAPES = [(2, 128, 128, 128), (3, 512, 48, 64), (1, 128, 8, 4096), (4, 128, 64, 128)]      # N, Cout, H, W (Cin = 128)
+# N, Cout, H, W (Cin = 128); the last two are large enough for the 16 x 16 / 8-wave form (conv_big_kernel<128, 9, HALO>)
+HALO_SHAPES = [(2, 128, 128, 128), (3, 512, 48, 64), (1, 128, 8, 4096), (4, 128, 64, 128), (4, 128, 256, 256), (2, 256, 128, 256)]
 
 
 @pytest.mark.parametrize("shape", HALO_SHAPES)
@@ -479,6 +480,7 @@ def test_halo_resident_tile_of_the_128_channel_convolution(shape, mode):
     from gaussianip_amd.guidance import fused
     N, co, H, W = shape
     assert fused._conv_tiles(N, H, W, co) >= 256 and H % 8 == 0 and W % 16 == 0
+    # (the debug knob below also switches the 8-wave halo form off: `base` is the streaming 128-pixel kernel for every shape)
     g = torch.Generator(device="cuda").manual_seed(co + H + W)
     cl = dict(memory_format=torch.channels_last)
     x = torch.randn(N, 128, H, W, device="cuda", generator=g).half().contiguous(**cl)
@@ -506,8 +508,13 @@ def test_halo_resident_tile_of_the_128_channel_convolution(shape, mode):
         tot = torch.stack([rows.reshape(N, -1, co).double().sum(1), (rows.reshape(N, -1, co).double() ** 2).sum(1)], dim=-1)   # per sample
         got = st.reshape(N, -1, co, 2).double().sum(1)
         assert float((got - tot).abs().max()) <= 2e-5 * float(tot.abs().max())
-        # a statistics block = the 128 pixels of ONE 16 x 8 image block of one sample
-        blk = out.float().reshape(N, co, H // 8, 8, W // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(N * (H // 8) * (W // 16), co, 128)
+        # a statistics block = the 128 pixels of ONE 16 x 8 image block of one sample; block order: (sample, block row, block column)
+        # on the 4-wave kernel, (sample, 16-row tile, tile column, upper / lower half) on the 8-wave one
+        big = H % 16 == 0 and co % 128 == 0 and (N * H * W // 256) * (co // 128) >= 224
+        if big:
+            blk = out.float().reshape(N, co, H // 16, 2, 8, W // 16, 16).permute(0, 2, 5, 3, 1, 4, 6).reshape(-1, co, 128)
+        else:
+            blk = out.float().reshape(N, co, H // 8, 8, W // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(N * (H // 8) * (W // 16), co, 128)
         want = torch.stack([blk.double().sum(-1), (blk.double() ** 2).sum(-1)], dim=-1)
         assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 

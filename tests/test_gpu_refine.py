@@ -42,4 +42,6 @@ def test_refine_pass_hip_path_matches_torch_path(monkeypatch):
     if os.path.isdir(gout):
         json.dump(dict(mean=float(d.mean()), median=float(q[0]), p99=float(q[1]), p9999=float(q[2]), max=float(d.max())),
                   open(os.path.join(gout, "refine_parity.json"), "w"))
-    assert float(d.mean()) < 4e-3 and float(d.max()) < 0.15, (float(d.mean()), float(d.max()))
+    # measured (round 4, profiles/r04_refine_parity.json): mean 1.2e-3, median 7.9e-4, p99 5.6e-3, p99.99 1.2e-2, max 2.0e-2 — two
+    # fp16 paths through 2 DDIM steps of ControlNet + U-Net and the VAE decoder; the round-3 bar was max < 0.15
+    assert float(d.mean()) < 2.5e-3 and float(q[1]) < 1.2e-2 and float(d.max()) < 0.06, (float(d.mean()), float(q[1]), float(d.max()))
