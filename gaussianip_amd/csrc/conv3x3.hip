@@ -615,26 +615,17 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #define CVB_BM 256
 #define CVB_THREADS 512
 
-// HALO (BN = 128, TAPS = 9, Cin = 128, stride 1 / pad 1, H % 16 == 0, W % 16 == 0): the 256-pixel tile is a 16 x 16 image block
-// whose 18 x 18 x 128-channel halo is brought into LDS once (82 KB) and read by all nine taps at shifted rows — the halo idea of
-// conv3x3_kernel<..., HALO> on this kernel's 8-wave skeleton: per 128 pixels 186 KB of LDS-DMA (half a halo + 288 KB / 2 of
-// weights) instead of 334 KB, because one weight stream now serves 256 pixels.
-#define CVBH_ROWS 328                       // halo rows held per channel block (324 used: 18 x 18; wave 0 of the sixth round)
-#define CVBH_KC_BYTES (CVBH_ROWS * 128)
-template <int BN, int TAPS, bool HALO = false>
+template <int BN, int TAPS>
 __global__ void __launch_bounds__(CVB_THREADS, 2)
 conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                 const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                 int m_tiles, int n_tiles, int Hin, int Win, int geom, float* __restrict__ chan_stats, GnBwdArgs gnb) {
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
-  static_assert(!HALO || (BN == 128 && TAPS == 9), "halo mode: 128-channel tile of a 3x3 convolution");
-  constexpr int HALO_BYTES = HALO ? 2 * CVBH_KC_BYTES : 0;
-  unsigned char* const smem = smem_raw + HALO_BYTES;      // the stage buffers (and the epilogue image) behind the halo image
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int WN = BN == 256 ? 4 : 2, WM = 8 / WN;      // wave grid: WM (pixel direction) x WN (channel direction)
   constexpr int MI = CVB_BM / WM / 16;                     // 16-pixel MFMA tiles per wave: 8 (BN = 256) or 4
   constexpr int NI = BN / WN / 16;                         // 16-channel MFMA tiles per wave: 4
-  constexpr int A_BYTES = HALO ? 0 : CVB_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = CVB_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_ROUNDS = CVB_BM / 64, B_ROUNDS = BN / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wr = wave / WN, wc = wave % WN;
@@ -647,25 +638,13 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   const unsigned m0 = (unsigned)mt * CVB_BM;
   const int co0 = nt * BN;
   const int HW = H * W;
-  // HALO: tile mt = 16 x 16 block (n, by, bx); tile row r = pixel (by * 16 + (r >> 4), bx * 16 + (r & 15)); tiles sample-major
-  unsigned h_n = 0, h_y0 = 0, h_x0 = 0;
-  if constexpr (HALO) {
-    const unsigned tiles_x = (unsigned)W >> 4, per_img = tiles_x * ((unsigned)H >> 4);
-    h_n = (unsigned)mt / per_img;
-    const unsigned rem = (unsigned)mt - h_n * per_img, by = rem / tiles_x;
-    h_y0 = by * 16u; h_x0 = (rem - by * tiles_x) * 16u;
-  }
-  auto row_m = [&](int row) -> unsigned {
-    if constexpr (HALO) return (h_n * (unsigned)H + h_y0 + ((unsigned)row >> 4)) * (unsigned)W + h_x0 + ((unsigned)row & 15u);
-    else return m0 + (unsigned)row;
-  };
 
   // ---- per-thread DMA descriptors: a round is 64 rows (8 waves x 8 rows), a lane fills one 16-byte chunk ----
   const int sub_row = wave * 8 + (lane >> 3);
   const int pchunk = lane & 7;
   unsigned a_off[A_ROUNDS], a_mask[A_ROUNDS];
 #pragma unroll
-  for (int i = 0; i < (HALO ? 0 : A_ROUNDS); i++) {
+  for (int i = 0; i < A_ROUNDS; i++) {
     const int row = i * 64 + sub_row;
     const unsigned m = m0 + row;
     const int lchunk = pchunk ^ ((row >> 1) & 7);
@@ -710,11 +689,9 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
     const int dy = tap / 3, dx = tap - dy * 3;
     const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * Win + dx) * Cin : 0) + cb * CV_BK) * 2u;
     const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
-    if constexpr (!HALO) {
-      unsigned char* sa = smem + buf * STAGE + wave * 1024;
+    unsigned char* sa = smem + buf * STAGE + wave * 1024;
 #pragma unroll
-      for (int i = 0; i < A_ROUNDS; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 8192);
-    }
+    for (int i = 0; i < A_ROUNDS; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 8192);
     unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; i++) dma16(wrs, b_off[i], wtap_off, sb + i * 8192);
@@ -729,10 +706,6 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   const int frag_row = lane & 15, swz = (lane >> 1) & 7, kq = lane >> 4;
   const int pix_base = (wr * (CVB_BM / WM) + frag_row) * 128;
   const int ch_base = A_BYTES + (wc * (BN / WN) + frag_row) * 128;
-  // HALO: halo row of this lane's pixel of fragment tile mi at tap (0, 0): (wr * (64 / 16) + mi) * 18 + (lane & 15) for the
-  // 64-pixel wave quarter (4 image rows of 16 pixels); tap (dy, dx) adds dy * 18 + dx
-  const int hrow0 = wr * (CVB_BM / WM / 16) * 18 + frag_row;
-  int h_shift = 0, h_cb = 0;                               // (tap, channel block) of the K step being computed (set in the loop)
 
   // A K step = 2 k-halves x (MI / 4) groups of 4 pixel fragments = 16 MFMAs per group.  The fragments of group g + 1 are
   // read while the MFMAs of group g run (two register sets, order pinned with sched_barrier: left alone the compiler
@@ -747,14 +720,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
     const int ks = g / (MI / 4), mg = (g % (MI / 4)) * 4;
     const int pc = ((ks * 4 + kq) ^ swz) * 16;
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-      if constexpr (HALO) {
-        const int hr = hrow0 + (mg + mi) * 18 + h_shift;
-        px[mi] = *(const f16x8*)(smem_raw + h_cb * CVBH_KC_BYTES + hr * 128 + (((ks * 4 + kq) ^ ((hr >> 1) & 7)) << 4));
-      } else {
-        px[mi] = *(const f16x8*)(sbuf + pix_base + (mg + mi) * 2048 + pc);
-      }
-    }
+    for (int mi = 0; mi < 4; mi++) px[mi] = *(const f16x8*)(sbuf + pix_base + (mg + mi) * 2048 + pc);
   };
   auto mma = [&](const f16x8* wt, const f16x8* px, int g) {
     const int mg = (g % (MI / 4)) * 4;
@@ -807,24 +773,6 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   auto advance = [&]() {
     if (++cb == cblocks) { cb = 0; ++tap; }
   };
-  if constexpr (HALO) {
-    // the halo image, once: 6 rounds of 64 rows per channel block (round 5: wave 0 only, rows 320..327; rows >= 324 and pixels
-    // outside the image read zeros).  Row r = halo pixel (r / 18, r % 18) = image pixel (y0 - 1 + r / 18, x0 - 1 + r % 18)
-    const __amdgpu_buffer_rsrc_t xh = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(M * (unsigned)Cin * 2u), CV_RSRC_FLAGS);
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      if (i == 5 && wave > 0) break;
-      const int hr = i * 64 + sub_row;
-      const int hy = hr / 18, hx = hr - hy * 18;
-      const int iy = (int)h_y0 - 1 + hy, ix = (int)h_x0 - 1 + hx;
-      const int lchunk = pchunk ^ ((hr >> 1) & 7);
-      const bool ok = hr < 324 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const unsigned off = ok ? (((h_n * (unsigned)H + (unsigned)iy) * (unsigned)W + (unsigned)ix) * (unsigned)Cin + lchunk * 8) * 2u : CV_OOB;
-      dma16(xh, off, 0u, smem_raw + i * 8192 + wave * 1024);
-      dma16(xh, off, 128u, smem_raw + CVBH_KC_BYTES + i * 8192 + wave * 1024);
-    }
-  }
-  int tap_c = tap, cb_c = cb;
   stage(tap, cb, 0);
   advance();
   {
@@ -832,10 +780,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
     __syncthreads();
     for (int kt = 0; kt < KT; kt++) {
       const int buf = kt & 1;
-      const int tap_n = tap, cb_n = cb;
       if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
-      if constexpr (HALO) { h_shift = (tap_c / 3) * 18 + (tap_c - (tap_c / 3) * 3); h_cb = cb_c; }
-      tap_c = tap_n; cb_c = cb_n;
       half1(smem + buf * STAGE);
       half2(smem + buf * STAGE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -844,7 +789,6 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
   }
 
   // ---- epilogue: half-rounded tile image [rows][BN] in LDS, 16-byte row accesses (see conv3x3_kernel) ----
-  unsigned char* const epi = smem_raw;                   // every LDS byte is free now (HALO: the halo image too)
   auto add4 = [](f32x4& v, const _Float16* p) {
     const f16x4 b = *(const f16x4*)p;
     v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
@@ -864,7 +808,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
 #pragma unroll
     for (int j = 0; j < 8; j++) { s8[b][j] = 0.f; q8[b][j] = 0.f; }
   GnBwdLane gl;
-  if (chan_stats && gnb.x && mine) gnb_load(gnb, (int)(HALO ? h_n : m0 / (unsigned)gnb.HW), co, Cout, gl);
+  if (chan_stats && gnb.x && mine) gnb_load(gnb, (int)(m0 / (unsigned)gnb.HW), co, Cout, gl);
 #pragma unroll
   for (int pass = 0; pass < PASSES; pass++) {
     // the residual rows of this pass are requested before the image is staged (geom bit 29, see conv3x3_kernel)
@@ -875,7 +819,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
 #pragma unroll
       for (int k = 0; k < RPF; k++) {
         const int row = r0 + k * RPP;
-        const unsigned m = row_m(pass * PROWS + row);
+        const unsigned m = m0 + pass * PROWS + row;
         rres[k] = (row < PROWS && m < M) ? *(const f16x8*)(early_src + (size_t)m * Cout + co) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
@@ -891,7 +835,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
           const f32x4 v = acc[ni][mi];
           f16x4 o;
           o[0] = (_Float16)(v[0] + b4[0]); o[1] = (_Float16)(v[1] + b4[1]); o[2] = (_Float16)(v[2] + b4[2]); o[3] = (_Float16)(v[3] + b4[3]);
-          *(f16x4*)(epi + p * ROWB + cl * 2) = o;
+          *(f16x4*)(smem + p * ROWB + cl * 2) = o;
         }
       }
     }
@@ -900,9 +844,9 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
 #pragma unroll
       for (int k = 0; k < RPT; k++) {
         const int row = r0 + k * RPP;
-        const unsigned m = row_m(pass * PROWS + row);
+        const unsigned m = m0 + pass * PROWS + row;
         if (row >= PROWS || m >= M) break;
-        f16x8 v = *(const f16x8*)(epi + row * ROWB + chunk * 16);
+        f16x8 v = *(const f16x8*)(smem + row * ROWB + chunk * 16);
         if (residual) {
           const f16x8 rr = (res_early && k < RPF) ? rres[k < RPF ? k : 0] : *(const f16x8*)(residual + (size_t)m * Cout + co);
 #pragma unroll
@@ -929,7 +873,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
     __syncthreads();                                      // the image is rewritten by the next pass / the partials below
   }
   if (chan_stats) {
-    float* part = (float*)epi;                            // [RPP][BN][2]
+    float* part = (float*)smem;                           // [RPP][BN][2]
 #pragma unroll
     for (int b = 0; b < 2; b++) {
       if ((size_t)(mt * 2 + b) * 128 >= M) break;         // uniform
@@ -1043,23 +987,23 @@ static int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-template <int BN, int TAPS, bool HALO = false>
+template <int BN, int TAPS>
 static int launch_big(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W, int Cin,
                       int Cout, hipStream_t s, int Hin, int Win, int geom, float* chan_stats, const GnBwdArgs& gnb) {
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + CVB_BM - 1) / CVB_BM), n_tiles = (Cout + BN - 1) / BN;
-  const size_t lds = HALO ? 2 * (size_t)CVBH_KC_BYTES + 2 * (size_t)BN * 128 : 2 * (size_t)(CVB_BM + BN) * 128;
+  const size_t lds = 2 * (size_t)(CVB_BM + BN) * 128;
   static_assert((size_t)(CVB_BM / (BN == 256 ? 2 : 1)) * (BN * 2 + 16) <= 2 * (size_t)(CVB_BM + BN) * 128 &&
                 (size_t)(CVB_THREADS / (BN / 8)) * BN * 8 <= 2 * (size_t)(CVB_BM + BN) * 128, "epilogue image / partials must fit");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_big_kernel<BN, TAPS, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv_big_kernel<BN, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return 3;
     attr_set = true;
   }
   static const int env_res = env_int("GIP_CONV_RES_EARLY", 1);
   geom |= env_res << 29;
-  hipLaunchKernelGGL((conv_big_kernel<BN, TAPS, HALO>), dim3(m_tiles * n_tiles), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
+  hipLaunchKernelGGL((conv_big_kernel<BN, TAPS>), dim3(m_tiles * n_tiles), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin, Cout,
                      m_tiles, n_tiles, Hin, Win, geom, chan_stats, gnb);
   return hipGetLastError() == hipSuccess ? 0 : 3;
@@ -1099,14 +1043,9 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
     // halo-resident pixel tile (see conv3x3_kernel): Cin = 128, plain 3x3 / stride 1 / pad 1, whole-K tiles that fill the chip
     static const int env_halo = env_int("GIP_CONV_HALO", 1);
     static const int env_epi_h = env_int("GIP_CONV_EPILOGUE", 1);
-    const bool halo_ok = env_halo && env_epi_h && gip_dbg_conv_epilogue != 0 && gip_dbg_conv_ksplit <= 0 && Cin == 128 &&
-                         (geom & 0xffffff) == (1 | (1 << 8) | (1 << 16)) && tapsel == 0x1ff && !(H & 7) && !(W & 15) && Hin == H && Win == W &&
-                         !(Cout & 7) && stats_rows == 128 && !(gnb.x && gnb.HW != H * W);
-    // 16 x 16 image blocks on the 8-wave kernel (one weight stream per 256 pixels) where those tiles still fill the chip at one
-    // workgroup per CU; GIP_CONV_HALO=2 keeps the 16 x 8 / 4-wave form everywhere (A/B)
-    if (halo_ok && env_halo != 2 && gip_dbg_conv_big != 0 && !(H & 15) && !(Cout & 127) && (M / CVB_BM) * (Cout / 128) >= 224)
-      return launch_big<128, TAPS, true>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, Hin, Win, geom, chan_stats, gnb);
-    if (halo_ok && (long long)m_tiles * n_tiles >= 256) {
+    if (env_halo && env_epi_h && gip_dbg_conv_epilogue != 0 && gip_dbg_conv_ksplit <= 0 && Cin == 128 && (geom & 0xffffff) == (1 | (1 << 8) | (1 << 16)) &&
+        tapsel == 0x1ff && !(H & 7) && !(W & 15) && Hin == H && Win == W && !(Cout & 7) && stats_rows == 128 &&
+        (long long)m_tiles * n_tiles >= 256 && !(gnb.x && gnb.HW != H * W)) {
       constexpr size_t lds_h = 2 * (size_t)CVH_KC_BYTES + STAGES * (size_t)BN * 128;
       static_assert((size_t)CV_BM * (BN * 2 + 16) + (size_t)(CV_THREADS / (BN / 8)) * BN * 8 <= lds_h, "epilogue image must fit");
       static bool attr_h = false;

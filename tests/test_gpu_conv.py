@@ -510,7 +510,7 @@ def test_halo_resident_tile_of_the_128_channel_convolution(shape, mode):
         assert float((got - tot).abs().max()) <= 2e-5 * float(tot.abs().max())
         # a statistics block = the 128 pixels of ONE 16 x 8 image block of one sample; block order: (sample, block row, block column)
         # on the 4-wave kernel, (sample, 16-row tile, tile column, upper / lower half) on the 8-wave one
-        big = H % 16 == 0 and co % 128 == 0 and (N * H * W // 256) * (co // 128) >= 224
+        big = False       # (the 8-wave 16 x 16 form was measured slower and is not dispatched: tools/experiments/conv_big_halo_16x16.diff.txt)
         if big:
             blk = out.float().reshape(N, co, H // 16, 2, 8, W // 16, 16).permute(0, 2, 5, 3, 1, 4, 6).reshape(-1, co, 128)
         else:
