@@ -414,6 +414,13 @@ def main():
         try:
             ahds = bench_ahds.measure(steps=args.ahds_steps, warmup=4, gaussians=P, flops=(rank == 0), rank=rank,
                                       world=world, device=dev)
+            if world > 1:
+                # every rank its own seed (launch.py:80), all 4 views local, nothing exchanged: the embarrassingly parallel layout —
+                # what N GPUs deliver when they are spent on seeds instead of on one step's views
+                so = bench_ahds.measure(steps=max(args.ahds_steps // 2, 4), warmup=3, gaussians=P, rank=rank, world=world, device=dev,
+                                        pieces=False, group_size=1)
+                ahds["layout_seeds_only_4_views_x_%d_seeds" % world] = dict(so, views_per_s=round(so["value"] * 4, 2),
+                                                                           note="ViewSharding(group_size=1): no collective in the step")
             if world >= 8 and world % 2 == 0:
                 # 8 GPUs spent the other way: 4 seed groups of 2 ranks x 2 views (batch-6 networks per rank), beside configs[3]'s 4 x 2
                 alt = bench_ahds.measure(steps=max(args.ahds_steps // 2, 4), warmup=3, gaussians=P, rank=rank, world=world, device=dev,

@@ -464,8 +464,8 @@ def test_winograd_convolution_at_the_16x16_level(cfg, monkeypatch):
     assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
-# N, Cout, H, W (Cin = 128); the last two are large enough for the 16 x 16 / 8-wave form (conv_big_kernel<128, 9, HALO>)
-HALO_SHAPES = [(2, 128, 128, 128), (3, 512, 48, 64), (1, 128, 8, 4096), (4, 128, 64, 128), (4, 128, 256, 256), (2, 256, 128, 256)]
+# N, Cout, H, W (Cin = 128).  (Cout % 256 == 0 at >= 224 tiles of 256 pixels goes to the 256 x 256 streaming kernel instead.)
+HALO_SHAPES = [(2, 128, 128, 128), (3, 512, 48, 64), (1, 128, 8, 4096), (4, 128, 64, 128), (4, 128, 256, 256), (2, 384, 128, 256)]
 
 
 @pytest.mark.parametrize("shape", HALO_SHAPES)
