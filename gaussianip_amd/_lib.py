@@ -173,6 +173,16 @@ def model_lib():
         lib.gip_unpack_bucket.restype = ctypes.c_int
         lib.gip_unpack_bucket.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, _vp,
                                           ctypes.c_int64, _vp, ctypes.c_float, _vp]
+        lib.gip_sparsity_workspace_bytes.restype = ctypes.c_size_t
+        lib.gip_sparsity_workspace_bytes.argtypes = []
+        lib.gip_sparsity_loss_forward.restype = ctypes.c_int
+        lib.gip_sparsity_loss_forward.argtypes = [_vp, ctypes.c_int64, _vp, _vp]
+        lib.gip_sparsity_loss_backward.restype = ctypes.c_int
+        lib.gip_sparsity_loss_backward.argtypes = [_vp, ctypes.c_int64, _vp, ctypes.c_float, _vp, _vp, _vp]
+        lib.gip_activate_gaussians.restype = ctypes.c_int
+        lib.gip_activate_gaussians.argtypes = [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]
+        lib.gip_activate_gaussians_backward.restype = ctypes.c_int
+        lib.gip_activate_gaussians_backward.argtypes = [_vp] * 6 + [ctypes.c_int64, _vp, _vp, _vp, _vp]
         _model = _Counted(lib)
     return _model
 
@@ -268,6 +278,20 @@ def nn_lib():
         lib.gip_linear_f16.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]
         lib.gip_conv3x3_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp, ctypes.c_size_t, _vp]
+        _i64p = ctypes.POINTER(ctypes.c_int64)
+        lib.gip_image_prep_f16.restype = ctypes.c_int
+        lib.gip_image_prep_f16.argtypes = [_vp] + [ctypes.c_int32] * 4 + [_vp, _vp]
+        lib.gip_image_prep_backward_f16.restype = ctypes.c_int
+        lib.gip_image_prep_backward_f16.argtypes = [_vp] + [ctypes.c_int32] * 4 + [_vp, _vp]
+        lib.gip_latent_sample_f16.restype = ctypes.c_int
+        lib.gip_latent_sample_f16.argtypes = [_vp, _i64p, _vp, _vp, _vp, _vp, ctypes.c_float] + [ctypes.c_int32] * 5 + [_vp, _vp, _vp]
+        lib.gip_latent_sample_backward_f16.restype = ctypes.c_int
+        lib.gip_latent_sample_backward_f16.argtypes = [_vp, _i64p, _vp, _vp, ctypes.c_float] + [ctypes.c_int32] * 4 + [_vp, _vp]
+        lib.gip_anpg_loss_f16.restype = ctypes.c_int
+        lib.gip_anpg_loss_f16.argtypes = [_vp, _i64p, _vp, _i64p, _vp, _vp] + [ctypes.c_int32] * 4 + [ctypes.c_float, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp]
+        lib.gip_scale_cast_f16.restype = ctypes.c_int
+        lib.gip_scale_cast_f16.argtypes = [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, _vp]
         _nn = _Counted(lib)
     return _nn
 

@@ -25,6 +25,10 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef AT_PK_FMA
+#define AT_PK_FMA 0
+#endif
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -37,6 +41,25 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 template <int ROWB> __device__ __forceinline__ int kswz(int row) { return ROWB == 128 ? ((row >> 1) & 7) : (row & 15); }
 template <int ROWB> __device__ __forceinline__ int vswz(int row) { return ROWB == 128 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
 #define AT_DEFER 8.0f
+#ifndef AT_OPT
+#define AT_OPT 0
+#endif
+#ifndef AT_NW8_WAVES
+#define AT_NW8_WAVES 2
+#endif
+#ifndef AT_DIAG
+#define AT_DIAG 0      // timing diagnostics only (wrong results): 1 = no exp2, 2 = no PV MFMAs, 4 = no S^T MFMAs
+#endif
+// max over the two lane halves without the LDS round trip of ds_bpermute (v_permlane32_swap: a = [a_lo | b_lo], b = [a_hi | b_hi])
+__device__ __forceinline__ float at_half_max(float v) {
+#if AT_OPT & 1
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+#else
+  return fmaxf(v, __shfl_xor(v, 32));
+#endif
+}
 
 union Frag8 {
   f16x8 v;
@@ -48,11 +71,12 @@ union Frag8 {
 // product of tile 0 before those of tile 1).  The S^T MFMAs of both tiles are still issued first; tile 0's maximum / exp2 then
 // depend on its own three MFMAs only, so they run while tile 1's are in the matrix pipe, and tile 1's vector work runs under
 // tile 0's PV MFMAs — the block-wide maximum made every exp2 wait for all six.  Same arithmetic per key (one more raise test).
-template <int D, bool TWO, bool SPLIT>
-__global__ void __launch_bounds__(256, D > 128 ? 1 : 2)
+template <int D, bool TWO, bool SPLIT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, D > 128 ? 1 : (NW == 8 && D <= 64 ? AT_NW8_WAVES : 2))   // (threads, waves per SIMD)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
-                const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
+                const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q,
+                int xcd_remap = 0) {
   // ld_kv / ld_kv2: elements between consecutive key rows of (k, v) / (k2, v2).  H * D for packed projections; larger
   // when a layer's keys are a column range of one wide matrix holding the key / value projections of MANY layers
   static_assert(D % 8 == 0 && D <= 160, "head dim");
@@ -64,16 +88,28 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   constexpr int NS = (D + 15) / 16;      // k-steps of the S^T product
   constexpr int ND = (D + 31) / 32;      // 32-row tiles of O^T
   constexpr int CH = D / 8;              // 16-byte chunks per row
-  constexpr int PER = (AT_BKV * CH + 255) / 256;
+  constexpr int NT = 64 * NW;            // threads: NW waves of 32 queries share the K / V stages (the stream from L2 per query ~ 1 / NW)
+  constexpr int PER = (AT_BKV * CH + NT - 1) / NT;
   // D < 64 leaves unused rows in the last O^T tile: row D of V^T is set to ONES, so that O^T[D][q] = sum_k p[k][q] — the
   // softmax denominator comes out of the PV matrix product and the 32 scalar adds per block disappear (VALU-bound kernel)
   constexpr bool L_FROM_MFMA = (D % 32) != 0;
   constexpr int L_TILE = D / 32, L_ROW = D % 32;          // position of that row in the O^T tiles
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 2 * AT_TILE];   // [stage][K | V]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y / H, h = blockIdx.y - b * H;
+  // workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest): with xcd_remap every (batch, head)'s query
+  // blocks land on ONE XCD, so its keys / values are filled into one L2 instead of eight (speed only)
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_remap) {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    if ((total & 7) == 0) {
+      const int lin = by * gx + bx, nl = (lin & 7) * (total >> 3) + (lin >> 3);
+      by = nl / gx;
+      bx = nl - by * gx;
+    }
+  }
+  const int b = by / H, h = by - b * H;
   const int C = H * D;
-  const int q0 = blockIdx.x * AT_BQ + wave * 32;
+  const int q0 = bx * (32 * NW) + wave * 32;
   const bool q_valid = q0 < Nq;          // Nq % 32 == 0: a wave's 32 query rows exist or not as a whole (the 8x8 level has 64)
 
   // Q^T fragments (B operand): lane = query column, element j = feature 16 s + 8 hh + j; zero beyond D
@@ -90,7 +126,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     }
   }
   // the padding columns of the images must be finite zeros (0 * garbage would poison S^T): clear everything once
-  for (int i = tid * 16; i < 2 * 2 * AT_TILE; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
+  for (int i = tid * 16; i < 2 * 2 * AT_TILE; i += NT * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
   if constexpr (L_FROM_MFMA) {
     __syncthreads();
     // feature D of every V row (both stages) = 1.0; the staging only ever rewrites chunks < D / 8
@@ -104,12 +140,12 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   // staging descriptors: every thread moves two chunks of K and of V per block; the tail indices wrap around (a few
   // chunks are moved twice with identical data) so that no load or LDS store is predicated; rows past the end of a
   // ragged key set are clamped to its last row (they are masked to -inf before the softmax)
-  static_assert(PER >= 2 && PER <= 5, "staging chunks per thread");
+  static_assert(PER >= 1 && PER <= 5 && NT * PER < 3 * AT_BKV * CH, "staging chunks per thread (two wrap-arounds at most)");
   // one set of NAMED scalars per staged chunk (e = 0 .. PER - 1), enumerated by macros under `if constexpr`: arrays (even
   // with fully unrolled loops, even inside inlined lambdas) were placed in scratch memory by hipcc, which made the D = 40
   // kernel 2x slower
 #define AT_SLOT(e)                                                                                        \
-  int idx##e = tid + 256 * e;                                                                             \
+  int idx##e = tid + NT * e;                                                                              \
   if (idx##e >= AT_BKV * CH) idx##e -= AT_BKV * CH;                                                       \
   if (idx##e >= AT_BKV * CH) idx##e -= AT_BKV * CH;                                                       \
   const int row##e = idx##e / CH, ch##e = idx##e - row##e * CH;                                           \
@@ -173,6 +209,23 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 
       // ---- S^T = K Q^T for the two 32-key tiles ----
       f32x16 S[2];
+#if AT_OPT & 4
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#if AT_OPT & 2
+      // the two tiles' accumulation chains interleaved: a dependent MFMA never follows its predecessor directly
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) S[t][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
+          S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+        }
+#else
 #pragma unroll
       for (int t = 0; t < 2; t++) {
 #pragma unroll
@@ -180,9 +233,17 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
         for (int s = 0; s < NS; s++) {
           const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
+#if AT_DIAG & 4
+          S[t][s] += (float)a[0] * (float)qf[s][1];
+#else
           S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+#endif
         }
       }
+#endif
+#if AT_OPT & 4
+      __builtin_amdgcn_s_setprio(0);
+#endif
 
       // ---- V^T fragments: issued now, they land while the softmax runs ----
       const unsigned char* sv = sk + AT_TILE;
@@ -255,7 +316,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
       for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, S[t][i]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      mloc = at_half_max(mloc);
       const bool raise = (mloc - m_run) * c > AT_DEFER;     // true on the first block (m_run = -inf)
       if (__any(raise)) {
         const float m_new = fmaxf(m_run, mloc);
@@ -274,10 +335,20 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
-            if constexpr (!L_FROM_MFMA) l_run += p;
-            P[t][s2].v[j] = (_Float16)p;
+          for (int j = 0; j < 8; j += 2) {
+#if AT_DIAG & 1
+            const float p0 = __builtin_fmaf(S[t][8 * s2 + j], c, -mc), p1 = __builtin_fmaf(S[t][8 * s2 + j + 1], c, -mc);
+#elif AT_PK_FMA
+            // the exponent arguments two at a time (v_pk_fma_f32: the accumulator registers are consecutive pairs)
+            const v2f e = __builtin_elementwise_fma((v2f){S[t][8 * s2 + j], S[t][8 * s2 + j + 1]}, (v2f){c, c}, (v2f){-mc, -mc});
+            const float p0 = __builtin_amdgcn_exp2f(e.x), p1 = __builtin_amdgcn_exp2f(e.y);
+#else
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j + 1], c, -mc));
+#endif
+            if constexpr (!L_FROM_MFMA) l_run += p0 + p1;
+            P[t][s2].v[j] = (_Float16)p0;
+            P[t][s2].v[j + 1] = (_Float16)p1;
           }
 
       // ---- O^T += V^T P^T ----
@@ -287,7 +358,11 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
         for (int t = 0; t < 2; t++)
 #pragma unroll
           for (int s2 = 0; s2 < 2; s2++)
+#if AT_DIAG & 2
+            O[dt][(t * 2 + s2) & 15] += (float)vt[dt][t][s2].v[0] * (float)P[t][s2].v[1];
+#else
             O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
+#endif
       }
 
       if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
@@ -345,6 +420,19 @@ static void launch_attn2(dim3 grid, hipStream_t s, const void* q, const void* k,
                        (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv, ld_kv, ld_q);
 }
 
+// long self-attention (one key set): NW waves of 32 queries per workgroup share the K / V stages
+template <int D, int NW>
+static void launch_attn_wide(hipStream_t s, const void* q, const void* k, const void* v, void* o, int BH, int Nq, int Nkv, int H, float c,
+                             int ld_kv, int ld_q) {
+  const dim3 grid((Nq + 32 * NW - 1) / (32 * NW), BH);
+  // every (batch, head)'s query blocks on ONE XCD (its keys / values fill one L2 instead of eight): 0.421 -> 0.4105 ms at batch 12,
+  // 0.140 -> 0.137 at batch 4, same box, two alternating runs; GIP_ATTN_XCD=0 switches it off
+  static const int xcd = [] { const char* e = getenv("GIP_ATTN_XCD"); return e && *e ? atoi(e) : 1; }();
+  hipLaunchKernelGGL((attn_fwd_kernel<D, false, false, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)q, (const _Float16*)k,
+                     (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv,
+                     ld_kv, ld_q, xcd);
+}
+
 template <int D>
 static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
                         float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
@@ -364,6 +452,17 @@ extern "C" int gip_attention_fwd_strided2_f16(const void* q, const void* k, cons
   const float c = scale * 1.4426950408889634f;
   const dim3 grid((Nq + AT_BQ - 1) / AT_BQ, B * H);
   hipStream_t s = (hipStream_t)stream;
+  // GIP_ATTN_NW (6 / 8; default 4): waves per workgroup of the long self-attention layers (D = 40 / 80, >= 1024 keys); A/B switch
+  // long D = 40 self-attention (the 64 x 64 level: 4096 keys): 8 waves per workgroup share the K / V stages.  The plain loop
+  // streams every (batch, head)'s keys / values from L2 once per 128 queries — 2 GB per launch at batch 12, and a build without
+  // any MFMA or exp2 still takes 2/3 of the time (tools/experiments/attention_pipelined_qk.md, round 4) — 256 queries per workgroup
+  // halve that stream: 0.44 -> 0.41 ms at batch 12, 0.155 -> 0.138 at batch 4 (one workgroup per CU, so only where >= 512
+  // workgroups remain; D = 80 at 1024 keys measured slower).  GIP_ATTN_NW = 4: the plain loop everywhere (A/B), 8: wherever supported
+  static const int nw = [] { const char* e = getenv("GIP_ATTN_NW"); return e && *e ? atoi(e) : 0; }();
+  if (!k2 && D == 40 && Nkv >= 1024 && Nq % 256 == 0 && nw != 4 && (nw == 8 || (Nq / 256) * B * H >= 512)) {
+    launch_attn_wide<40, 8>(s, q, k, v, o, B * H, Nq, Nkv, H, c, ld_kv, ld_q);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
   switch (D) {
     case 40: launch_attn<40>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2, ld_q); break;
     case 64: launch_attn<64>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, weight2, ld_kv, ld_kv2, ld_q); break;

@@ -261,3 +261,187 @@ extern "C" int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, doubl
   hipLaunchKernelGGL(gip_adam_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, found_inf);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+
+// ---- the sparsity term of the stage-1 loss: mean(sqrt((depth / (max(depth) + 1e-5))^2 + 0.01))  (GaussianIP.py:225, :377-380) -------
+// The reference spells it as max -> add -> div -> pow -> add -> sqrt -> mean on the [B, H, W, 1] depth maps (4 M elements at the
+// training shape): seven forward and about twice as many backward launches of 6-20 us each.  Here: two launches forward, two backward,
+// fixed summation orders (bitwise reproducible).  `ws` (workspace, float32, ZERO before its first use): [0] max, [1] loss, [2] count
+// of maxima, [3] the gradient each maximum receives, [4, 4 + 2 * SP_BLOCKS) per-workgroup partials, then one uint32 ticket counter
+// (the workgroup that draws the last ticket adds the partials up in index order and resets the counter).
+#define SP_BLOCKS 1024
+#define SP_THREADS 256
+
+__device__ __forceinline__ float sp_block_reduce(float v, bool is_max, float* s_red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float o = __shfl_xor(v, d, 64);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = s_red[0];
+  for (int i = 1; i < SP_THREADS / 64; i++) t = is_max ? fmaxf(t, s_red[i]) : t + s_red[i];
+  return t;
+}
+
+// the workgroup that takes the last ticket sees every other workgroup's partial (release / acquire through the ticket counter)
+__device__ __forceinline__ bool sp_last_block(unsigned int* ticket) {
+  __shared__ bool s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, 1u);
+    s_last = t == gridDim.x - 1;
+    if (s_last) *ticket = 0;
+  }
+  __syncthreads();
+  __threadfence();
+  return s_last;
+}
+
+__global__ void __launch_bounds__(SP_THREADS) sp_max_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ ws) {
+  __shared__ float s_red[SP_THREADS / 64];
+  float m = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) m = fmaxf(m, d[i]);
+  m = sp_block_reduce(m, true, s_red);
+  if (threadIdx.x == 0) ws[4 + blockIdx.x] = m;
+  if (!sp_last_block((unsigned int*)(ws + 4 + 2 * SP_BLOCKS))) return;
+  float t = -INFINITY;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += SP_THREADS) t = fmaxf(t, ws[4 + i]);
+  t = sp_block_reduce(t, true, s_red);
+  if (threadIdx.x == 0) ws[0] = t;
+}
+
+__global__ void __launch_bounds__(SP_THREADS) sp_loss_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ ws) {
+  __shared__ float s_red[SP_THREADS / 64];
+  const float dmax = ws[0], den = dmax + 1e-5f;
+  float sum = 0.f, cnt = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+    const float x = d[i], o = x / den;
+    sum += sqrtf(o * o + 0.01f);
+    cnt += x == dmax ? 1.f : 0.f;
+  }
+  sum = sp_block_reduce(sum, false, s_red);
+  cnt = sp_block_reduce(cnt, false, s_red);
+  float* part = ws + 4;
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sum; part[2 * blockIdx.x + 1] = cnt; }
+  if (!sp_last_block((unsigned int*)(ws + 4 + 2 * SP_BLOCKS))) return;
+  float a = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += SP_THREADS) {
+    a += part[2 * i];
+    c += part[2 * i + 1];
+  }
+  a = sp_block_reduce(a, false, s_red);
+  c = sp_block_reduce(c, false, s_red);
+  if (threadIdx.x == 0) { ws[1] = a / (float)n; ws[2] = c; }
+}
+
+// pass 1 of the backward: g_d[i] = (g / n) (o / sqrt(o^2 + 0.01)) / den, and the gradient that reaches the maximum through the
+// denominator, -sum_i (g / n) (o_i / v_i) o_i / den, shared evenly by the elements that equal it (torch.max()'s backward)
+__global__ void __launch_bounds__(SP_THREADS) sp_bwd_kernel(const float* __restrict__ d, int64_t n, const float* __restrict__ g_loss,
+                                                              float mult, float* __restrict__ ws, float* __restrict__ g_d) {
+  __shared__ float s_red[SP_THREADS / 64];
+  const float dmax = ws[0], den = dmax + 1e-5f, gn = g_loss[0] * mult / (float)n;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+    const float o = d[i] / den;
+    const float go = gn * (o / sqrtf(o * o + 0.01f));          // d loss / d opacity_i
+    g_d[i] = go / den;
+    acc += go * o;
+  }
+  acc = sp_block_reduce(acc, false, s_red);
+  float* part = ws + 4;
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  if (!sp_last_block((unsigned int*)(ws + 4 + 2 * SP_BLOCKS))) return;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += SP_THREADS) a += part[i];
+  a = sp_block_reduce(a, false, s_red);
+  if (threadIdx.x == 0) ws[3] = -(a / den) / ws[2];
+}
+
+__global__ void __launch_bounds__(SP_THREADS) sp_bwd_max_kernel(const float* __restrict__ d, int64_t n, const float* __restrict__ ws,
+                                                                  float* __restrict__ g_d) {
+  const float dmax = ws[0], add = ws[3];
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS)
+    if (d[i] == dmax) g_d[i] += add;
+}
+
+extern "C" size_t gip_sparsity_workspace_bytes(void) { return (4 + 2 * SP_BLOCKS + 4) * sizeof(float); }
+
+extern "C" int gip_sparsity_loss_forward(const float* depth, int64_t n, void* workspace, void* stream) {
+  if (!depth || !workspace || n < 1) return 1;
+  const int blocks = (int)((n + SP_THREADS - 1) / SP_THREADS < SP_BLOCKS ? (n + SP_THREADS - 1) / SP_THREADS : SP_BLOCKS);
+  float* ws = (float*)workspace;
+  hipLaunchKernelGGL(sp_max_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, ws);
+  hipLaunchKernelGGL(sp_loss_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, ws);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_sparsity_loss_backward(const float* depth, int64_t n, const float* g_loss, float mult, void* workspace, float* g_depth,
+                                          void* stream) {
+  if (!depth || !workspace || !g_loss || !g_depth || n < 1) return 1;
+  const int blocks = (int)((n + SP_THREADS - 1) / SP_THREADS < SP_BLOCKS ? (n + SP_THREADS - 1) / SP_THREADS : SP_BLOCKS);
+  float* ws = (float*)workspace;
+  hipLaunchKernelGGL(sp_bwd_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, g_loss, mult, ws, g_depth);
+  hipLaunchKernelGGL(sp_bwd_max_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, ws, g_depth);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+
+// ---- the three parameter activations of GaussianModel (gaussian_model.py:36-41, getters :72-89) in one launch each way ---------------
+// opacity = sigmoid(o), scaling = exp(s), rotation = q / max(||q||, 1e-12): three op chains forward (sigmoid; exp; norm, clamp,
+// div) and about a dozen launches backward in the reference's spelling; one thread per Gaussian here.
+__global__ void activate_kernel(const float* __restrict__ o, const float* __restrict__ sc, const float* __restrict__ q, int64_t P,
+                                float* __restrict__ oo, float* __restrict__ so, float* __restrict__ qo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  oo[i] = 1.f / (1.f + expf(-o[i]));
+#pragma unroll
+  for (int k = 0; k < 3; k++) so[3 * i + k] = expf(sc[3 * i + k]);
+  const float4 v = *(const float4*)(q + 4 * i);
+  const float n = sqrtf(((v.x * v.x + v.y * v.y) + v.z * v.z) + v.w * v.w), den = fmaxf(n, 1e-12f);
+  *(float4*)(qo + 4 * i) = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
+}
+
+__global__ void activate_bwd_kernel(const float* __restrict__ oo, const float* __restrict__ so, const float* __restrict__ q,
+                                    const float* __restrict__ g_o, const float* __restrict__ g_s, const float* __restrict__ g_q, int64_t P,
+                                    float* __restrict__ d_o, float* __restrict__ d_s, float* __restrict__ d_q) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  if (d_o) { const float y = oo[i]; d_o[i] = g_o ? (g_o[i] * (1.f - y)) * y : 0.f; }                       // sigmoid_backward
+  if (d_s) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) d_s[3 * i + k] = g_s ? g_s[3 * i + k] * so[3 * i + k] : 0.f;              // exp: grad * result
+  }
+  if (d_q) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_q) {
+      const float4 v = *(const float4*)(q + 4 * i), g = *(const float4*)(g_q + 4 * i);
+      const float n = sqrtf(((v.x * v.x + v.y * v.y) + v.z * v.z) + v.w * v.w), den = fmaxf(n, 1e-12f);
+      // y = v / den: d v = g / den + [n >= eps] * (-(g . v) / den^2) * v / n   (div, clamp_min and norm backward in autograd's order)
+      const float gden = -(((g.x * v.x + g.y * v.y) + g.z * v.z) + g.w * v.w) / (den * den);
+      const float k = n >= 1e-12f && n > 0.f ? gden / n : 0.f;
+      r = make_float4(g.x / den + k * v.x, g.y / den + k * v.y, g.z / den + k * v.z, g.w / den + k * v.w);
+    }
+    *(float4*)(d_q + 4 * i) = r;
+  }
+}
+
+extern "C" int gip_activate_gaussians(const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int64_t P,
+                                      float* opacity, float* scaling, float* rotation, void* stream) {
+  if (!opacity_raw || !scaling_raw || !rotation_raw || !opacity || !scaling || !rotation || P < 1) return 1;
+  hipLaunchKernelGGL(activate_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, opacity_raw, scaling_raw,
+                     rotation_raw, P, opacity, scaling, rotation);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_activate_gaussians_backward(const float* opacity, const float* scaling, const float* rotation_raw, const float* g_opacity,
+                                               const float* g_scaling, const float* g_rotation, int64_t P, float* d_opacity_raw,
+                                               float* d_scaling_raw, float* d_rotation_raw, void* stream) {
+  if (!opacity || !scaling || !rotation_raw || P < 1) return 1;
+  hipLaunchKernelGGL(activate_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, opacity, scaling,
+                     rotation_raw, g_opacity, g_scaling, g_rotation, P, d_opacity_raw, d_scaling_raw, d_rotation_raw);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}

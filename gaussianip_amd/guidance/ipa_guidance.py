@@ -16,7 +16,7 @@ from typing import Any, Callable, Optional
 import torch
 import torch.nn.functional as F
 
-from . import fused, sds
+from . import fused, glue, sds
 from .ahds import AHDSSchedule
 from .networks import IP_TOKENS, TEXT_TOKENS, ControlNet, UNet, VAEEncoder, init_for_benchmark
 
@@ -318,10 +318,17 @@ class StableDiffusionGuidance:
                 return self._encode_graphed(x, generator).to(imgs.dtype)
             return self.vae.encode(x, generator).to(imgs.dtype)
 
+    def _moments(self, x):
+        """The VAE encoder's (mean | logvar) of an already prepared image (half, channels-last, in [-1, 1])."""
+        with torch.autocast("cuda", enabled=False):
+            if _GRAPH_VAE and x.requires_grad and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+                return self._encode_graphed(x, None, moments_only=True)
+            return self.vae.moments(x)
+
     _vae_graphs = None
     _vae_live = None
 
-    def _encode_graphed(self, x, generator):
+    def _encode_graphed(self, x, generator, moments_only=False):
         """The differentiable VAE encoder (fixed shape, frozen weights: ~350 launches forward, ~400 backward) as two HIP-graph
         launches: torch.cuda.make_graphed_callables captures `moments` and its backward; the stochastic part of
         latent_dist.sample() (ipa_guidance.py:522-531) stays outside the graph.  First call of a shape runs eagerly (lazy
@@ -332,7 +339,7 @@ class StableDiffusionGuidance:
         ent = self._vae_graphs.get(key)
         if ent is None:
             self._vae_graphs[key] = "warm"
-            return self.vae.encode(x, generator)
+            return self.vae.moments(x) if moments_only else self.vae.encode(x, generator)
         if ent == "warm":
             sample = torch.zeros_like(x, memory_format=torch.channels_last).requires_grad_(True)
             ent = self._vae_graphs[key] = torch.cuda.make_graphed_callables(lambda t_: self.vae.moments(t_), (sample,), num_warmup_iters=2)
@@ -343,13 +350,13 @@ class StableDiffusionGuidance:
             self._vae_live = {}
         live = self._vae_live.get(key)
         if live is not None and live[0]() is not None and not live[1][0]:
-            return self.vae.encode(x, generator)
+            return self.vae.moments(x) if moments_only else self.vae.encode(x, generator)
         import weakref
         moments = ent(x)
         done = [False]
         moments.register_hook(lambda g_, d_=done: d_.__setitem__(0, True))
         self._vae_live[key] = (weakref.ref(moments), done)
-        return self.vae.sample(moments, generator)
+        return moments if moments_only else self.vae.sample(moments, generator)
 
     # ------------------------------------------------------------------ gradients
     def _prompt_embeds(self, prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, n_sets):
@@ -364,6 +371,33 @@ class StableDiffusionGuidance:
             return torch.cat([neg, pos], dim=0)                    # ipa_guidance.py:470
         null = torch.cat([null_t, ex(self.null_image_embeds)], dim=1)
         return torch.cat([neg, pos, null], dim=0)
+
+    _embed_table = None
+
+    def _prompt_embeds_anpg_table(self, prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances):
+        """`_prompt_embeds(..., 3)` as ONE gather: the 13 view directions x (neg | pos | null) rows, image-prompt tokens
+        appended, are laid out once as a [3 * 13, 81, 768] table (rebuilt when the prompt tables or the image embeddings
+        change); a step selects row set * 13 + direction(view).  Same values (a gather instead of gather + four concatenations)."""
+        from .prompts import direction_index
+        if not hasattr(prompt_utils, "text_embeddings_vd"):
+            return None
+        srcs = (prompt_utils.text_embeddings_vd, prompt_utils.uncond_text_embeddings_vd, prompt_utils.null_embeddings,
+                self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds)
+        if not self.cfg.view_dependent_prompting or any(e.shape[0] != 1 for e in srcs[2:]):
+            return None
+        key = tuple((id(e), e._version, e.data_ptr()) for e in srcs) + (self.weights_dtype,)
+        if self._embed_table is None or self._embed_table[0] != key:
+            dt, dev = self.weights_dtype, self.device
+            vd, un, nl, pos, neg, nul = (e.to(device=dev, dtype=dt) for e in srcs)
+            D = vd.shape[0]
+            rows = torch.cat([torch.cat([un, neg.expand(D, -1, -1)], dim=1),            # neg  (ipa_guidance.py:470 order)
+                              torch.cat([vd, pos.expand(D, -1, -1)], dim=1),            # pos
+                              torch.cat([nl.expand(D, -1, -1), nul.expand(D, -1, -1)], dim=1)], dim=0).contiguous()
+            self._embed_table = (key, rows, D, srcs)
+        _, rows, D, _ = self._embed_table
+        idx = direction_index(elevation, azimuth, center, all_vis_all, camera_distances, prompt_utils.head_offset)
+        flat = torch.cat([idx, idx + D, idx + 2 * D]).to(rows.device, non_blocking=True)       # host-side batch: host arithmetic
+        return rows.index_select(0, flat)
 
     def compute_grad_anpg(self, latents, control_img, t, prompt_utils, use_pose_controlnet, all_vis_all, elevation,
                           azimuth, center, camera_distances, generator=None, control_embedding=None):
@@ -399,13 +433,49 @@ class StableDiffusionGuidance:
         grad = sds.sds_weight(t, self.alphas, self.cfg.weighting_strategy) * direction
         return grad, {"t_orig": t, "latents_noisy": latents_noisy, "noise_pred": noise_pred}
 
+    # ------------------------------------------------------------------ the plugin call, glue fused (guidance/glue.py)
+    def _fused_call_ok(self, rgb, use_pose_controlnet):
+        """The fp16 CUDA ANPG training path: every element-wise chain between the rasterizer and the networks is one launch."""
+        return (glue.ENABLED and self.cfg.use_anpg and rgb.is_cuda and self.weights_dtype == torch.float16 and self.cfg.channels_last and
+                self.cfg.weighting_strategy in ("sds", "fantasia3d") and glue.image_prep_supported(rgb.permute(0, 3, 1, 2), (512, 512)) and
+                not (use_pose_controlnet and _TWO_STREAMS and not _GRAPH_DENOISE))
+
+    def _call_fused(self, step, rgb, control, prompt_utils, use_pose_controlnet, all_vis_all, elevation, azimuth, center,
+                    camera_distances, generator):
+        """Same values as the op-chain path below (same random draws in the same order: the VAE's sample noise, the timesteps,
+        the diffusion noise), with the chains of ipa_guidance.py:612-614 / :524-531 / :395-431 / :645-653 as four launches."""
+        B = rgb.shape[0]
+        x = glue.image_prep(rgb.permute(0, 3, 1, 2), (512, 512))
+        moments = self._moments(x)
+        lat_shape = (moments.shape[1] // 2,) + tuple(moments.shape[2:])
+        draw = lambda k, g: torch.randn((k,) + lat_shape, device=moments.device, dtype=moments.dtype, generator=g)  # noqa: E731
+        eps = sds.per_sample(draw, B, generator)                     # VAEEncoder.sample's draw
+        t = self.schedule.sample(step, B, self.device, generator)
+        noise = sds.per_sample(draw, B, generator)                   # compute_grad_anpg's draw
+        if not glue.latent_sample_supported(moments, eps, noise, t, self.alphas):
+            raise RuntimeError("fused guidance glue: unsupported tensors (set GIP_FUSED_GLUE=0 for the op-chain path)")
+        latents, latents_noisy = glue.latent_sample(moments, eps, noise, t, self.alphas, self.vae.scaling_factor, 3)
+        embeds = self._prompt_embeds_anpg_table(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances)
+        if embeds is None:
+            embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 3)
+        assert embeds.shape[1] == TEXT_TOKENS + IP_TOKENS
+        with torch.no_grad():
+            noise_pred = self.forward_unet(latents_noisy, control, t.repeat(3), embeds, use_pose_controlnet, replicas=3)
+        clip = self.cfg.grad_clip_threshold if self.cfg.grad_clip_pixel else None
+        loss_sds, grad, grad_norm = glue.anpg_loss(latents, noise_pred, t, self.alphas, self.cfg.guidance_scale,
+                                                   self.cfg.weighting_strategy, clip)
+        return {"loss_sds": loss_sds, "grad_norm": grad_norm}
+
     # ------------------------------------------------------------------ the plugin call
     def __call__(self, step, rgb, control_img, prompt_utils, use_pose_controlnet, all_vis_all, elevation, azimuth,
                  center, camera_distances, generator=None, **kwargs: Any):
         """rgb [B,H,W,3], control_img [B,h,w,3] -> {"loss_sds", "grad_norm"}."""
         B = rgb.shape[0]
-        rgb_512 = F.interpolate(rgb.permute(0, 3, 1, 2), (512, 512), mode="bilinear", align_corners=False)
         control = control_img.permute(0, 3, 1, 2)
+        if self._fused_call_ok(rgb, use_pose_controlnet):
+            return self._call_fused(step, rgb, control, prompt_utils, use_pose_controlnet, all_vis_all, elevation, azimuth, center,
+                                    camera_distances, generator)
+        rgb_512 = F.interpolate(rgb.permute(0, 3, 1, 2), (512, 512), mode="bilinear", align_corners=False)
         hint = None
         if use_pose_controlnet and control.is_cuda and _TWO_STREAMS and not _GRAPH_DENOISE:
             # the ControlNet's hint stem depends on the pose maps only: it runs on the side stream beside the VAE encoder

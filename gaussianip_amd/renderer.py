@@ -27,11 +27,16 @@ def _settings(cam, pc, bg_color, scaling_modifier):
         sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
 
 
-def _select_inputs(cam, pc, pipe, scaling_modifier, override_color):
-    """(scales, rotations, cov3D_precomp, shs, colors_precomp) following the reference's switches (:57-80)."""
+def _select_inputs(cam, pc, pipe, scaling_modifier, override_color, activated=False):
+    """(scales, rotations, cov3D_precomp, shs, colors_precomp) following the reference's switches (:57-80).
+    `activated`: the caller also needs the opacity and takes all three activations from one launch (GaussianModel.get_activated),
+    left in pc._act_cache."""
     scales = rotations = cov3D = shs = colors = None
     if pipe.compute_cov3D_python:
         cov3D = pc.get_covariance(scaling_modifier)
+    elif activated and hasattr(pc, "get_activated"):
+        pc._act_cache = pc.get_activated()
+        _, scales, rotations = pc._act_cache
     else:
         scales, rotations = pc.get_scaling, pc.get_rotation
     if override_color is not None:
@@ -108,10 +113,12 @@ def render_views(cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
         pass
     if pipe.convert_SHs_python and override_color is None:
         raise ValueError("render_views: convert_SHs_python colours are view dependent; use render() per camera")
-    scales, rotations, cov3D, shs, colors = _select_inputs(cameras[0], pc, pipe, scaling_modifier, override_color)
+    scales, rotations, cov3D, shs, colors = _select_inputs(cameras[0], pc, pipe, scaling_modifier, override_color, activated=True)
+    act = pc.__dict__.pop("_act_cache", None)
+    opacity = act[0] if act is not None else pc.get_opacity
     sts = [_settings(c, pc, bg_color, scaling_modifier) for c in cameras]
     image, radii, depth, alpha = rasterize_views(
-        xyz.float(), screenspace_points.float(), pc.get_opacity.float(), sts, shs=_f(shs), colors_precomp=colors,
+        xyz.float(), screenspace_points.float(), opacity.float(), sts, shs=_f(shs), colors_precomp=colors,
         scales=_f(scales), rotations=_f(rotations), cov3D_precomp=cov3D)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "depth_3dgs": depth, "alpha_3dgs": alpha}

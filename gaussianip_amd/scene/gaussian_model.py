@@ -31,7 +31,57 @@ def _covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
     return strip_symmetric(L @ L.transpose(1, 2))
 
 
+_FUSED_ACT = os.environ.get("GIP_FUSED_ACTIVATIONS", "1") != "0"     # 0: the three getters' op chains (same-box A/B)
+
+
+class _Activate(torch.autograd.Function):
+    """(sigmoid(opacity), exp(scaling), normalize(rotation)) in one launch, their backward in one (include/gip_model.h:
+    gip_activate_gaussians*): the values of the getters :72-89, which stay what every other caller uses."""
+
+    @staticmethod
+    def forward(ctx, o, s, q):
+        import ctypes
+
+        from .. import _lib
+        oo, so, qo = torch.empty_like(o), torch.empty_like(s), torch.empty_like(q)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        rc = _lib.model_lib().gip_activate_gaussians(p(o), p(s), p(q), o.shape[0], p(oo), p(so), p(qo),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(o.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_activate_gaussians failed with status %d" % rc)
+        ctx.save_for_backward(oo, so, q)
+        return oo, so, qo
+
+    @staticmethod
+    def backward(ctx, go, gs, gq):
+        import ctypes
+
+        from .. import _lib
+        oo, so, q = ctx.saved_tensors
+        p = lambda t: ctypes.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+        go, gs, gq = (None if g_ is None else g_.contiguous() for g_ in (go, gs, gq))
+        need = ctx.needs_input_grad
+        d_o = torch.empty_like(oo) if need[0] else None
+        d_s = torch.empty_like(so) if need[1] else None
+        d_q = torch.empty_like(q) if need[2] else None
+        rc = _lib.model_lib().gip_activate_gaussians_backward(p(oo), p(so), p(q), p(go), p(gs), p(gq), oo.shape[0], p(d_o), p(d_s), p(d_q),
+                                                              ctypes.c_void_p(torch.cuda.current_stream(oo.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_activate_gaussians_backward failed with status %d" % rc)
+        return d_o, d_s, d_q
+
+
 class GaussianModel:
+    def get_activated(self):
+        """(get_opacity, get_scaling, get_rotation) of one step — on the GPU with the stock activations one launch forward and
+        one backward instead of the three getters' op chains."""
+        o, s, q = self._opacity, self._scaling, self._rotation
+        if (_FUSED_ACT and o.is_cuda and self.opacity_activation is torch.sigmoid and self.scaling_activation is torch.exp and
+                self.rotation_activation is torch.nn.functional.normalize and
+                all(t.dtype == torch.float32 and t.is_contiguous() for t in (o, s, q)) and o.shape[0] > 0):
+            return _Activate.apply(o, s, q)
+        return self.get_opacity, self.get_scaling, self.get_rotation
+
     def setup_functions(self):
         self.scaling_activation = torch.exp
         self.scaling_inverse_activation = torch.log

@@ -9,6 +9,9 @@ caller's (out of scope): pose maps and prompt embeddings are inputs here.
 One behavioural difference, by design: the cameras of a step are rendered in ONE launch set (`render_views`) instead
 of sequentially; per-view results are identical (tests/test_gpu_pipeline.py).
 """
+import contextlib
+import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -16,6 +19,57 @@ import torch
 
 from .renderer import render_views
 from .scene.cameras import Camera
+
+_POSE_STREAM = os.environ.get("GIP_POSE_STREAM", "1") != "0"      # 0: pose maps on the main stream (same-box A/B)
+_FUSED_LOSS = os.environ.get("GIP_FUSED_LOSS", "1") != "0"        # 0: the sparsity term as the reference's op chain (same-box A/B)
+_sparsity_ws = {}
+
+
+class _SparsityTerm(torch.autograd.Function):
+    """mean(sqrt((depth / (max(depth) + 1e-5))^2 + 0.01)) of a step's depth maps (GaussianIP.py:225, :377-380) in two launches
+    forward and two backward (include/gip_model.h: gip_sparsity_loss_*); the op chain it replaces is ~20 launches on 4 M
+    elements.  One workspace per device: forward and backward of a step pair up (the step's loss is consumed before the next
+    forward runs)."""
+
+    @staticmethod
+    def forward(ctx, depth):
+        from . import _lib
+        lib = _lib.model_lib()
+        ws = _sparsity_ws.get(depth.device)
+        if ws is None:
+            ws = _sparsity_ws[depth.device] = torch.zeros(lib.gip_sparsity_workspace_bytes() // 4, dtype=torch.float32, device=depth.device)
+        rc = lib.gip_sparsity_loss_forward(ctypes.c_void_p(depth.data_ptr()), depth.numel(), ctypes.c_void_p(ws.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream(depth.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_sparsity_loss_forward failed with status %d" % rc)
+        ctx.save_for_backward(depth)
+        ctx.ws = ws
+        return ws[1].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        depth, = ctx.saved_tensors
+        g_depth = torch.empty_like(depth)
+        g = g.to(torch.float32).reshape(1)
+        rc = _lib.model_lib().gip_sparsity_loss_backward(
+            ctypes.c_void_p(depth.data_ptr()), depth.numel(), ctypes.c_void_p(g.data_ptr()), 1.0, ctypes.c_void_p(ctx.ws.data_ptr()),
+            ctypes.c_void_p(g_depth.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(depth.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_sparsity_loss_backward failed with status %d" % rc)
+        return g_depth
+
+
+class _StepOutputs(dict):
+    """forward()'s dict; "opacity" = depth / (max + 1e-5) (GaussianIP.py:225-226) is made when somebody reads it: the fused
+    sparsity term works on the depth maps directly and the [B, H, W, 1] quotient is otherwise a dead 16 MB tensor per step."""
+
+    def __missing__(self, key):
+        if key == "opacity" and "_dmax" in self:
+            v = self["depth"] / (dict.__getitem__(self, "_dmax")() + 1e-5)
+            self[key] = v
+            return v
+        raise KeyError(key)
 
 
 @dataclass
@@ -116,6 +170,7 @@ class StageOneStep:
         ids = list(range(B)) if self.sharding is None else list(self.sharding.views)
         cams: List[Camera] = [Camera(c2w=batch["c2w"][i], FoVy=batch["fovy"][i], height=batch["height"], width=batch["width"])
                               for i in ids]
+        pose_job = self._start_pose_maps(batch, ids, batch["c2w"].device if torch.is_tensor(batch["c2w"]) else None)
         pkg = render_views(cams, self.gaussian, self.pipe, bg)
         self.viewspace_points = pkg["viewspace_points"]              # [B,P,3]; .grad after backward
         self.viewspace_grad_sum = None
@@ -123,26 +178,59 @@ class StageOneStep:
         self.visibility_filter = self.visibility(self.radii)
         images = pkg["render"].permute(0, 2, 3, 1)                   # [B,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)               # [B,H,W,1]
-        dmax = depths.max()                                          # batch-global maximum (:225)
-        if self.sharding is not None and self.sharding.active:
-            dmax = self.sharding.depth_max(dmax)                     # over all ranks' views, differentiable
-        elif self.depth_max_reduce is not None:
-            # replicated batches: the maximum over ALL ranks' views; its gradient flows on the rank that holds it
-            gmax = self.depth_max_reduce(dmax.detach().clone())
-            dmax = torch.where(dmax.detach() == gmax, dmax, gmax)
-        out = {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (dmax + 1e-5),
-               "scale": self.gaussian.get_scaling}
-        if self.skeleton is not None and "mvp_mtx" in batch:
-            dev = images.device
-            az, cent, mvp = torch.as_tensor(batch["azimuth"]), torch.as_tensor(batch["center"]), batch["mvp_mtx"]
-            if self.sharding is not None:           # (indexing with a Python list would synchronise: cached index tensors)
-                az, cent, mvp = self._take(az, ids), self._take(cent, ids), self._take(mvp, ids)
+        local_max = not (self.sharding is not None and self.sharding.active) and self.depth_max_reduce is None
+        if local_max and _FUSED_LOSS and depths.is_cuda and depths.dtype == torch.float32 and pkg["depth_3dgs"].is_contiguous():
+            # one process, no exchange: the loss takes the sparsity term straight from the depth maps (loss()); the quotient
+            # itself is only materialised if somebody asks for it
+            out = _StepOutputs({**pkg, "comp_rgb": images, "depth": depths, "scale": self.gaussian.get_scaling,
+                                "_dmax": lambda d_=depths: d_.max()})
+        else:
+            dmax = depths.max()                                      # batch-global maximum (:225)
+            if self.sharding is not None and self.sharding.active:
+                dmax = self.sharding.depth_max(dmax)                 # over all ranks' views, differentiable
+            elif self.depth_max_reduce is not None:
+                # replicated batches: the maximum over ALL ranks' views; its gradient flows on the rank that holds it
+                gmax = self.depth_max_reduce(dmax.detach().clone())
+                dmax = torch.where(dmax.detach() == gmax, dmax, gmax)
+            out = {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (dmax + 1e-5),
+                   "scale": self.gaussian.get_scaling}
+        if pose_job is not None:
+            out["pose"], out["all_vis_all"] = self._finish_pose_maps(pose_job, images.device)
+        return out
+
+    # the ControlNet pose maps depend on the batch only (GaussianIP.forward :175-196): they are drawn on a second HIP stream while
+    # the rasterizer runs (the span kernel is one wave per limb, 0.15 ms of latency that needs 68 of the chip's 1024 SIMDs)
+    _pose_stream = None
+
+    def _start_pose_maps(self, batch, ids, _unused):
+        if self.skeleton is None or "mvp_mtx" not in batch:
+            return None
+        dev = self.skeleton.device
+        az, cent, mvp = torch.as_tensor(batch["azimuth"]), torch.as_tensor(batch["center"]), batch["mvp_mtx"]
+        if self.sharding is not None:           # (indexing with a Python list would synchronise: cached index tensors)
+            az, cent, mvp = self._take(az, ids), self._take(cent, ids), self._take(mvp, ids)
+        side = None
+        if dev.type == "cuda" and _POSE_STREAM and not torch.cuda.is_current_stream_capturing():
+            if self._pose_stream is None:
+                self._pose_stream = torch.cuda.Stream(device=dev)
+            side = self._pose_stream
+            side.wait_stream(torch.cuda.current_stream(dev))        # device-side batch tensors were produced on the main stream
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if not (mvp.device.type == "cpu" and az.device.type == "cpu" and cent.device.type == "cpu"):
                 az, cent = az.to(dev, non_blocking=True), cent.to(dev, non_blocking=True)       # device-side batch: stay on the device
             head_zoom = (cent == self.head_offset) & (az > 0)        # :176
             pose, all_vis, _ = self.skeleton.openpose_draw(mvp, self.pose_hw[0], self.pose_hw[1], az, head_zoom, True)
-            out["pose"], out["all_vis_all"] = pose, all_vis
-        return out
+        return pose, all_vis, side
+
+    def _finish_pose_maps(self, job, dev):
+        pose, all_vis, side = job
+        if side is not None:
+            main = torch.cuda.current_stream(pose.device)
+            main.wait_stream(side)
+            for t_ in (pose, all_vis):
+                if torch.is_tensor(t_) and t_.is_cuda:
+                    t_.record_stream(main)                           # allocated on the side stream, consumed on the main one
+        return pose, all_vis
 
     # GaussianIP.training_step (stage 1 branch, :362-395)
     def training_step(self, step: int, batch: Dict, guidance, prompt_utils, use_pose_controlnet: bool = True):
@@ -195,7 +283,10 @@ class StageOneStep:
     def loss(self, out: Dict, guidance_out: Dict) -> torch.Tensor:
         c = self.cfg
         loss = guidance_out["loss_sds"] * c.lambda_sds
-        loss = loss + (out["opacity"] ** 2 + 0.01).sqrt().mean() * c.lambda_sparsity
+        if isinstance(out, _StepOutputs) and "opacity" not in out and torch.is_grad_enabled():
+            loss = loss + _SparsityTerm.apply(out["depth_3dgs"]) * c.lambda_sparsity
+        else:
+            loss = loss + (out["opacity"] ** 2 + 0.01).sqrt().mean() * c.lambda_sparsity
         if c.lambda_opaque != 0:
             oc = out["opacity"].clamp(1.0e-3, 1.0 - 1.0e-3)
             loss = loss + binary_cross_entropy(oc, oc) * c.lambda_opaque

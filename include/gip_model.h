@@ -73,6 +73,26 @@ typedef struct {
 } GipAdamGroup;
 int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps, const float* found_inf,
                   void* stream);   /* betas / eps as doubles: the caller's Python floats, no re-rounding (0 <= beta < 1, else status 1) */
+
+/* The sparsity term of the stage-1 loss (threestudio/systems/GaussianIP.py:225, :377-380):
+ *   mean(sqrt((depth / (max(depth) + 1e-5))^2 + 0.01))   over the n = B * H * W depths of a step,
+ * two launches forward, two backward (the reference's op chain: ~20 launches on 4 M elements), fixed summation orders.
+ * workspace: gip_sparsity_workspace_bytes() bytes, zero before its first use, kept between forward and backward;
+ * after forward: ((float*)workspace)[0] = max(depth), [1] = the term.  backward: g_depth[i] = d term / d depth[i] * g_loss[0] * mult
+ * (the maximum's share through the denominator goes evenly to the elements equal to it, like torch.max()'s backward). */
+size_t gip_sparsity_workspace_bytes(void);
+int gip_sparsity_loss_forward(const float* depth, int64_t n, void* workspace, void* stream);
+int gip_sparsity_loss_backward(const float* depth, int64_t n, const float* g_loss, float mult, void* workspace, float* g_depth,
+                               void* stream);
+
+/* The three parameter activations of GaussianModel (gaussiansplatting/scene/gaussian_model.py:36-41, getters :72-89) in one launch:
+ *   opacity [P] = sigmoid(opacity_raw), scaling [P,3] = exp(scaling_raw), rotation [P,4] = rotation_raw / max(||rotation_raw||, 1e-12)
+ * (float32, contiguous), and their backward in one launch (g_* may be NULL = no gradient arrived for that output; d_* may be NULL). */
+int gip_activate_gaussians(const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, int64_t P, float* opacity,
+                           float* scaling, float* rotation, void* stream);
+int gip_activate_gaussians_backward(const float* opacity, const float* scaling, const float* rotation_raw, const float* g_opacity,
+                                    const float* g_scaling, const float* g_rotation, int64_t P, float* d_opacity_raw,
+                                    float* d_scaling_raw, float* d_rotation_raw, void* stream);
 #ifdef __cplusplus
 }
 #endif

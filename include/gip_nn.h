@@ -246,6 +246,35 @@ int gip_attention_fwd_strided_f16(const void* q, const void* k, const void* v, v
 int gip_attention_fwd_strided2_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t Nq,
                                    int32_t Nkv, int32_t D, float scale, const void* k2, const void* v2, int32_t Nkv2,
                                    float weight2, int32_t ld_q, int32_t ld_kv, int32_t ld_kv2, void* stream);
+
+/* Guidance glue (csrc/guidance_glue.hip): the element-wise algebra around the denoiser, one launch per stage instead of the
+ * reference's op chains; same expressions, same order, same intermediate half roundings.
+ * gip_image_prep_f16: rgb [B,C,2 Hout,2 Wout] float32 contiguous -> out [B,Hout,Wout,C] half (the channels-last image the VAE reads)
+ *   = (F.interpolate(rgb, (Hout, Wout), "bilinear", align_corners=False).half() * 2 - 1)   (ipa_guidance.py:612-614, :524);
+ *   _backward: g_out [B,Hout,Wout,C] half -> g_rgb [B,C,2 Hout,2 Wout] float32.
+ * gip_latent_sample_f16: moments [B,2C,H,W] half with element strides m_strides[4] (host array: b, c, h, w), eps / noise [B,C,H,W]
+ *   half contiguous, t [B] int64, acp [1000] float32 (alphas_cumprod) -> latents [B,C,H,W] half =
+ *   (mean + exp(0.5 clamp(logvar, -30, 20)) eps) * scaling   (latent_dist.sample() * scaling_factor, :529) and
+ *   noisy [replicas B,C,H,W] half = `replicas` copies of sqrt(acp_t) latents + sqrt(1 - acp_t) noise   (add_noise, :395-399);
+ *   _backward: g_latents [B,C,H,W] half -> g_moments in the moments' layout.
+ * gip_anpg_loss_f16: noise_pred [3B,C,H,W] half (neg | text | null; strides np_strides[4]), latents [B,C,H,W] half (lat_strides[4]) ->
+ *   grad_out [B,C,H,W] float32 = nan_to_num(clip(w(t) * (guidance_scale (text - null) + (t < t_switch ? null : null - neg))))
+ *   (:411-431; weighting 0 "sds" 1 - acp_t, 1 "uniform", 2 "fantasia3d"; clip_threshold <= 0: no clip; the clip's norm runs over
+ *   the LAST axis), diff_out = lat32 - (lat32 - grad)  (what the MSE's backward multiplies, :645-653),
+ *   scalars[0] = 0.5 sum diff^2 / B  (loss_sds), scalars[1] = ||grad||_2  (grad_norm).  One workgroup.
+ * gip_scale_cast_f16: out[i] = half(x[i] * scale[0] * mult)  (scale: a device scalar, e.g. the upstream gradient of the loss). */
+int gip_image_prep_f16(const float* rgb, int32_t B, int32_t C, int32_t Hout, int32_t Wout, void* out, void* stream);
+int gip_image_prep_backward_f16(const void* g_out, int32_t B, int32_t C, int32_t Hout, int32_t Wout, float* g_rgb, void* stream);
+int gip_latent_sample_f16(const void* moments, const int64_t* m_strides, const void* eps, const void* noise, const int64_t* t,
+                          const float* acp, float scaling, int32_t B, int32_t C, int32_t H, int32_t W, int32_t replicas,
+                          void* latents, void* noisy, void* stream);
+int gip_latent_sample_backward_f16(const void* moments, const int64_t* m_strides, const void* eps, const void* g_latents,
+                                   float scaling, int32_t B, int32_t C, int32_t H, int32_t W, void* g_moments, void* stream);
+int gip_anpg_loss_f16(const void* noise_pred, const int64_t* np_strides, const void* latents, const int64_t* lat_strides,
+                      const int64_t* t, const float* acp, int32_t B, int32_t C, int32_t H, int32_t W, float guidance_scale,
+                      int32_t t_switch, int32_t weighting, float clip_threshold, float* grad_out, float* diff_out,
+                      float* scalars, void* stream);
+int gip_scale_cast_f16(const float* x, const float* scale, float mult, void* out, int64_t n, void* stream);
 #ifdef __cplusplus
 }
 #endif
