@@ -183,6 +183,8 @@ def model_lib():
         lib.gip_activate_gaussians.argtypes = [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]
         lib.gip_activate_gaussians_backward.restype = ctypes.c_int
         lib.gip_activate_gaussians_backward.argtypes = [_vp] * 6 + [ctypes.c_int64, _vp, _vp, _vp, _vp]
+        lib.gip_densify_stats.restype = ctypes.c_int
+        lib.gip_densify_stats.argtypes = [_vp, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]
         _model = _Counted(lib)
     return _model
 
@@ -289,7 +291,9 @@ def nn_lib():
         lib.gip_latent_sample_backward_f16.argtypes = [_vp, _i64p, _vp, _vp, ctypes.c_float] + [ctypes.c_int32] * 4 + [_vp, _vp]
         lib.gip_anpg_loss_f16.restype = ctypes.c_int
         lib.gip_anpg_loss_f16.argtypes = [_vp, _i64p, _vp, _i64p, _vp, _vp] + [ctypes.c_int32] * 4 + [ctypes.c_float, ctypes.c_int32,
-                                          ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp]
+                                          ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
+        lib.gip_timestep_embedding_f16.restype = ctypes.c_int
+        lib.gip_timestep_embedding_f16.argtypes = [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp]
         lib.gip_scale_cast_f16.restype = ctypes.c_int
         lib.gip_scale_cast_f16.argtypes = [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, _vp]
         _nn = _Counted(lib)

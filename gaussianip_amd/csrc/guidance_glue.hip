@@ -35,56 +35,71 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 }
 
 // ---- ANPG combination -> weighting -> row clip -> nan_to_num -> detached-target MSE ------------------------------------------
-// one thread per (b, c, h) row of W latents: the clip's L2 norm runs over the LAST axis (ipa_guidance.py:427-431)
-__global__ void __launch_bounds__(1024)
+// The clip's L2 norm runs over the LAST axis (ipa_guidance.py:427-431): one WAVE per (b, h) image row, lane = w, every lane walks
+// the C channels; a channel's row norm is a wave reduction (fixed butterfly order).  Per-wave (loss, norm^2) partials, added up in
+// index order by anpg_finish_kernel.  (A first version with one thread per row in a single workgroup took 330 us.)
+#define ANPG_MAXC 8
+__global__ void __launch_bounds__(256)
 anpg_loss_kernel(const _Float16* __restrict__ noise_pred, Strides4 ns, const _Float16* __restrict__ latents, Strides4 ls,
                  const int64_t* __restrict__ t, const float* __restrict__ acp, int B, int C, int Hh, int W, float guidance_scale,
                  int t_switch, int weighting, float clip_threshold, float* __restrict__ grad_out, float* __restrict__ diff_out,
-                 float* __restrict__ scalars) {
-  __shared__ float s_red[16];
-  const int rows = B * C * Hh;
+                 float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63, wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wv >= B * Hh) return;
+  const int b = wv / Hh, h = wv - b * Hh;
+  const int64_t tb = t[b];
+  const float a = acp[tb];
+  const float wgt = weighting == 0 ? 1.f - a : (weighting == 1 ? 1.f : sqrtf(a) * (1.f - a));
+  const float mf = tb < (int64_t)t_switch ? 1.f : 0.f;
   float loss = 0.f, nrm = 0.f;
-  for (int row = threadIdx.x; row < rows; row += blockDim.x) {
-    const int h = row % Hh, c = (row / Hh) % C, b = row / (Hh * C);
-    const int64_t tb = t[b];
-    const float a = acp[tb];
-    const float wgt = weighting == 0 ? 1.f - a : (weighting == 1 ? 1.f : sqrtf(a) * (1.f - a));
-    const float mf = tb < (int64_t)t_switch ? 1.f : 0.f;
-    // noise_pred rows (neg | text | null) of sample b: b, B + b, 2B + b
-    const _Float16* pn = noise_pred + (int64_t)b * ns.b + (int64_t)c * ns.c + (int64_t)h * ns.h;
-    const _Float16* pt = pn + (int64_t)B * ns.b;
-    const _Float16* pu = pt + (int64_t)B * ns.b;
-    const _Float16* pl = latents + (int64_t)b * ls.b + (int64_t)c * ls.c + (int64_t)h * ls.h;
-    float* go = grad_out + (int64_t)row * W;
-    float* dfo = diff_out + (int64_t)row * W;
-    float ss = 0.f;
-    for (int w = 0; w < W; w++) {
-      const float en = ldh(pn + w * ns.w), et = ldh(pt + w * ns.w), eu = ldh(pu + w * ns.w);
-      const float dc = H(guidance_scale * H(et - eu));                  // guidance_scale * (eps_text - eps_null)
-      const float dd = H(H(mf * eu) + H((1.f - mf) * H(eu - en)));      // mask * eps_null + (1 - mask) * (eps_null - eps_neg): 0 * NaN stays NaN
-      const float g = wgt * H(dc + dd);                                 // float32 from here on (w is a float32 tensor)
-      go[w] = g;
-      ss += g * g;
-    }
-    float n = sqrtf(ss) + 1e-8f, nc = clip_threshold > 0.f ? fminf(n, clip_threshold) : n;
-    for (int w = 0; w < W; w++) {
-      float g = go[w];
-      if (clip_threshold > 0.f) g = nc * g / n;                         // n.clamp(max = threshold) * grad / n
-      if (g != g) g = 0.f;                                              // nan_to_num
+  for (int w0 = 0; w0 < W; w0 += 64) {            // W <= 64 at the training shape: one trip; the row norm below needs W <= 64
+    const int w = w0 + lane;
+    const bool on = w < W;
+    for (int c = 0; c < C; c++) {
+      float g = 0.f, l32 = 0.f;
+      if (on) {
+        // noise_pred rows (neg | text | null) of sample b: b, B + b, 2B + b
+        const _Float16* pn = noise_pred + (int64_t)b * ns.b + (int64_t)c * ns.c + (int64_t)h * ns.h + (int64_t)w * ns.w;
+        const float en = ldh(pn), et = ldh(pn + (int64_t)B * ns.b), eu = ldh(pn + 2 * (int64_t)B * ns.b);
+        l32 = ldh(latents + (int64_t)b * ls.b + (int64_t)c * ls.c + (int64_t)h * ls.h + (int64_t)w * ls.w);
+        const float dc = H(guidance_scale * H(et - eu));                  // guidance_scale * (eps_text - eps_null)
+        const float dd = H(H(mf * eu) + H((1.f - mf) * H(eu - en)));      // mask * eps_null + (1 - mask) * (eps_null - eps_neg): 0 * NaN stays NaN
+        g = wgt * H(dc + dd);                                             // float32 from here on (w(t) is a float32 tensor)
+      }
+      if (clip_threshold > 0.f) {
+        float ss = g * g;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 64);
+        const float n = sqrtf(ss) + 1e-8f;
+        g = fminf(n, clip_threshold) * g / n;                             // n.clamp(max = threshold) * grad / n
+      }
+      if (g != g) g = 0.f;                                                // nan_to_num
       else if (g == INFINITY) g = 3.4028234663852886e38f;
       else if (g == -INFINITY) g = -3.4028234663852886e38f;
-      go[w] = g;
-      const float l32 = ldh(pl + w * ls.w);
-      const float d = l32 - (l32 - g);                                  // lat32 - target, target = (lat32 - grad).detach()
-      dfo[w] = d;
-      loss += d * d;
-      nrm += g * g;
+      if (on) {
+        const int64_t o = (((int64_t)b * C + c) * Hh + h) * W + w;
+        const float d = l32 - (l32 - g);                                  // lat32 - target, target = (lat32 - grad).detach()
+        grad_out[o] = g;
+        diff_out[o] = d;
+        loss += d * d;
+        nrm += g * g;
+      }
     }
   }
-  const float ls_ = block_sum(loss, s_red), ns_ = block_sum(nrm, s_red);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { loss += __shfl_xor(loss, d, 64); nrm += __shfl_xor(nrm, d, 64); }
+  if (lane == 0) { partials[2 * wv] = loss; partials[2 * wv + 1] = nrm; }
+}
+
+__global__ void __launch_bounds__(256) anpg_finish_kernel(const float* __restrict__ partials, int n, int B, float* __restrict__ scalars) {
+  __shared__ float s_red[16];
+  float l = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { l += partials[2 * i]; q += partials[2 * i + 1]; }
+  l = block_sum(l, s_red);
+  q = block_sum(q, s_red);
   if (threadIdx.x == 0) {
-    scalars[0] = 0.5f * ls_ / (float)B;
-    scalars[1] = sqrtf(ns_);
+    scalars[0] = 0.5f * l / (float)B;
+    scalars[1] = sqrtf(q);
   }
 }
 
@@ -162,6 +177,18 @@ __global__ void image_prep_bwd_kernel(const _Float16* __restrict__ g, int B, int
   }
 }
 
+// ---- diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(max_period) k / (dim/2)) ----
+// (arange, two scalar ops, exp, cast, outer product, cos, sin, concatenation, cast in the op-chain spelling: ten launches per network)
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, int half_dim, float neg_log_period, _Float16* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half_dim) return;
+  const int b = i / half_dim, k = i - b * half_dim;
+  const float freq = expf((neg_log_period * (float)k) / (float)half_dim);
+  const float arg = (float)t[b] * freq;
+  out[(size_t)b * 2 * half_dim + k] = (_Float16)cosf(arg);
+  out[(size_t)b * 2 * half_dim + half_dim + k] = (_Float16)sinf(arg);
+}
+
 Strides4 strides(const int64_t* s) { return Strides4{s[0], s[1], s[2], s[3]}; }
 
 }  // namespace
@@ -169,12 +196,16 @@ Strides4 strides(const int64_t* s) { return Strides4{s[0], s[1], s[2], s[3]}; }
 extern "C" int gip_anpg_loss_f16(const void* noise_pred, const int64_t* np_strides, const void* latents, const int64_t* lat_strides,
                                  const int64_t* t, const float* acp, int32_t B, int32_t C, int32_t H, int32_t W, float guidance_scale,
                                  int32_t t_switch, int32_t weighting, float clip_threshold, float* grad_out, float* diff_out,
-                                 float* scalars, void* stream) {
+                                 float* scalars, float* partials, void* stream) {
   if (!noise_pred || !np_strides || !latents || !lat_strides || !t || !acp || !grad_out || !diff_out || !scalars) return 1;
   if (B < 1 || C < 1 || H < 1 || W < 1 || weighting < 0 || weighting > 2) return 1;
-  hipLaunchKernelGGL(anpg_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)noise_pred, strides(np_strides),
-                     (const _Float16*)latents, strides(lat_strides), t, acp, B, C, H, W, guidance_scale, t_switch, weighting,
-                     clip_threshold, grad_out, diff_out, scalars);
+  if (clip_threshold > 0.f && W > 64) return 1;                 // the row norm is one wave reduction
+  if (!partials) return 1;
+  const int waves = B * H;
+  hipLaunchKernelGGL(anpg_loss_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const _Float16*)noise_pred,
+                     strides(np_strides), (const _Float16*)latents, strides(lat_strides), t, acp, B, C, H, W, guidance_scale, t_switch,
+                     weighting, clip_threshold, grad_out, diff_out, partials);
+  hipLaunchKernelGGL(anpg_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, waves, B, scalars);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -216,5 +247,13 @@ extern "C" int gip_image_prep_backward_f16(const void* g_out, int32_t B, int32_t
   const int64_t n = (int64_t)B * Hout * Wout;
   hipLaunchKernelGGL(image_prep_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)g_out, B, C,
                      Hout, Wout, g_rgb);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_timestep_embedding_f16(const int64_t* t, int32_t B, int32_t dim, float max_period, void* out, void* stream) {
+  if (!t || !out || B < 1 || dim < 2 || (dim & 1) || !(max_period > 1.f)) return 1;
+  const int n = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, B, dim / 2,
+                     (float)(-log((double)max_period)), (_Float16*)out);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -265,10 +265,12 @@ extern "C" int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, doubl
 
 // ---- the sparsity term of the stage-1 loss: mean(sqrt((depth / (max(depth) + 1e-5))^2 + 0.01))  (GaussianIP.py:225, :377-380) -------
 // The reference spells it as max -> add -> div -> pow -> add -> sqrt -> mean on the [B, H, W, 1] depth maps (4 M elements at the
-// training shape): seven forward and about twice as many backward launches of 6-20 us each.  Here: two launches forward, two backward,
-// fixed summation orders (bitwise reproducible).  `ws` (workspace, float32, ZERO before its first use): [0] max, [1] loss, [2] count
-// of maxima, [3] the gradient each maximum receives, [4, 4 + 2 * SP_BLOCKS) per-workgroup partials, then one uint32 ticket counter
-// (the workgroup that draws the last ticket adds the partials up in index order and resets the counter).
+// training shape): seven forward and about twice as many backward launches.  Here: three launches forward, two backward, fixed
+// summation orders (bitwise reproducible), no inter-workgroup fences (a first version that let the last workgroup of a launch add up
+// the partials behind `__threadfence()` took 130 us per kernel: an agent-scope release writes the L2 back, once per workgroup).
+// Every workgroup of a consumer kernel re-derives the scalar it needs from the producer's per-workgroup partials (4 KB, same order
+// everywhere).  `ws` (float32): [0] max, [1] loss, [2] count of maxima, [4, 4 + SP_BLOCKS) maxima / backward sums per workgroup,
+// [4 + SP_BLOCKS, 4 + 3 SP_BLOCKS) (loss sum, tie count) per workgroup.
 #define SP_BLOCKS 1024
 #define SP_THREADS 256
 
@@ -286,19 +288,11 @@ __device__ __forceinline__ float sp_block_reduce(float v, bool is_max, float* s_
   return t;
 }
 
-// the workgroup that takes the last ticket sees every other workgroup's partial (release / acquire through the ticket counter)
-__device__ __forceinline__ bool sp_last_block(unsigned int* ticket) {
-  __shared__ bool s_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int t = atomicAdd(ticket, 1u);
-    s_last = t == gridDim.x - 1;
-    if (s_last) *ticket = 0;
-  }
-  __syncthreads();
-  __threadfence();
-  return s_last;
+// the same value in every workgroup: partial[0 .. nb) combined in one fixed order
+__device__ __forceinline__ float sp_combine(const float* __restrict__ part, int nb, int stride, bool is_max, float* s_red) {
+  float t = is_max ? -INFINITY : 0.f;
+  for (int i = threadIdx.x; i < nb; i += SP_THREADS) t = is_max ? fmaxf(t, part[(size_t)i * stride]) : t + part[(size_t)i * stride];
+  return sp_block_reduce(t, is_max, s_red);
 }
 
 __global__ void __launch_bounds__(SP_THREADS) sp_max_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ ws) {
@@ -307,16 +301,11 @@ __global__ void __launch_bounds__(SP_THREADS) sp_max_kernel(const float* __restr
   for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) m = fmaxf(m, d[i]);
   m = sp_block_reduce(m, true, s_red);
   if (threadIdx.x == 0) ws[4 + blockIdx.x] = m;
-  if (!sp_last_block((unsigned int*)(ws + 4 + 2 * SP_BLOCKS))) return;
-  float t = -INFINITY;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += SP_THREADS) t = fmaxf(t, ws[4 + i]);
-  t = sp_block_reduce(t, true, s_red);
-  if (threadIdx.x == 0) ws[0] = t;
 }
 
 __global__ void __launch_bounds__(SP_THREADS) sp_loss_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ ws) {
   __shared__ float s_red[SP_THREADS / 64];
-  const float dmax = ws[0], den = dmax + 1e-5f;
+  const float dmax = sp_combine(ws + 4, (int)gridDim.x, 1, true, s_red), den = dmax + 1e-5f;
   float sum = 0.f, cnt = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
     const float x = d[i], o = x / den;
@@ -325,21 +314,20 @@ __global__ void __launch_bounds__(SP_THREADS) sp_loss_kernel(const float* __rest
   }
   sum = sp_block_reduce(sum, false, s_red);
   cnt = sp_block_reduce(cnt, false, s_red);
-  float* part = ws + 4;
+  float* part = ws + 4 + SP_BLOCKS;
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = sum; part[2 * blockIdx.x + 1] = cnt; }
-  if (!sp_last_block((unsigned int*)(ws + 4 + 2 * SP_BLOCKS))) return;
-  float a = 0.f, c = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += SP_THREADS) {
-    a += part[2 * i];
-    c += part[2 * i + 1];
-  }
-  a = sp_block_reduce(a, false, s_red);
-  c = sp_block_reduce(c, false, s_red);
-  if (threadIdx.x == 0) { ws[1] = a / (float)n; ws[2] = c; }
 }
 
-// pass 1 of the backward: g_d[i] = (g / n) (o / sqrt(o^2 + 0.01)) / den, and the gradient that reaches the maximum through the
-// denominator, -sum_i (g / n) (o_i / v_i) o_i / den, shared evenly by the elements that equal it (torch.max()'s backward)
+__global__ void __launch_bounds__(SP_THREADS) sp_finish_kernel(int nb, int64_t n, float* __restrict__ ws) {
+  __shared__ float s_red[SP_THREADS / 64];
+  const float dmax = sp_combine(ws + 4, nb, 1, true, s_red);
+  const float sum = sp_combine(ws + 4 + SP_BLOCKS, nb, 2, false, s_red);
+  const float cnt = sp_combine(ws + 4 + SP_BLOCKS + 1, nb, 2, false, s_red);
+  if (threadIdx.x == 0) { ws[0] = dmax; ws[1] = sum / (float)n; ws[2] = cnt; }
+}
+
+// pass 1 of the backward: g_d[i] = (g / n) (o / sqrt(o^2 + 0.01)) / den; per workgroup the sum of (d loss / d o_i) o_i, whose
+// negative over den is what reaches the maximum through the denominator
 __global__ void __launch_bounds__(SP_THREADS) sp_bwd_kernel(const float* __restrict__ d, int64_t n, const float* __restrict__ g_loss,
                                                               float mult, float* __restrict__ ws, float* __restrict__ g_d) {
   __shared__ float s_red[SP_THREADS / 64];
@@ -352,43 +340,42 @@ __global__ void __launch_bounds__(SP_THREADS) sp_bwd_kernel(const float* __restr
     acc += go * o;
   }
   acc = sp_block_reduce(acc, false, s_red);
-  float* part = ws + 4;
-  if (threadIdx.x == 0) part[blockIdx.x] = acc;
-  if (!sp_last_block((unsigned int*)(ws + 4 + 2 * SP_BLOCKS))) return;
-  float a = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += SP_THREADS) a += part[i];
-  a = sp_block_reduce(a, false, s_red);
-  if (threadIdx.x == 0) ws[3] = -(a / den) / ws[2];
+  if (threadIdx.x == 0) ws[4 + blockIdx.x] = acc;
 }
 
+// pass 2: the maximum's share, split evenly among the elements that equal it (torch.max()'s backward)
 __global__ void __launch_bounds__(SP_THREADS) sp_bwd_max_kernel(const float* __restrict__ d, int64_t n, const float* __restrict__ ws,
                                                                   float* __restrict__ g_d) {
-  const float dmax = ws[0], add = ws[3];
+  __shared__ float s_red[SP_THREADS / 64];
+  const float dmax = ws[0], den = dmax + 1e-5f;
+  const float add = -(sp_combine(ws + 4, (int)gridDim.x, 1, false, s_red) / den) / ws[2];
   for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS)
     if (d[i] == dmax) g_d[i] += add;
 }
 
-extern "C" size_t gip_sparsity_workspace_bytes(void) { return (4 + 2 * SP_BLOCKS + 4) * sizeof(float); }
+static int sp_blocks(int64_t n) { const int64_t b = (n + SP_THREADS - 1) / SP_THREADS; return (int)(b < SP_BLOCKS ? b : SP_BLOCKS); }
+
+extern "C" size_t gip_sparsity_workspace_bytes(void) { return (4 + 3 * SP_BLOCKS) * sizeof(float); }
 
 extern "C" int gip_sparsity_loss_forward(const float* depth, int64_t n, void* workspace, void* stream) {
   if (!depth || !workspace || n < 1) return 1;
-  const int blocks = (int)((n + SP_THREADS - 1) / SP_THREADS < SP_BLOCKS ? (n + SP_THREADS - 1) / SP_THREADS : SP_BLOCKS);
+  const int blocks = sp_blocks(n);
   float* ws = (float*)workspace;
   hipLaunchKernelGGL(sp_max_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, ws);
   hipLaunchKernelGGL(sp_loss_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, ws);
+  hipLaunchKernelGGL(sp_finish_kernel, dim3(1), dim3(SP_THREADS), 0, (hipStream_t)stream, blocks, n, ws);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 extern "C" int gip_sparsity_loss_backward(const float* depth, int64_t n, const float* g_loss, float mult, void* workspace, float* g_depth,
                                           void* stream) {
   if (!depth || !workspace || !g_loss || !g_depth || n < 1) return 1;
-  const int blocks = (int)((n + SP_THREADS - 1) / SP_THREADS < SP_BLOCKS ? (n + SP_THREADS - 1) / SP_THREADS : SP_BLOCKS);
+  const int blocks = sp_blocks(n);
   float* ws = (float*)workspace;
   hipLaunchKernelGGL(sp_bwd_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, g_loss, mult, ws, g_depth);
   hipLaunchKernelGGL(sp_bwd_max_kernel, dim3(blocks), dim3(SP_THREADS), 0, (hipStream_t)stream, depth, n, ws, g_depth);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
-
 
 // ---- the three parameter activations of GaussianModel (gaussian_model.py:36-41, getters :72-89) in one launch each way ---------------
 // opacity = sigmoid(o), scaling = exp(s), rotation = q / max(||q||, 1e-12): three op chains forward (sigmoid; exp; norm, clamp,
@@ -443,5 +430,35 @@ extern "C" int gip_activate_gaussians_backward(const float* opacity, const float
   if (!opacity || !scaling || !rotation_raw || P < 1) return 1;
   hipLaunchKernelGGL(activate_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, opacity, scaling,
                      rotation_raw, g_opacity, g_scaling, g_rotation, P, d_opacity_raw, d_scaling_raw, d_rotation_raw);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+
+// ---- densification statistics of a step (GaussianIP.on_before_optimizer_step :451-457 + gaussian_model.py:420-422) in one launch ---------
+//   grad = sum_v viewspace_grad[v]           (V = 1: the exchange of a multi-GPU step already summed it)
+//   max_radii2D[vis] = max(max_radii2D, radii)[vis];  xyz_gradient_accum += ||grad[:, :2]|| * vis;  denom += vis
+// the reference's chain: a view sum, a cast, max, where, slice + norm, mask cast, mul and two in-place adds.
+__global__ void densify_stats_kernel(const float* __restrict__ vgrad, int V, int64_t P, const uint8_t* __restrict__ vis,
+                                     const int32_t* __restrict__ radii, float* __restrict__ max_radii, float* __restrict__ accum,
+                                     float* __restrict__ denom) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float gx = 0.f, gy = 0.f;
+  for (int v = 0; v < V; v++) {
+    const float* g = vgrad + ((int64_t)v * P + i) * 3;
+    gx = v == 0 ? g[0] : gx + g[0];
+    gy = v == 0 ? g[1] : gy + g[1];
+  }
+  const float m = vis[i] ? 1.f : 0.f;
+  if (vis[i]) max_radii[i] = fmaxf(max_radii[i], (float)radii[i]);
+  accum[i] += sqrtf(gx * gx + gy * gy) * m;
+  denom[i] += m;
+}
+
+extern "C" int gip_densify_stats(const float* viewspace_grad, int32_t V, int64_t P, const uint8_t* visible, const int32_t* radii,
+                                 float* max_radii2D, float* xyz_gradient_accum, float* denom, void* stream) {
+  if (!viewspace_grad || !visible || !radii || !max_radii2D || !xyz_gradient_accum || !denom || V < 1 || P < 1) return 1;
+  hipLaunchKernelGGL(densify_stats_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, viewspace_grad, V, P, visible,
+                     radii, max_radii2D, xyz_gradient_accum, denom);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -201,8 +201,12 @@ class StableDiffusionGuidance:
                                "analysis and the IP-Adapter image projection run outside this package)")
         self.num_samples = int(self.cfg.batch_size)
         tile = lambda e: e.expand(self.num_samples, -1, -1).contiguous() if e.shape[0] == 1 else e  # noqa: E731
+        single = [e if e.shape[0] == 1 else None for e in (self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds)]
         self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds = (
             tile(self.pos_image_embeds), tile(self.neg_image_embeds), tile(self.null_image_embeds))
+        # the one-row originals of the tiled tokens (every view shares them): what the prompt table of the fused call is built from
+        self._image_embeds_single = None if any(e is None for e in single) else (
+            tuple(single), tuple(id(e) for e in (self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds)))
         self.bs_embed, self.seq_len = 1, self.pos_image_embeds.shape[1]
 
     def set_image_embeds(self, pos, neg, null):
@@ -246,7 +250,8 @@ class StableDiffusionGuidance:
         if self._graphs is None:
             self._graphs = {}
         key = (tuple(noisy_latents.shape), noisy_latents.dtype, tuple(control_img.shape), control_img.dtype, tuple(t.shape), t.dtype,
-               tuple(ctx.shape), ctx.dtype, bool(use_pose), int(replicas), noisy_latents.device.index, fused.graph_signature())
+               tuple(ctx.shape), ctx.dtype, bool(use_pose), int(replicas), noisy_latents.device.index, fused.graph_signature(),
+               bool(glue.timestep_embedding_supported(t, self.weights_dtype)))
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs[key] = "warm"
@@ -381,8 +386,11 @@ class StableDiffusionGuidance:
         from .prompts import direction_index
         if not hasattr(prompt_utils, "text_embeddings_vd"):
             return None
-        srcs = (prompt_utils.text_embeddings_vd, prompt_utils.uncond_text_embeddings_vd, prompt_utils.null_embeddings,
-                self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds)
+        img = (self.pos_image_embeds, self.neg_image_embeds, self.null_image_embeds)
+        one = getattr(self, "_image_embeds_single", None)
+        if one is not None and one[1] == tuple(id(e) for e in img):
+            img = one[0]                           # prepare_for_sds tiled these single rows to batch_size identical rows
+        srcs = (prompt_utils.text_embeddings_vd, prompt_utils.uncond_text_embeddings_vd, prompt_utils.null_embeddings) + tuple(img)
         if not self.cfg.view_dependent_prompting or any(e.shape[0] != 1 for e in srcs[2:]):
             return None
         key = tuple((id(e), e._version, e.data_ptr()) for e in srcs) + (self.weights_dtype,)

@@ -371,7 +371,8 @@ class _Encoder(nn.Module):
         self.mid_res1, self.mid_attn, self.mid_res2 = ResBlock(1280, 1280), SpatialTransformer(1280, 768, 8, lora_rank, ip, ip_scale), ResBlock(1280, 1280)
 
     def temb(self, t, dtype):
-        e = timestep_embedding(t).to(dtype)
+        from . import glue
+        e = glue.timestep_embedding(t) if glue.timestep_embedding_supported(t, dtype) else timestep_embedding(t).to(dtype)
         temb = self.time_l2(F.silu(self.time_l1(e)))
         self.stage_time_embedding(temb)
         return temb

@@ -100,17 +100,46 @@ def render_deformed(viewpoint_camera, means3D, opacity, scales, rotations, shs, 
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
+_ZEROS = {}
+
+
+class _LazyDict(dict):
+    """A dict whose listed entries are computed on first access (the reference's return dicts carry tensors a training step
+    never reads: `visibility_filter` per view, the activated `scale`)."""
+
+    def __init__(self, items, lazy):
+        super().__init__(items)
+        self._lazy = dict(lazy)
+
+    def __missing__(self, key):
+        fn = self._lazy.pop(key, None)
+        if fn is None:
+            raise KeyError(key)
+        v = self[key] = fn()
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 def render_views(cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """All cameras of a batch in one launch set.  Returns the reference dict with a leading view axis:
     render [V,3,H,W], viewspace_points [V,P,3] (grad carrier), visibility_filter / radii [V,P],
     depth_3dgs / alpha_3dgs [V,1,H,W].  Per-view results equal render() called camera by camera."""
     xyz = pc.get_xyz
     V = len(cameras)
-    screenspace_points = torch.zeros((V,) + tuple(xyz.shape), dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # the gradient carrier of the 2-D means (the reference's `zeros_like(...) + 0` with retain_grad): a fresh autograd leaf per call
+    # over ONE cached block of zeros per shape — nothing ever writes the values, only .grad is read — instead of a fill and an add
+    # of V x P x 3 floats per step
+    key = (V,) + tuple(xyz.shape) + (xyz.dtype, xyz.device)
+    zeros = _ZEROS.get(key)
+    if zeros is None:
+        _ZEROS.clear()
+        zeros = _ZEROS[key] = torch.zeros((V,) + tuple(xyz.shape), dtype=xyz.dtype, device=xyz.device)
+    screenspace_points = zeros.detach().requires_grad_(True)
     if pipe.convert_SHs_python and override_color is None:
         raise ValueError("render_views: convert_SHs_python colours are view dependent; use render() per camera")
     scales, rotations, cov3D, shs, colors = _select_inputs(cameras[0], pc, pipe, scaling_modifier, override_color, activated=True)
@@ -120,5 +149,5 @@ def render_views(cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
     image, radii, depth, alpha = rasterize_views(
         xyz.float(), screenspace_points.float(), opacity.float(), sts, shs=_f(shs), colors_precomp=colors,
         scales=_f(scales), rotations=_f(rotations), cov3D_precomp=cov3D)
-    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "depth_3dgs": depth, "alpha_3dgs": alpha}
+    return _LazyDict({"render": image, "viewspace_points": screenspace_points, "radii": radii, "depth_3dgs": depth, "alpha_3dgs": alpha},
+                     {"visibility_filter": lambda r_=radii: r_ > 0})

@@ -22,29 +22,26 @@ from .scene.cameras import Camera
 
 _POSE_STREAM = os.environ.get("GIP_POSE_STREAM", "1") != "0"      # 0: pose maps on the main stream (same-box A/B)
 _FUSED_LOSS = os.environ.get("GIP_FUSED_LOSS", "1") != "0"        # 0: the sparsity term as the reference's op chain (same-box A/B)
-_sparsity_ws = {}
 
 
 class _SparsityTerm(torch.autograd.Function):
-    """mean(sqrt((depth / (max(depth) + 1e-5))^2 + 0.01)) of a step's depth maps (GaussianIP.py:225, :377-380) in two launches
+    """mean(sqrt((depth / (max(depth) + 1e-5))^2 + 0.01)) of a step's depth maps (GaussianIP.py:225, :377-380) in three launches
     forward and two backward (include/gip_model.h: gip_sparsity_loss_*); the op chain it replaces is ~20 launches on 4 M
-    elements.  One workspace per device: forward and backward of a step pair up (the step's loss is consumed before the next
-    forward runs)."""
+    elements."""
 
     @staticmethod
     def forward(ctx, depth):
         from . import _lib
         lib = _lib.model_lib()
-        ws = _sparsity_ws.get(depth.device)
-        if ws is None:
-            ws = _sparsity_ws[depth.device] = torch.zeros(lib.gip_sparsity_workspace_bytes() // 4, dtype=torch.float32, device=depth.device)
+        # a workspace per call (12 KB): it carries the maximum and the tie count to THIS call's backward, whatever runs in between
+        ws = torch.empty(lib.gip_sparsity_workspace_bytes() // 4, dtype=torch.float32, device=depth.device)
         rc = lib.gip_sparsity_loss_forward(ctypes.c_void_p(depth.data_ptr()), depth.numel(), ctypes.c_void_p(ws.data_ptr()),
                                            ctypes.c_void_p(torch.cuda.current_stream(depth.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("gip_sparsity_loss_forward failed with status %d" % rc)
         ctx.save_for_backward(depth)
         ctx.ws = ws
-        return ws[1].clone()
+        return ws[1]
 
     @staticmethod
     def backward(ctx, g):
@@ -65,11 +62,20 @@ class _StepOutputs(dict):
     sparsity term works on the depth maps directly and the [B, H, W, 1] quotient is otherwise a dead 16 MB tensor per step."""
 
     def __missing__(self, key):
-        if key == "opacity" and "_dmax" in self:
+        if key == "opacity" and dict.__contains__(self, "_dmax"):
             v = self["depth"] / (dict.__getitem__(self, "_dmax")() + 1e-5)
             self[key] = v
             return v
+        if key == "scale" and dict.__contains__(self, "_scale"):           # "scale": the activated scaling (GaussianIP.py:228), made when read
+            v = self[key] = dict.__getitem__(self, "_scale")()
+            return v
+        if key == "visibility_filter" and dict.__contains__(self, "radii"):
+            v = self[key] = self["radii"] > 0
+            return v
         raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in ("opacity", "scale", "visibility_filter")
 
 
 @dataclass
@@ -182,8 +188,8 @@ class StageOneStep:
         if local_max and _FUSED_LOSS and depths.is_cuda and depths.dtype == torch.float32 and pkg["depth_3dgs"].is_contiguous():
             # one process, no exchange: the loss takes the sparsity term straight from the depth maps (loss()); the quotient
             # itself is only materialised if somebody asks for it
-            out = _StepOutputs({**pkg, "comp_rgb": images, "depth": depths, "scale": self.gaussian.get_scaling,
-                                "_dmax": lambda d_=depths: d_.max()})
+            out = _StepOutputs({**pkg, "comp_rgb": images, "depth": depths, "_dmax": lambda d_=depths: d_.max(),
+                                "_scale": lambda g_=self.gaussian: g_.get_scaling})
         else:
             dmax = depths.max()                                      # batch-global maximum (:225)
             if self.sharding is not None and self.sharding.active:
@@ -192,8 +198,8 @@ class StageOneStep:
                 # replicated batches: the maximum over ALL ranks' views; its gradient flows on the rank that holds it
                 gmax = self.depth_max_reduce(dmax.detach().clone())
                 dmax = torch.where(dmax.detach() == gmax, dmax, gmax)
-            out = {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (dmax + 1e-5),
-                   "scale": self.gaussian.get_scaling}
+            out = {**pkg, "visibility_filter": pkg["visibility_filter"], "comp_rgb": images, "depth": depths,
+                   "opacity": depths / (dmax + 1e-5), "scale": self.gaussian.get_scaling}
         if pose_job is not None:
             out["pose"], out["all_vis_all"] = self._finish_pose_maps(pose_job, images.device)
         return out
@@ -283,7 +289,7 @@ class StageOneStep:
     def loss(self, out: Dict, guidance_out: Dict) -> torch.Tensor:
         c = self.cfg
         loss = guidance_out["loss_sds"] * c.lambda_sds
-        if isinstance(out, _StepOutputs) and "opacity" not in out and torch.is_grad_enabled():
+        if isinstance(out, _StepOutputs) and not dict.__contains__(out, "opacity") and torch.is_grad_enabled():
             loss = loss + _SparsityTerm.apply(out["depth_3dgs"]) * c.lambda_sparsity
         else:
             loss = loss + (out["opacity"] ** 2 + 0.01).sqrt().mean() * c.lambda_sparsity
@@ -291,6 +297,25 @@ class StageOneStep:
             oc = out["opacity"].clamp(1.0e-3, 1.0 - 1.0e-3)
             loss = loss + binary_cross_entropy(oc, oc) * c.lambda_opaque
         return loss
+
+    def _fused_stats(self, vis) -> bool:
+        """accumulate() below as one launch (include/gip_model.h: gip_densify_stats) when everything lives on the GPU in the stock
+        dtypes; False = not applicable, the op chain runs."""
+        g = self.gaussian
+        vg = self.viewspace_grad_sum if self.viewspace_grad_sum is not None else self.viewspace_points.grad
+        if not (_FUSED_LOSS and vg is not None and vg.is_cuda and vg.dtype == torch.float32 and vg.is_contiguous() and vis.dtype == torch.bool and
+                vis.is_contiguous() and self.radii.dtype == torch.int32 and self.radii.is_contiguous() and
+                all(t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda for t in (g.max_radii2D, g.xyz_gradient_accum, g.denom))):
+            return False
+        from . import _lib
+        P = vis.shape[0]
+        V = vg.shape[0] if vg.dim() == 3 else 1
+        p_ = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        rc = _lib.model_lib().gip_densify_stats(p_(vg), V, P, p_(vis), p_(self.radii), p_(g.max_radii2D), p_(g.xyz_gradient_accum), p_(g.denom),
+                                                ctypes.c_void_p(torch.cuda.current_stream(vis.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_densify_stats failed with status %d" % rc)
+        return True
 
     # GaussianIP.on_before_optimizer_step (stage 1 branch)
     @torch.no_grad()
@@ -302,8 +327,10 @@ class StageOneStep:
 
         def accumulate():
             # sum of the per-view grads (:451-454); a multi-GPU exchange leaves the all-reduced sum in viewspace_grad_sum
-            grad = self.viewspace_grad_sum if self.viewspace_grad_sum is not None else self.viewspace_points.grad.sum(dim=0)
             vis = self.visibility_filter
+            if self._fused_stats(vis):
+                return
+            grad = self.viewspace_grad_sum if self.viewspace_grad_sum is not None else self.viewspace_points.grad.sum(dim=0)
             # same values as the reference's masked assignment (:456), without nonzero() = without a host synchronisation
             g.max_radii2D = torch.where(vis, torch.max(g.max_radii2D, self.radii.to(g.max_radii2D.dtype)), g.max_radii2D)
             g.add_densification_stats(grad, vis)

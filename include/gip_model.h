@@ -76,8 +76,8 @@ int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, double beta1, do
 
 /* The sparsity term of the stage-1 loss (threestudio/systems/GaussianIP.py:225, :377-380):
  *   mean(sqrt((depth / (max(depth) + 1e-5))^2 + 0.01))   over the n = B * H * W depths of a step,
- * two launches forward, two backward (the reference's op chain: ~20 launches on 4 M elements), fixed summation orders.
- * workspace: gip_sparsity_workspace_bytes() bytes, zero before its first use, kept between forward and backward;
+ * three launches forward, two backward (the reference's op chain: ~20 launches on 4 M elements), fixed summation orders.
+ * workspace: gip_sparsity_workspace_bytes() bytes, kept between forward and backward;
  * after forward: ((float*)workspace)[0] = max(depth), [1] = the term.  backward: g_depth[i] = d term / d depth[i] * g_loss[0] * mult
  * (the maximum's share through the denominator goes evenly to the elements equal to it, like torch.max()'s backward). */
 size_t gip_sparsity_workspace_bytes(void);
@@ -93,6 +93,12 @@ int gip_activate_gaussians(const float* opacity_raw, const float* scaling_raw, c
 int gip_activate_gaussians_backward(const float* opacity, const float* scaling, const float* rotation_raw, const float* g_opacity,
                                     const float* g_scaling, const float* g_rotation, int64_t P, float* d_opacity_raw,
                                     float* d_scaling_raw, float* d_rotation_raw, void* stream);
+
+/* Densification statistics of one step in one launch (threestudio/systems/GaussianIP.py:451-457, gaussian_model.py:420-422):
+ *   grad = sum over the V views of viewspace_grad [V,P,3];  where visible: max_radii2D = max(max_radii2D, radii);
+ *   xyz_gradient_accum += ||grad[:, :2]|| * visible;  denom += visible.   (visible: bytes 0 / 1; radii int32; the rest float32 [P].) */
+int gip_densify_stats(const float* viewspace_grad, int32_t V, int64_t P, const uint8_t* visible, const int32_t* radii,
+                      float* max_radii2D, float* xyz_gradient_accum, float* denom, void* stream);
 #ifdef __cplusplus
 }
 #endif

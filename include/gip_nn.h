@@ -261,7 +261,8 @@ int gip_attention_fwd_strided2_f16(const void* q, const void* k, const void* v, 
  *   grad_out [B,C,H,W] float32 = nan_to_num(clip(w(t) * (guidance_scale (text - null) + (t < t_switch ? null : null - neg))))
  *   (:411-431; weighting 0 "sds" 1 - acp_t, 1 "uniform", 2 "fantasia3d"; clip_threshold <= 0: no clip; the clip's norm runs over
  *   the LAST axis), diff_out = lat32 - (lat32 - grad)  (what the MSE's backward multiplies, :645-653),
- *   scalars[0] = 0.5 sum diff^2 / B  (loss_sds), scalars[1] = ||grad||_2  (grad_norm).  One workgroup.
+ *   scalars[0] = 0.5 sum diff^2 / B  (loss_sds), scalars[1] = ||grad||_2  (grad_norm); one wave per (b, h) row (W <= 64 with
+ *   the clip), fixed summation order.
  * gip_scale_cast_f16: out[i] = half(x[i] * scale[0] * mult)  (scale: a device scalar, e.g. the upstream gradient of the loss). */
 int gip_image_prep_f16(const float* rgb, int32_t B, int32_t C, int32_t Hout, int32_t Wout, void* out, void* stream);
 int gip_image_prep_backward_f16(const void* g_out, int32_t B, int32_t C, int32_t Hout, int32_t Wout, float* g_rgb, void* stream);
@@ -273,8 +274,12 @@ int gip_latent_sample_backward_f16(const void* moments, const int64_t* m_strides
 int gip_anpg_loss_f16(const void* noise_pred, const int64_t* np_strides, const void* latents, const int64_t* lat_strides,
                       const int64_t* t, const float* acp, int32_t B, int32_t C, int32_t H, int32_t W, float guidance_scale,
                       int32_t t_switch, int32_t weighting, float clip_threshold, float* grad_out, float* diff_out,
-                      float* scalars, void* stream);
+                      float* scalars, float* partials /* [B * H][2] scratch */, void* stream);
 int gip_scale_cast_f16(const float* x, const float* scale, float mult, void* out, int64_t n, void* stream);
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) as one launch: out [B, dim] half =
+ * [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(max_period) k / (dim / 2)), float32 arithmetic, t [B] int64
+ * (the U-Net's / ControlNet's time_proj, driven by ipa_guidance.py:311-358). */
+int gip_timestep_embedding_f16(const int64_t* t, int32_t B, int32_t dim, float max_period, void* out, void* stream);
 #ifdef __cplusplus
 }
 #endif

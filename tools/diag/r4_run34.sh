@@ -1,0 +1,2 @@
+#!/bin/bash
+python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r4_run34_tests.txt
