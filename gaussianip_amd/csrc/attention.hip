@@ -409,6 +409,227 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     }
 }
 
+// ---- two query tiles per wave (long self-attention, one key set) -----------------------------------------------------------------
+// The loop above runs its S^T MFMAs, its softmax and its PV MFMAs one after the other, and co-resident waves do not fill the
+// gaps (counters + ablation builds: tools/experiments/attention_pipelined_qk.md).  Here a wave owns TWO 32-query tiles: the K
+// and V^T fragments of a block are read from LDS once for both, and the two tiles' chains are independent, so inside ONE wave
+// the matrix pipe works on one tile's products while the vector unit does the other tile's softmax.  Same arithmetic per
+// (query, key): bit-identical outputs.  64 * NW queries per workgroup.
+template <int D, int NW>
+__global__ void __launch_bounds__(64 * NW, 2)
+attn_fwd_q2_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
+                   _Float16* __restrict__ o, int Nq, int Nkv, int H, float c, int ld_kv, int ld_q, int xcd_remap) {
+  static_assert(D % 8 == 0 && D <= 64, "head dim");
+  constexpr int AT_ROW = 128;
+  constexpr int AT_TILE = AT_BKV * AT_ROW;
+  constexpr int NS = (D + 15) / 16, ND = (D + 31) / 32, CH = D / 8;
+  constexpr int NT = 64 * NW;
+  constexpr int PER = (AT_BKV * CH + NT - 1) / NT;
+  constexpr bool L_FROM_MFMA = (D % 32) != 0;
+  constexpr int L_TILE = D / 32, L_ROW = D % 32;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 2 * AT_TILE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_remap) {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    if ((total & 7) == 0) {
+      const int lin = by * gx + bx, nl = (lin & 7) * (total >> 3) + (lin >> 3);
+      by = nl / gx;
+      bx = nl - by * gx;
+    }
+  }
+  const int b = by / H, h = by - b * H;
+  const int C = H * D;
+  const int q0 = bx * (64 * NW) + wave * 64;
+  bool q_valid[2];
+  f16x8 qf[2][NS];
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++) {
+    q_valid[qt] = q0 + 32 * qt < Nq;
+    const _Float16* qp = q + ((size_t)b * Nq + q0 + 32 * qt + r) * ld_q + h * D;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int d0 = 16 * s + 8 * hh;
+      Frag8 f;
+      f.u = make_uint4(0, 0, 0, 0);
+      if (d0 < D && q_valid[qt]) f.u = *(const uint4*)(qp + d0);
+      qf[qt][s] = f.v;
+    }
+  }
+  for (int i = tid * 16; i < 2 * 2 * AT_TILE; i += NT * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
+  if constexpr (L_FROM_MFMA) {
+    __syncthreads();
+    if (tid < 2 * AT_BKV) {
+      const int stage = tid / AT_BKV, row = tid % AT_BKV, lch = D / 8;
+      unsigned char* p = smem + stage * 2 * AT_TILE + AT_TILE + row * AT_ROW + ((lch ^ vswz<AT_ROW>(row)) << 4) + (D % 8) * 2;
+      *(_Float16*)p = (_Float16)1.0f;
+    }
+  }
+  static_assert(PER >= 1 && PER <= 5 && NT * PER < 3 * AT_BKV * CH, "staging chunks per thread");
+#define AT_SLOT(e)                                                                                        \
+  int idx##e = tid + NT * e;                                                                              \
+  if (idx##e >= AT_BKV * CH) idx##e -= AT_BKV * CH;                                                       \
+  if (idx##e >= AT_BKV * CH) idx##e -= AT_BKV * CH;                                                       \
+  const int row##e = idx##e / CH, ch##e = idx##e - row##e * CH;                                           \
+  const int kl##e = row##e * AT_ROW + ((ch##e ^ kswz<AT_ROW>(row##e)) << 4);                              \
+  const int vl##e = AT_TILE + row##e * AT_ROW + ((ch##e ^ vswz<AT_ROW>(row##e)) << 4);                    \
+  uint4 kr##e = make_uint4(0, 0, 0, 0), vr##e = make_uint4(0, 0, 0, 0);
+  AT_SLOT(0) AT_SLOT(1) AT_SLOT(2) AT_SLOT(3) AT_SLOT(4)
+#undef AT_SLOT
+  const int k_row_off = r * AT_ROW, k_swz = kswz<AT_ROW>(r);
+  const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, half16 = (lane >> 4) & 1;
+
+  f32x16 O[2][ND];
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) O[qt][dt][i] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  const int n_keys = Nkv;
+  const size_t ld = (size_t)ld_kv;
+  const _Float16* kp = k + (size_t)b * n_keys * ld + h * D;
+  const _Float16* vp = v + (size_t)b * n_keys * ld + h * D;
+
+  AT_FETCH(0);
+  __syncthreads();
+  AT_DEPOSIT(0);
+  __syncthreads();
+  const int NB = (n_keys + AT_BKV - 1) / AT_BKV;
+  for (int blk = 0; blk < NB; blk++) {
+    const int stage = blk & 1;
+    const unsigned char* sk = smem + stage * 2 * AT_TILE;
+    const int nblk = blk + 1 < NB ? blk + 1 : blk;
+    AT_FETCH(nblk);
+
+    // ---- S^T = K Q^T: every K fragment feeds both query tiles ----
+    f32x16 S[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) S[qt][t][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++) S[qt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[qt][s], S[qt][t], 0, 0, 0);
+      }
+
+    // ---- V^T fragments (shared by both tiles) ----
+    const unsigned char* sv = sk + AT_TILE;
+    Frag8 vt[ND][2][2];
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++) {
+      const int col = dt * 32 + 16 * half16 + 4 * p4;
+      const int lch = col >> 3, sub = (p4 & 1) * 8;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          const int row = t * 32 + 16 * s2 + 4 * hh + q4;
+          const int off = row * AT_ROW + ((lch ^ vswz<AT_ROW>(row)) << 4) + sub;
+          vt[dt][t][s2].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off));
+          vt[dt][t][s2].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off + 8 * AT_ROW));
+        }
+    }
+
+    if (blk * AT_BKV + AT_BKV > n_keys) {
+#pragma unroll
+      for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            if (blk * AT_BKV + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= n_keys) S[qt][t][i] = -INFINITY;
+    }
+
+    // ---- per tile: online softmax, then O^T += V^T P^T (tile 1's softmax has tile 0's PV MFMAs to run beside) ----
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+      float mloc = S[qt][0][0];
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, S[qt][t][i]);
+      mloc = at_half_max(mloc);
+      const bool raise = (mloc - m_run[qt]) * c > AT_DEFER;
+      if (__any(raise)) {
+        const float m_new = fmaxf(m_run[qt], mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
+        if constexpr (!L_FROM_MFMA) l_run[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) O[qt][dt][i] *= alpha;
+        m_run[qt] = m_new;
+      }
+      const float mc = m_run[qt] * c;
+      Frag8 P[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[qt][t][8 * s2 + j], c, -mc));
+            if constexpr (!L_FROM_MFMA) l_run[qt] += p;
+            P[t][s2].v[j] = (_Float16)p;
+          }
+#pragma unroll
+      for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++)
+            O[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[qt][dt], 0, 0, 0);
+    }
+
+    if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++) {
+    float l_tot;
+    if constexpr (L_FROM_MFMA) {
+      constexpr int reg = (L_ROW & 3) + 4 * (L_ROW >> 3), half = (L_ROW >> 2) & 1;
+      const float mine = O[qt][L_TILE][reg];
+      const float other = __shfl_xor(mine, 32);
+      l_tot = (hh == half) ? mine : other;
+    } else {
+      l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+    }
+    const float inv = 1.f / l_tot;
+    _Float16* op = o + ((size_t)b * Nq + q0 + 32 * qt + r) * C + h * D;
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int d = dt * 32 + 8 * i + 4 * hh;
+        if (d < D && q_valid[qt]) {
+          f16x4 w;
+#pragma unroll
+          for (int j = 0; j < 4; j++) w[j] = (_Float16)(O[qt][dt][4 * i + j] * inv);
+          *(f16x4*)(op + d) = w;
+        }
+      }
+  }
+}
+
+template <int D, int NW>
+static void launch_attn_q2(hipStream_t s, const void* q, const void* k, const void* v, void* o, int BH, int Nq, int Nkv, int H, float c,
+                           int ld_kv, int ld_q) {
+  static const int xcd = [] { const char* e = getenv("GIP_ATTN_XCD"); return e && *e ? atoi(e) : 1; }();
+  const dim3 grid((Nq + 64 * NW - 1) / (64 * NW), BH);
+  hipLaunchKernelGGL((attn_fwd_q2_kernel<D, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                     (_Float16*)o, Nq, Nkv, H, c, ld_kv, ld_q, xcd);
+}
+
 template <int D, bool SPLIT>
 static void launch_attn2(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
                          float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
@@ -459,6 +680,16 @@ extern "C" int gip_attention_fwd_strided2_f16(const void* q, const void* k, cons
   // halve that stream: 0.44 -> 0.41 ms at batch 12, 0.155 -> 0.138 at batch 4 (one workgroup per CU, so only where >= 512
   // workgroups remain; D = 80 at 1024 keys measured slower).  GIP_ATTN_NW = 4: the plain loop everywhere (A/B), 8: wherever supported
   static const int nw = [] { const char* e = getenv("GIP_ATTN_NW"); return e && *e ? atoi(e) : 0; }();
+  // Two query tiles per wave, 8 waves (512 queries) per workgroup for the long D = 40 layers that leave >= 192 workgroups
+  // (attn_fwd_q2_kernel): one wave's matrix and vector work overlap across its two tiles and the K / V stream per query is a
+  // quarter of the plain loop's.  Same box, bit-identical outputs: 0.44 -> 0.39 ms at batch 12 on a slow box (0.365 on a fast
+  // one), 0.150 -> 0.141 at batch 4, 1.11 -> 0.99 at 16384 keys (refine).  GIP_ATTN_QT = 1: off (A/B); 2: wherever supported
+  static const int qt2 = [] { const char* e = getenv("GIP_ATTN_QT"); return e && *e ? atoi(e) : 0; }();
+  if (qt2 != 1 && !k2 && D == 40 && Nkv >= 1024 && Nq % 64 == 0 && (qt2 == 2 || ((Nq + 511) / 512) * B * H >= 192)) {
+    if (nw == 4) launch_attn_q2<40, 4>(s, q, k, v, o, B * H, Nq, Nkv, H, c, ld_kv, ld_q);
+    else launch_attn_q2<40, 8>(s, q, k, v, o, B * H, Nq, Nkv, H, c, ld_kv, ld_q);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
   if (!k2 && D == 40 && Nkv >= 1024 && Nq % 256 == 0 && nw != 4 && (nw == 8 || (Nq / 256) * B * H >= 512)) {
     launch_attn_wide<40, 8>(s, q, k, v, o, B * H, Nq, Nkv, H, c, ld_kv, ld_q);
     return hipGetLastError() == hipSuccess ? 0 : 3;
