@@ -690,16 +690,6 @@ extern "C" int gip_attention_fwd_strided2_f16(const void* q, const void* k, cons
     else launch_attn_q2<40, 8>(s, q, k, v, o, B * H, Nq, Nkv, H, c, ld_kv, ld_q);
     return hipGetLastError() == hipSuccess ? 0 : 3;
   }
-  // GIP_ATTN_CROSS8 = 1 (experiment): the decoupled cross-attention of the 64 x 64 level (two short key sets, 4096 queries) with 8
-  // waves per workgroup: a quarter of the workgroups, each clearing / staging its LDS once for 256 queries
-  static const int cross8 = [] { const char* e = getenv("GIP_ATTN_CROSS8"); return e && *e ? atoi(e) : 0; }();
-  if (cross8 && k2 && D == 40 && Nq % 256 == 0 && (Nq / 256) * B * H >= 512) {
-    static const int xcd = [] { const char* e = getenv("GIP_ATTN_XCD"); return e && *e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL((attn_fwd_kernel<40, true, false, 8>), dim3(Nq / 256, B * H), dim3(512), 0, s, (const _Float16*)q, (const _Float16*)k,
-                       (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, weight2, ld_kv,
-                       ld_kv2, ld_q, xcd);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
-  }
   if (!k2 && D == 40 && Nkv >= 1024 && Nq % 256 == 0 && nw != 4 && (nw == 8 || (Nq / 256) * B * H >= 512)) {
     launch_attn_wide<40, 8>(s, q, k, v, o, B * H, Nq, Nkv, H, c, ld_kv, ld_q);
     return hipGetLastError() == hipSuccess ? 0 : 3;
