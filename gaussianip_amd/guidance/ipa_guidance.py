@@ -227,7 +227,7 @@ class StableDiffusionGuidance:
             return self.controlnet.embed_condition(cond)
 
     def forward_unet(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet=True,
-                     control_embedding=None, replicas=1, **_unused):
+                     control_embedding=None, replicas=1, borrow_output=False, **_unused):
         """`replicas` = r: the batch is r copies of the same (latents, t, pose map) with different prompt embeddings
         (ANPG: 3, classifier-free guidance: 2); the layers in front of the first cross-attention then run on one copy
         (networks._Encoder.encode) — identical algebra."""
@@ -235,13 +235,14 @@ class StableDiffusionGuidance:
             replicas = 1
         if (_GRAPH_DENOISE and noisy_latents.is_cuda and control_embedding is None and control_img is not None and
                 not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
-            return self._forward_unet_graph(noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet, replicas)
+            return self._forward_unet_graph(noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet, replicas,
+                                            borrow_output)
         return self._forward_unet_eager(noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet,
                                         control_embedding, replicas)
 
     _graphs = None
 
-    def _forward_unet_graph(self, noisy_latents, control_img, t, ctx, use_pose, replicas):
+    def _forward_unet_graph(self, noisy_latents, control_img, t, ctx, use_pose, replicas, borrow_output=False):
         """GIP_GRAPH_DENOISE=1: the frozen, fixed-shape denoise (~700 launches on two streams) as ONE HIP-graph launch per call.
         The GPU time is the same (measured: 24.7 vs 24.6 ms); it saves host time — 16.5 -> 9 ms of the 40 ms the host needs
         to enqueue a training step.  On the pool's hosts the step is GPU-bound either way (43.3-44.0 eager vs 43.6-43.7 ms
@@ -268,7 +269,9 @@ class StableDiffusionGuidance:
         for d_, s_ in zip(static, (noisy_latents, control_img, t, ctx)):
             d_.copy_(s_)
         graph.replay()
-        return out.clone()
+        # `borrow_output`: the caller consumes the prediction before the next replay (same stream) and does not keep it:
+        # the graph's own output buffer is handed out instead of a copy
+        return out if borrow_output else out.clone()
 
     def _forward_unet_eager(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet, control_embedding,
                             replicas):
@@ -468,7 +471,7 @@ class StableDiffusionGuidance:
             embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 3)
         assert embeds.shape[1] == TEXT_TOKENS + IP_TOKENS
         with torch.no_grad():
-            noise_pred = self.forward_unet(latents_noisy, control, t.repeat(3), embeds, use_pose_controlnet, replicas=3)
+            noise_pred = self.forward_unet(latents_noisy, control, t.repeat(3), embeds, use_pose_controlnet, replicas=3, borrow_output=True)
         clip = self.cfg.grad_clip_threshold if self.cfg.grad_clip_pixel else None
         loss_sds, grad, grad_norm = glue.anpg_loss(latents, noise_pred, t, self.alphas, self.cfg.guidance_scale,
                                                    self.cfg.weighting_strategy, clip)

@@ -381,6 +381,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(color, depth, alpha)
         ctx.mark_non_differentiable(radii)
+        # outputs nobody differentiated (alpha in the training step) reach backward as None = a NULL pointer in GipRasterGradsIn,
+        # which the kernels treat as zero — instead of autograd filling a [V, 1, H, W] tensor of zeros for the kernel to read
+        ctx.set_materialize_grads(False)
         return color, radii, depth, alpha
 
     @staticmethod
@@ -393,6 +396,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 return None
             return g.float().contiguous()
 
+        if g_color is None and g_depth is None and g_alpha is None:          # nothing upstream: the zero gradient, no launch
+            z = lambda t: None if t is None else torch.zeros_like(t)  # noqa: E731
+            g2d = None if ctx.means2D_shape is None else torch.zeros(ctx.means2D_shape, dtype=torch.float32, device=plan.means3D.device)
+            return (z(plan.means3D), g2d, z(plan.shs), z(plan.colors_precomp), z(plan.opacities), z(plan.scales), z(plan.rotations),
+                    z(plan.cov3D_precomp), None, None)
         g = _run_backward(plan, (color, depth, alpha), prep(g_color), prep(g_depth), prep(g_alpha))
         # The deferred overflow check runs AFTER the backward kernels are enqueued: waiting for the forward's header copy
         # then overlaps with GPU work instead of idling the device when backward follows forward immediately.  The
