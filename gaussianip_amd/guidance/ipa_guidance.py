@@ -327,7 +327,7 @@ class StableDiffusionGuidance:
             if (_GRAPH_VAE and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and self.cfg.channels_last and
                     not torch.cuda.is_current_stream_capturing()):
                 return self._encode_graphed(x, generator).to(imgs.dtype)
-            return self.vae.sample(self._vae_moments(x), generator).to(imgs.dtype)
+            return self._vae_encode(x, generator).to(imgs.dtype)
 
     def _moments(self, x):
         """The VAE encoder's (mean | logvar) of an already prepared image (half, channels-last, in [-1, 1])."""
@@ -335,6 +335,12 @@ class StableDiffusionGuidance:
             if _GRAPH_VAE and x.requires_grad and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
                 return self._encode_graphed(x, None, moments_only=True)
             return self._vae_moments(x)
+
+    def _vae_encode(self, x, generator):
+        """vae.encode(x, generator) (any module with that method); the two-stream form needs the moments / sample split."""
+        if _VAE_STREAMS < 2 or not hasattr(self.vae, "moments"):
+            return self.vae.encode(x, generator)
+        return self.vae.sample(self._vae_moments(x), generator)
 
     def _vae_moments(self, x):
         """vae.moments(x), with GIP_VAE_STREAMS=2 as two half batches on two streams (same kernels per image, same values)."""
@@ -364,7 +370,7 @@ class StableDiffusionGuidance:
         ent = self._vae_graphs.get(key)
         if ent is None:
             self._vae_graphs[key] = "warm"
-            return self._vae_moments(x) if moments_only else self.vae.sample(self._vae_moments(x), generator)
+            return self._vae_moments(x) if moments_only else self._vae_encode(x, generator)
         if ent == "warm":
             sample = torch.zeros_like(x, memory_format=torch.channels_last).requires_grad_(True)
             ent = self._vae_graphs[key] = torch.cuda.make_graphed_callables(lambda t_: self._vae_moments(t_), (sample,), num_warmup_iters=2)
@@ -375,7 +381,7 @@ class StableDiffusionGuidance:
             self._vae_live = {}
         live = self._vae_live.get(key)
         if live is not None and live[0]() is not None and not live[1][0]:
-            return self._vae_moments(x) if moments_only else self.vae.sample(self._vae_moments(x), generator)
+            return self._vae_moments(x) if moments_only else self._vae_encode(x, generator)
         import weakref
         moments = ent(x)
         done = [False]
