@@ -225,6 +225,8 @@ def nn_lib():
         lib.gip_winograd_output_stats_f16.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]
         lib.gip_conv3x3_fewch_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_fewch_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 7 + [_vp]
+        lib.gip_conv3x3_c3_fwd_stats_nhwc_f16.restype = ctypes.c_int
+        lib.gip_conv3x3_c3_fwd_stats_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp, _vp]
         lib.gip_conv3x3_c3_fwd_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3_c3_fwd_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]
         lib.gip_conv3x3_c3_dgrad_nhwc_f16.restype = ctypes.c_int
@@ -267,6 +269,8 @@ def nn_lib():
         lib.gip_attention_fwd_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [ctypes.c_float, _vp, _vp, ctypes.c_int32, ctypes.c_float, _vp]
         lib.gip_attention_fwd_strided_f16.restype = ctypes.c_int
         lib.gip_attention_fwd_strided_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [ctypes.c_float, _vp, _vp, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, ctypes.c_int32, _vp]
+        lib.gip_conv3x3s2_stats_nhwc_f16.restype = ctypes.c_int
+        lib.gip_conv3x3s2_stats_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 7 + [_vp, _vp]
         lib.gip_conv3x3s2_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3s2_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 7 + [_vp, ctypes.c_size_t, _vp]
         lib.gip_linear_row_parts.restype = ctypes.c_int32

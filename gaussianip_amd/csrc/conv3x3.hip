@@ -1259,6 +1259,23 @@ extern "C" int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* 
               : launch<128, 2, 9, false>(x, w, bias, nullptr, out, N, H, W, Cin, Cout, s, workspace, workspace_bytes, Hin, Win, geom);
 }
 
+// The same stride-2 convolution whose epilogue also leaves the NEXT GroupNorm's statistics (per 128 output pixels and channel,
+// like gip_conv3x3_stats_nhwc_f16): the ResnetBlock2D behind every Downsample2D then reads its input once.  Whole-K tiles only.
+extern "C" int gip_conv3x3s2_stats_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin,
+                                            int32_t Win, int32_t Cin, int32_t Cout, int32_t pad_top, int32_t pad_left,
+                                            float* chan_stats, void* stream) {
+  if (!x || !w || !out || !chan_stats || N < 1 || Hin < 2 || Win < 2 || (Hin & 1) || (Win & 1) || Cin < CV_BK || Cin % CV_BK ||
+      Cout < 8 || (Cout & 7) || pad_top < 0 || pad_top > 1 || pad_left < 0 || pad_left > 1)
+    return 1;
+  if (!fits32((long long)N * Hin * Win, Cin, Cout, Cout, 9)) return 1;
+  const int H = Hin / 2, W = Win / 2, geom = 2 | (pad_top << 8) | (pad_left << 16);
+  if (((long long)H * W) % 128) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  return wide ? launch<160, 2, 9, false>(x, w, bias, nullptr, out, N, H, W, Cin, Cout, s, nullptr, 0, Hin, Win, geom, chan_stats)
+              : launch<128, 2, 9, false>(x, w, bias, nullptr, out, N, H, W, Cin, Cout, s, nullptr, 0, Hin, Win, geom, chan_stats);
+}
+
 // Data gradient of the 3x3 / stride 2 convolution y[oy][ox] = sum x[2 oy + ky][2 ox + kx] w[ky][kx] (input zero beyond its
 // last row / column: the VAE's F.pad(x, (0, 1, 0, 1)) + padding = 0 form).  dx[2 a + pi][2 b + pj] only receives the taps
 // with ky = pi, kx = pj (mod 2): four independent small convolutions over dy's own grid — 4, 2, 2 and 1 taps — each a

@@ -33,10 +33,14 @@ __device__ __forceinline__ _Float16 silu_h(_Float16 h) {      // torch's half Si
   return (_Float16)(v * __builtin_amdgcn_rcpf(1.f + __expf(-v)));      // v_rcp_f32 instead of the IEEE division sequence
 }
 
+// chan_stats (optional): per 16 x 8 half tile (128 pixels: waves 0-1 / 2-3 of the workgroup) and channel the (sum, sum of squares)
+// of the half-rounded outputs, [N * H * W / 128][CO][2] float32 in the convention of conv3x3.hip's statistics epilogue (a
+// block = 128 pixels of ONE sample; consumers only add a sample's blocks): the GroupNorm behind the VAE's conv_in then needs
+// no statistics pass over the 268 MB tensor.
 template <int CO, bool ACT>
 __global__ void __launch_bounds__(256)
 conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w /* [CO][3][3][3] */, const _Float16* __restrict__ bias,
-                   _Float16* __restrict__ out, int H, int W) {
+                   _Float16* __restrict__ out, int H, int W, float* __restrict__ chan_stats = nullptr) {
   constexpr int NI = CO / 16;
   constexpr int IN_W = 18 * 3;                               // halves per patch row
   constexpr int ROWB = CO * 2 + 16;                          // padded output staging row
@@ -77,6 +81,9 @@ conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ 
   }
   __syncthreads();
   unsigned char* so = s_out[wave];
+  f32x4 st_s[NI], st_q[NI];                 // this lane's pixel column x its 4 channels per tile, over the wave's 4 rows
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) { st_s[ni] = (f32x4){0.f, 0.f, 0.f, 0.f}; st_q[ni] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
     const int ty = wave * 4 + i;
@@ -91,6 +98,10 @@ conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ 
       o[0] = (_Float16)acc[0]; o[1] = (_Float16)acc[1]; o[2] = (_Float16)acc[2]; o[3] = (_Float16)acc[3];
       if (ACT) { o[0] = silu_h(o[0]); o[1] = silu_h(o[1]); o[2] = silu_h(o[2]); o[3] = silu_h(o[3]); }
       *(f16x4*)(so + frow * ROWB + (ni * 16 + kq * 4) * 2) = o;
+      if (chan_stats) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float v = (float)o[j]; st_s[ni][j] += v; st_q[ni][j] += v * v; }
+      }
     }
     // the wave's own 16 pixels x CO channels: 16-byte chunks, CO / 8 lanes per pixel row (only this wave touches `so`)
     _Float16* orow = out + (((size_t)n * H + y0 + ty) * W + x0) * CO;
@@ -99,6 +110,28 @@ conv_c3_fwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ 
     for (int q = lane; q < 16 * CPP; q += 64) {
       const int px = q / CPP, ch = q % CPP;
       *(uint4*)(orow + (size_t)px * CO + ch * 8) = *(const uint4*)(so + px * ROWB + ch * 16);
+    }
+  }
+  if (chan_stats) {
+    // the 16 pixel columns of a channel quadruple sit on the 16 lanes of one DPP row (lane = 16 kq + column): row sums by four
+    // shifts, then the two waves of a half tile through LDS (fixed order: wave 2 h, then 2 h + 1)
+    __shared__ float s_st[4][CO][2];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float a = st_s[ni][j], q = st_q[ni][j];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); q += __shfl_xor(q, d, 64); }
+        if (frow == 0) { s_st[wave][ni * 16 + kq * 4 + j][0] = a; s_st[wave][ni * 16 + kq * 4 + j][1] = q; }
+      }
+    __syncthreads();
+    const size_t blk0 = ((size_t)n * gridDim.x + tile) * 2;
+    for (int e = tid; e < 2 * CO; e += 256) {
+      const int hb = e / CO, c = e - hb * CO;
+      float* dst = chan_stats + ((blk0 + hb) * CO + c) * 2;
+      dst[0] = s_st[2 * hb][c][0] + s_st[2 * hb + 1][c][0];
+      dst[1] = s_st[2 * hb][c][1] + s_st[2 * hb + 1][c][1];
     }
   }
 }
@@ -303,6 +336,15 @@ extern "C" int gip_conv3x3_c3_fwd_nhwc_f16(const void* x, const void* w, const v
   if ((long long)N * H * W * Cout * 2 >= (1ll << 32)) return 1;
   hipLaunchKernelGGL((conv_c3_fwd_kernel<128, false>), dim3((H / 16) * (W / 16), N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, H, W);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_conv3x3_c3_fwd_stats_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t H, int32_t W,
+                                                 int32_t Cout, float* chan_stats, void* stream) {
+  if (!x || !w || !out || !chan_stats || N < 1 || H < 16 || W < 16 || (H & 15) || (W & 15) || Cout != 128) return 1;
+  if ((long long)N * H * W * Cout * 2 >= (1ll << 32)) return 1;
+  hipLaunchKernelGGL((conv_c3_fwd_kernel<128, false>), dim3((H / 16) * (W / 16), N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
+                     (const _Float16*)w, (const _Float16*)bias, (_Float16*)out, H, W, chan_stats);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

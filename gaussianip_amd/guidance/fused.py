@@ -104,7 +104,7 @@ _STATS_ATTR = "_gip_chan_stats"
 _weights_epoch = 0
 _ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_GN_STATS", "GIP_SPLITK_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
               "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
-              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD")
+              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
 
 
 def bump_weights_epoch():
@@ -840,12 +840,22 @@ def _conv_s2_supported(x, w):
             _conv_tiles(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w.shape[0]) >= _MIN_CONV_TILES and x.numel() * 2 < (1 << 31))
 
 
-def _conv_s2_call(x, w, bias, pad):
-    """3x3 / stride 2 through the MFMA kernel; pad = 1 (symmetric padding=1) or 0 (F.pad(x, (0, 1, 0, 1)) form)."""
+def _conv_s2_call(x, w, bias, pad, stats=None):
+    """3x3 / stride 2 through the MFMA kernel; pad = 1 (symmetric padding=1) or 0 (F.pad(x, (0, 1, 0, 1)) form).
+    `stats`: a list that receives the output's chan_stats (see producer_stats) when the shape qualifies (whole-K tiles)."""
     N, C, H, W = x.shape
     cout = w.shape[0]
     out = torch.empty((N, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     null = ctypes.c_void_p(None)
+    if (stats is not None and _conv_tiles(N, H // 2, W // 2, cout) >= 256 and ((H // 2) * (W // 2)) % 128 == 0 and cout % 8 == 0 and
+            cout // 32 <= 256 and os.environ.get("GIP_GN_STATS", "1") != "0" and os.environ.get("GIP_CONV_S2_STATS", "1") != "0"):
+        st = torch.empty((N * (H // 2) * (W // 2) // 128, cout, 2), dtype=torch.float32, device=x.device)
+        rc = _lib.nn_lib().gip_conv3x3s2_stats_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias), _p(out), N, H, W, C, cout, pad, pad,
+                                                        _p(st), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_conv3x3s2_stats_nhwc_f16 failed with status %d" % rc)
+        stats.append(st)
+        return out
     ws = _workspace(x.device, _SPLITK_WS_BYTES) if _conv_tiles(N, H // 2, W // 2, cout) < 256 else None
     rc = _lib.nn_lib().gip_conv3x3s2_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias), _p(out), N, H, W, C, cout, pad, pad,
                                               null if ws is None else _p(ws), 0 if ws is None else ws.numel(),
@@ -858,7 +868,8 @@ def _conv_s2_call(x, w, bias, pad):
 def downsample_sym(x, w, bias):
     """diffusers Downsample2D of the U-Net / ControlNet: 3x3, stride 2, padding 1 (frozen, no gradient path needed)."""
     if _conv_s2_supported(x, w) and not (torch.is_grad_enabled() and x.requires_grad):
-        return _conv_s2_call(x, w, bias, 1)
+        holder = []
+        return attach_stats(_conv_s2_call(x, w, bias, 1, holder), holder[0] if holder else None)
     return F.conv2d(x, w, bias, stride=2, padding=1)
 
 
@@ -918,11 +929,11 @@ class _DownsampleAsym(torch.autograd.Function):
     128-channel 512^2 level it replaces a 54 TFLOP/s library kernel (1.44 ms) by ~0.5 ms."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, stats_out=None):
         ctx.save_for_backward(w)
         ctx.x_shape = tuple(x.shape)
         if _conv_s2_supported(x, w):
-            return _conv_s2_call(x, w, bias, 0)
+            return _conv_s2_call(x, w, bias, 0, stats_out)
         return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
 
     @staticmethod
@@ -938,12 +949,12 @@ class _DownsampleAsym(torch.autograd.Function):
                                                             w.shape[0], C, ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream))
             if rc != 0:
                 raise RuntimeError("gip_conv3x3s2_dgrad_nhwc_f16 failed with status %d" % rc)
-            return dx, None, None
+            return dx, None, None, None
         if w.shape[0] > 128:          # measured: the library's backward-data kernels are as fast at 256 / 512 channels
-            return torch.nn.grad.conv2d_input((N, C, H + 1, W + 1), w, dy, stride=2)[:, :, :H, :W], None, None
+            return torch.nn.grad.conv2d_input((N, C, H + 1, W + 1), w, dy, stride=2)[:, :, :H, :W], None, None, None
         up = torch.empty((N, w.shape[0], H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
         up[:, :, 1::2, 1::2] = dy
-        return _conv_call(up, _transposed_weight(w), w.shape[1]), None, None
+        return _conv_call(up, _transposed_weight(w), w.shape[1]), None, None, None
 
 
 def downsample_asym(x, w, bias):
@@ -951,10 +962,11 @@ def downsample_asym(x, w, bias):
     level; at 256 / 512 channels the library's backward-data kernels are as fast)."""
     if (fusable(x) and not w.requires_grad and w.shape[0] % 64 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and
             w.is_contiguous(memory_format=torch.channels_last)):
+        holder = []
         if x.requires_grad and torch.is_grad_enabled():
-            return _DownsampleAsym.apply(x, w, bias)
+            return attach_stats(_DownsampleAsym.apply(x, w, bias, holder), holder[0] if holder else None)
         if _conv_s2_supported(x, w):
-            return _conv_s2_call(x, w, bias, 0)
+            return attach_stats(_conv_s2_call(x, w, bias, 0, holder), holder[0] if holder else None)
     return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
 
 
@@ -974,14 +986,21 @@ class _ConvFewInputChannels(torch.autograd.Function):
     not take fall back to those routes."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, stats_out=None):
         ctx.save_for_backward(w)
         ctx.c3 = _c3_kernels_apply(x, w)
         if ctx.c3:
             N, _, H, W = x.shape
             out = torch.empty((N, 128, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-            rc = _lib.nn_lib().gip_conv3x3_c3_fwd_nhwc_f16(_p(x), _p(w), ctypes.c_void_p(None) if bias is None else _p(bias), _p(out),
-                                                           N, H, W, 128, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            null = ctypes.c_void_p(None)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            if stats_out is not None and os.environ.get("GIP_GN_STATS", "1") != "0" and os.environ.get("GIP_CONV_S2_STATS", "1") != "0":
+                st = torch.empty((N * H * W // 128, 128, 2), dtype=torch.float32, device=x.device)
+                rc = _lib.nn_lib().gip_conv3x3_c3_fwd_stats_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias), _p(out), N, H, W, 128,
+                                                                     _p(st), stream)
+                stats_out.append(st)
+            else:
+                rc = _lib.nn_lib().gip_conv3x3_c3_fwd_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias), _p(out), N, H, W, 128, stream)
             if rc != 0:
                 raise RuntimeError("gip_conv3x3_c3_fwd_nhwc_f16 failed with status %d" % rc)
             return out
@@ -1000,14 +1019,14 @@ class _ConvFewInputChannels(torch.autograd.Function):
                                                              ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream))
             if rc != 0:
                 raise RuntimeError("gip_conv3x3_c3_dgrad_nhwc_f16 failed with status %d" % rc)
-            return dx, None, None
+            return dx, None, None, None
 
         def make(t):
             wt4 = torch.zeros((4, t.shape[0], 3, 3), dtype=t.dtype, device=t.device)
             wt4[:t.shape[1]] = t.detach().flip(2, 3).transpose(0, 1)
             return wt4.contiguous(memory_format=torch.channels_last)
         wt = _wt_cache.get("few", w, make)
-        return _conv_call(dy, wt, 4)[:, :w.shape[1]], None, None
+        return _conv_call(dy, wt, 4)[:, :w.shape[1]], None, None, None
 
 
 # (Cin, Cout, stride) -> output rows per workgroup tile (the output height must be a multiple of it)
@@ -1094,5 +1113,6 @@ def conv3x3_few_inputs(x, w, bias):
             not w.requires_grad and w.shape[1] <= 4 and w.shape[0] % 64 == 0 and
             _conv_tiles(x.shape[0], x.shape[2], x.shape[3], 4) >= _MIN_CONV_TILES and
             x.shape[0] * x.shape[2] * x.shape[3] * w.shape[0] * 2 < (1 << 31)):
-        return _ConvFewInputChannels.apply(x, w, bias)
+        holder = []
+        return attach_stats(_ConvFewInputChannels.apply(x, w, bias, holder), holder[0] if holder else None)
     return F.conv2d(x, w, bias, padding=1)

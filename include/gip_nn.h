@@ -143,6 +143,10 @@ int gip_linear_stats_f16(const void* x, const void* w, const void* bias, const v
  *            (the gradient that leaves the VAE towards the bilinear resize and the rasterizer); H % 8 == 0, W % 16 == 0. */
 int gip_conv3x3_c3_fwd_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t H, int32_t W,
                                 int32_t Cout, void* stream);
+/* The same, leaving the next GroupNorm's statistics: chan_stats [N * H * W / 128][128][2] float32 = (sum, sum of squares) per
+ * 16 x 8 half tile and channel of the half-rounded outputs (AutoencoderKL.encode: conv_in -> down_blocks[0].resnets[0].norm1). */
+int gip_conv3x3_c3_fwd_stats_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t H, int32_t W,
+                                      int32_t Cout, float* chan_stats, void* stream);
 int gip_conv3x3_c3_dgrad_nhwc_f16(const void* dy, const void* wt, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                   void* stream);
 
@@ -164,6 +168,10 @@ int gip_conv3x3_fewch_nhwc_f16(const void* x, const void* w, const void* bias, v
 int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin, int32_t Win,
                            int32_t Cin, int32_t Cout, int32_t pad_top, int32_t pad_left, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* gip_conv3x3s2_nhwc_f16 whose epilogue also takes the next GroupNorm's statistics: chan_stats [N * (Hin/2) * (Win/2) / 128][Cout][2]
+ * float32 (sum, sum of squares per 128 output pixels and channel; (Hin/2) * (Win/2) % 128 == 0, Cout % 8 == 0, no split-K). */
+int gip_conv3x3s2_stats_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin, int32_t Win,
+                                 int32_t Cin, int32_t Cout, int32_t pad_top, int32_t pad_left, float* chan_stats, void* stream);
 
 /* DATA GRADIENT of that stride-2 convolution in its pad_top = pad_left = 0 form (the VAE's Downsample2D, whose gradient the
  * reference gets from autograd through AutoencoderKL.encode, ipa_guidance.py:309-314): dy [N,Ho,Wo,Cin] half (Cin = the forward

@@ -104,7 +104,7 @@ def test_three_full_ahds_steps(rig):
     # and the hand-written HIP path is what ran
     ran = {k: _lib.call_counts.get(k, 0) - before.get(k, 0) for k in _lib.call_counts}
     for sym in ("gip_raster_forward", "gip_raster_backward", "gip_openpose_draw", "gip_conv3x3_nhwc_f16",
-                "gip_attention_fwd_strided2_f16", "gip_adam_step", "gip_conv3x3_c3_fwd_nhwc_f16", "gip_conv3x3_c3_dgrad_nhwc_f16", "gip_gn_silu_forward", "gip_gn_silu_backward", "gip_layernorm_f16",
+                "gip_attention_fwd_strided2_f16", "gip_adam_step", "gip_conv3x3_c3_fwd_stats_nhwc_f16", "gip_conv3x3s2_stats_nhwc_f16", "gip_conv3x3_c3_dgrad_nhwc_f16", "gip_gn_silu_forward", "gip_gn_silu_backward", "gip_layernorm_f16",
                 "gip_conv3x3_stats_ws_nhwc_f16", "gip_linear_stats_f16", "gip_gn_silu_forward_stats", "gip_cat2_stats_f16",
                     "gip_conv3x3_fewch_nhwc_f16", "gip_upsample2x_conv3x3_nhwc_f16", "gip_conv3x3s2_dgrad_nhwc_f16"):
         assert ran.get(sym, 0) >= (4 if sym.startswith("gip_raster") or sym == "gip_openpose_draw" else 2), (sym, ran.get(sym, 0))

@@ -273,10 +273,11 @@ def test_vae_conv_in_and_its_data_gradient(shape):
     w = (torch.randn(128, 3, 3, 3, device="cuda", generator=g) / 5.0).half().contiguous(**cl)
     b = torch.randn(128, device="cuda", generator=g).half()
     dy = torch.randn(N, 128, H, W, device="cuda", generator=g).half().contiguous(**cl)
-    before = (_lib.call_counts.get("gip_conv3x3_c3_fwd_nhwc_f16", 0), _lib.call_counts.get("gip_conv3x3_c3_dgrad_nhwc_f16", 0))
+    fwd = lambda: _lib.call_counts.get("gip_conv3x3_c3_fwd_nhwc_f16", 0) + _lib.call_counts.get("gip_conv3x3_c3_fwd_stats_nhwc_f16", 0)  # noqa: E731
+    before = (fwd(), _lib.call_counts.get("gip_conv3x3_c3_dgrad_nhwc_f16", 0))
     y = fused.conv3x3_few_inputs(x, w, b)
     (dx,) = torch.autograd.grad(y, x, dy)
-    ran = (_lib.call_counts.get("gip_conv3x3_c3_fwd_nhwc_f16", 0) - before[0], _lib.call_counts.get("gip_conv3x3_c3_dgrad_nhwc_f16", 0) - before[1])
+    ran = (fwd() - before[0], _lib.call_counts.get("gip_conv3x3_c3_dgrad_nhwc_f16", 0) - before[1])
     assert ran == ((1, 1) if H % 16 == 0 and W % 16 == 0 else (0, 0))
     xr = x.detach().float().requires_grad_(True)
     yr = F.conv2d(xr, w.float(), b.float(), padding=1)

@@ -283,3 +283,68 @@ def test_skip_concatenation_falls_back_for_shapes_the_kernel_does_not_take():
     h = torch.randn(2, 40, 8, 8, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
     s = torch.randn(2, 24, 8, 8, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
     assert torch.equal(fused.cat_skip(h, s, s), torch.cat([h, s + s], dim=1))
+
+
+@pytest.mark.parametrize("grad", [False, True])
+def test_stride2_convolution_leaves_the_next_groupnorm_its_statistics(grad):
+    """gip_conv3x3s2_stats_nhwc_f16 (the VAE's Downsample2D, F.pad(x, (0, 1, 0, 1)) + stride 2): same output as the kernel without
+    statistics, and per-(128-pixel block, channel) sums of exactly that output attached to it; also through the autograd node."""
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(11)
+    cl = dict(memory_format=torch.channels_last)
+    N, C, H, W, co = 4, 128, 256, 256, 128                                     # 4 x 128^2 output pixels = 512 tiles
+    x = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(co, C, 3, 3, device="cuda", generator=g) / (3 * C ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(co, device="cuda", generator=g).half()
+    xin = x.clone(**cl).requires_grad_(True) if grad else x
+    out = fused.downsample_asym(xin, w, b)
+    st = fused.producer_stats(out)
+    assert st is not None and st.shape == (N * (H // 2) * (W // 2) // 128, co, 2)
+    rows = out.detach().permute(0, 2, 3, 1).reshape(-1, 128, co).double()
+    want = torch.stack([rows.sum(1), (rows * rows).sum(1)], dim=-1)
+    assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+    assert float((out.detach().float() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+    import os
+    os.environ["GIP_CONV_S2_STATS"] = "0"
+    try:
+        plain = fused.downsample_asym(x, w, b)
+    finally:
+        del os.environ["GIP_CONV_S2_STATS"]
+    assert fused.producer_stats(plain) is None and torch.equal(plain, out.detach())
+    if grad:
+        out.float().square().sum().backward()
+        assert xin.grad is not None and torch.isfinite(xin.grad).all()
+
+
+def test_vae_conv_in_leaves_the_first_groupnorm_its_statistics():
+    """gip_conv3x3_c3_fwd_stats_nhwc_f16 (3 -> 128 channels, the VAE encoder's conv_in): identical output to the kernel without
+    statistics, per-(16 x 8 half tile, channel) sums of that output attached to it, and its image gradient unchanged."""
+    import os
+
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(12)
+    cl = dict(memory_format=torch.channels_last)
+    N, H, W = 2, 128, 256
+    x = torch.randn(N, 3, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(128, 3, 3, 3, device="cuda", generator=g) / 5.0).half().contiguous(**cl)
+    b = torch.randn(128, device="cuda", generator=g).half()
+    a = x.clone(**cl).requires_grad_(True)
+    out = fused.conv3x3_few_inputs(a, w, b)
+    st = fused.producer_stats(out)
+    assert st is not None and st.shape == (N * H * W // 128, 128, 2)
+    # block (n, tile, half) = rows 8 half .. 8 half + 7 of the 16 x 16 tile
+    t = out.detach().permute(0, 2, 3, 1).reshape(N, H // 16, 2, 8, W // 16, 16, 128).permute(0, 1, 4, 2, 3, 5, 6).reshape(-1, 128, 128).double()
+    want = torch.stack([t.sum(1), (t * t).sum(1)], dim=-1)
+    assert float((st.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    os.environ["GIP_CONV_S2_STATS"] = "0"
+    try:
+        c = x.clone(**cl).requires_grad_(True)
+        plain = fused.conv3x3_few_inputs(c, w, b)
+    finally:
+        del os.environ["GIP_CONV_S2_STATS"]
+    assert fused.producer_stats(plain) is None and torch.equal(plain, out)
+    up = torch.randn(out.shape, device="cuda", generator=g).half().contiguous(**cl)
+    out.backward(up)
+    plain.backward(up)
+    assert torch.equal(a.grad, c.grad)
