@@ -25,10 +25,6 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef AT_PK_FMA
-#define AT_PK_FMA 0
-#endif
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -41,24 +37,9 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 template <int ROWB> __device__ __forceinline__ int kswz(int row) { return ROWB == 128 ? ((row >> 1) & 7) : (row & 15); }
 template <int ROWB> __device__ __forceinline__ int vswz(int row) { return ROWB == 128 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
 #define AT_DEFER 8.0f
-#ifndef AT_OPT
-#define AT_OPT 0
-#endif
-#ifndef AT_NW8_WAVES
-#define AT_NW8_WAVES 2
-#endif
-#ifndef AT_DIAG
-#define AT_DIAG 0      // timing diagnostics only (wrong results): 1 = no exp2, 2 = no PV MFMAs, 4 = no S^T MFMAs
-#endif
-// max over the two lane halves without the LDS round trip of ds_bpermute (v_permlane32_swap: a = [a_lo | b_lo], b = [a_hi | b_hi])
+// max over the two lane halves (the v_permlane32_swap form measured the same as this ds_bpermute: DESIGN.md section 4d)
 __device__ __forceinline__ float at_half_max(float v) {
-#if AT_OPT & 1
-  float a = v, b = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return fmaxf(a, b);
-#else
   return fmaxf(v, __shfl_xor(v, 32));
-#endif
 }
 
 union Frag8 {
@@ -72,7 +53,7 @@ union Frag8 {
 // depend on its own three MFMAs only, so they run while tile 1's are in the matrix pipe, and tile 1's vector work runs under
 // tile 0's PV MFMAs — the block-wide maximum made every exp2 wait for all six.  Same arithmetic per key (one more raise test).
 template <int D, bool TWO, bool SPLIT, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, D > 128 ? 1 : (NW == 8 && D <= 64 ? AT_NW8_WAVES : 2))   // (threads, waves per SIMD)
+__global__ void __launch_bounds__(64 * NW, D > 128 ? 1 : 2)   // (threads, waves per SIMD)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
                 const _Float16* __restrict__ k2, const _Float16* __restrict__ v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q,
@@ -209,23 +190,6 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 
       // ---- S^T = K Q^T for the two 32-key tiles ----
       f32x16 S[2];
-#if AT_OPT & 4
-      __builtin_amdgcn_s_setprio(1);
-#endif
-#if AT_OPT & 2
-      // the two tiles' accumulation chains interleaved: a dependent MFMA never follows its predecessor directly
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) S[t][i] = 0.f;
-#pragma unroll
-      for (int s = 0; s < NS; s++)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
-          S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
-        }
-#else
 #pragma unroll
       for (int t = 0; t < 2; t++) {
 #pragma unroll
@@ -233,17 +197,9 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
         for (int s = 0; s < NS; s++) {
           const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
-#if AT_DIAG & 4
-          S[t][s] += (float)a[0] * (float)qf[s][1];
-#else
           S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
-#endif
         }
       }
-#endif
-#if AT_OPT & 4
-      __builtin_amdgcn_s_setprio(0);
-#endif
 
       // ---- V^T fragments: issued now, they land while the softmax runs ----
       const unsigned char* sv = sk + AT_TILE;
@@ -336,16 +292,8 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
         for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
           for (int j = 0; j < 8; j += 2) {
-#if AT_DIAG & 1
-            const float p0 = __builtin_fmaf(S[t][8 * s2 + j], c, -mc), p1 = __builtin_fmaf(S[t][8 * s2 + j + 1], c, -mc);
-#elif AT_PK_FMA
-            // the exponent arguments two at a time (v_pk_fma_f32: the accumulator registers are consecutive pairs)
-            const v2f e = __builtin_elementwise_fma((v2f){S[t][8 * s2 + j], S[t][8 * s2 + j + 1]}, (v2f){c, c}, (v2f){-mc, -mc});
-            const float p0 = __builtin_amdgcn_exp2f(e.x), p1 = __builtin_amdgcn_exp2f(e.y);
-#else
             const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
             const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j + 1], c, -mc));
-#endif
             if constexpr (!L_FROM_MFMA) l_run += p0 + p1;
             P[t][s2].v[j] = (_Float16)p0;
             P[t][s2].v[j + 1] = (_Float16)p1;
@@ -358,11 +306,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
         for (int t = 0; t < 2; t++)
 #pragma unroll
           for (int s2 = 0; s2 < 2; s2++)
-#if AT_DIAG & 2
-            O[dt][(t * 2 + s2) & 15] += (float)vt[dt][t][s2].v[0] * (float)P[t][s2].v[1];
-#else
             O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
-#endif
       }
 
       if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
