@@ -379,6 +379,34 @@ def test_guidance_plugin_is_called_like_the_reference_system_calls_it():
         StableDiffusionGuidance({"no_such_key": 1}, device="cpu", unet=_TinyUNet(), controlnet=_TinyControlNet(), vae=_TinyVAE())
 
 
+def test_prompt_table_gather_equals_the_concatenated_embeddings():
+    """`_prompt_embeds_anpg_table` (one gather from a [3 * 13, 81, 768] table, built once) against `_prompt_embeds(..., 3)`
+    (ipa_guidance.py:462-470: two table lookups and four concatenations per step) for every view direction, with the
+    image-prompt tokens tiled by prepare_for_sds; a replaced token set drops the table."""
+    from gaussianip_amd.guidance import StableDiffusionGuidance
+    from gaussianip_amd.guidance.ahds import AHDSSchedule
+    from gaussianip_amd.guidance.prompts import PromptProcessor
+    g = torch.Generator().manual_seed(3)
+    tokens = (torch.randn(1, 4, 768, generator=g) * 0.1, torch.zeros(1, 4, 768), torch.randn(1, 4, 768, generator=g) * 0.1)
+    gd = StableDiffusionGuidance(_EXP_YAML_GUIDANCE, device="cpu", unet=_TinyUNet(), controlnet=_TinyControlNet(), vae=_TinyVAE(),
+                                 schedule=AHDSSchedule(list(range(2400))), image_embeds_provider=lambda _: tokens)
+    pp = PromptProcessor("a person", lambda texts: torch.stack([torch.randn(77, 768, generator=g) for _ in texts]), negative_prompt="blurry")
+    gd.prepare_for_sds(pp.prompt, pp.negative_prompt, pp.null_prompt)
+    B = 4
+    for az, cen, vis in (([30.0, -100.0, 150.0, 90.0], [0.0, 0.65, 0.0, 0.65], [1.0, 1.0, 0.0, 1.0]),
+                         ([-170.0, 10.0, -45.0, 179.0], [0.65, 0.65, 0.0, 0.0], [0.0, 1.0, 1.0, 0.0])):
+        args = (torch.zeros(B), torch.tensor(az), torch.tensor(cen), torch.tensor(vis), torch.full((B,), 1.5))
+        ref = gd._prompt_embeds(pp(), *args, 3).to(gd.weights_dtype)
+        tab = gd._prompt_embeds_anpg_table(pp(), *args)
+        assert tab is not None and tab.shape == ref.shape == (3 * B, 81, 768) and torch.equal(tab, ref)
+    built = gd._embed_table[1]
+    gd._prompt_embeds_anpg_table(pp(), *args)
+    assert gd._embed_table[1] is built                              # same sources: the table is reused
+    gd.set_image_embeds(tokens[0] * 2, tokens[1], tokens[2])         # [1, 4, 768] rows replaced after prepare_for_sds
+    tab2 = gd._prompt_embeds_anpg_table(pp(), *args)
+    assert tab2 is not None and torch.equal(tab2, gd._prompt_embeds(pp(), *args, 3).to(gd.weights_dtype)) and gd._embed_table[1] is not built
+
+
 def test_stage_three_densify_schedule_matches_reference_quirks(tmp_path):
     """GaussianIP.on_before_optimizer_step, stage 3 branch (GaussianIP.py:476-506): max_radii2D adopted at step 0,
     statistics every step, ONE densify_and_prune at global step 2500 (stage step 100) with the screen-size limit off
