@@ -34,3 +34,18 @@ def test_step_outputs_make_opacity_scale_and_visibility_when_read():
         raise AssertionError("KeyError expected")
     except KeyError:
         pass
+
+
+def test_fused_glue_is_not_offered_for_cpu_tensors_or_other_dtypes():
+    """guidance/glue.py: the single-launch stages exist for fp16 CUDA tensors only; everything else keeps the reference's op chains
+    (there is no CPU implementation behind the kernels)."""
+    from gaussianip_amd.guidance import glue, sds
+    rgb = torch.rand(2, 3, 1024, 1024)
+    assert not glue.image_prep_supported(rgb, (512, 512))
+    moments = torch.randn(2, 8, 64, 64).half()
+    eps = torch.randn(2, 4, 64, 64).half()
+    t = torch.tensor([10, 500])
+    acp = sds.alphas_cumprod()
+    assert not glue.latent_sample_supported(moments, eps, eps, t, acp)
+    assert not glue.anpg_loss_supported(eps, torch.cat([eps] * 3), t, acp, "sds")
+    assert not glue.timestep_embedding_supported(t, torch.float16)
