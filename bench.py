@@ -120,13 +120,15 @@ def _visible_gpus():
         return 0
 
 
-def spawn_ranks(n, cmd, env=None, out=None, err=None):
+def spawn_ranks(n, cmd, env=None, out=None, err=None, timeout=None):
     """Start `n` fresh rank processes of `cmd` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their
     environment, the contract torch.distributed.run gives its workers), wait for all of them, and relay ONE line to `out`:
     the last line of rank 0's stdout that is a JSON object with a "metric" key.  Everything else the ranks print on stdout
     (library banners such as "[Gloo] Rank ..." included) goes to `err`, prefixed by the rank.  Returns the exit code: 0 only
     if every rank exited 0 and rank 0 produced its line; the first failing rank's code otherwise (the remaining ranks are
-    terminated by PID).  The calling process never touches the GPU."""
+    terminated by PID, and killed if they ignore that for 10 s).  `timeout` (seconds, None = none): overall deadline — when
+    it passes with ranks still running (all of them blocked in a rendezvous, say), they are stopped the same way, their
+    output is dumped and the code is 124.  The calling process never touches the GPU."""
     import subprocess
     import threading
     out = sys.stdout if out is None else out
@@ -150,6 +152,16 @@ def spawn_ranks(n, cmd, env=None, out=None, err=None):
         procs.append(p)
         threads.append(t)
     rc, pending = 0, set(range(n))
+    deadline = None if not timeout else time.monotonic() + float(timeout)
+    kill_at = None                      # ranks that were sent SIGTERM and are still alive at this time get SIGKILL
+
+    def stop_others(reason):
+        nonlocal kill_at
+        print("bench.py launcher: %s; stopping the other ranks" % reason, file=err)
+        for q in pending:
+            procs[q].terminate()          # exact PIDs this launcher started
+        kill_at = time.monotonic() + 10.0
+
     while pending:
         for r in sorted(pending):
             code = procs[r].poll()
@@ -158,9 +170,17 @@ def spawn_ranks(n, cmd, env=None, out=None, err=None):
             pending.discard(r)
             if code != 0 and rc == 0:
                 rc = code
-                print("bench.py launcher: rank %d exited with code %d; stopping the other ranks" % (r, code), file=err)
-                for q in pending:
-                    procs[q].terminate()          # exact PIDs this launcher started
+                stop_others("rank %d exited with code %d" % (r, code))
+        if pending and deadline is not None and time.monotonic() > deadline and rc == 0:
+            # every rank may be blocked (a rendezvous that never completes, a peer stuck in a kernel): no rank exits, so
+            # nothing above ever fires — the launcher gives up itself, dumps what the ranks printed and fails
+            rc = 124
+            deadline = None
+            stop_others("no result after %.0f s (--launch-timeout / GIP_BENCH_LAUNCH_TIMEOUT)" % float(timeout))
+        if pending and kill_at is not None and time.monotonic() > kill_at:
+            for q in pending:             # SIGTERM ignored (blocked inside the driver): escalate
+                procs[q].kill()
+            kill_at = None
         time.sleep(0.05)
     for t in threads:
         t.join(timeout=5)
@@ -202,6 +222,9 @@ def main():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact_lists mode measurement")
     ap.add_argument("--no-proxy", action="store_true", help="skip the 1-GPU proxy of one configs[3] rank's shard")
     ap.add_argument("--no-trained", action="store_true", help="skip the secondary raster measurement on a trained-looking state")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 1M-Gaussian per-stage roofline object (BASELINE configs[4])")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("GIP_BENCH_LAUNCH_TIMEOUT", "3600")),
+                    help="--gpus N launcher: seconds after which still-running ranks are stopped and the run fails (0 = never)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -215,7 +238,7 @@ def main():
             # fewer GPUs than ranks (a functional check on a 1-GPU box): RCCL cannot put two ranks on one device, gloo can;
             # the line says so (config.gpus_visible / config.backend) — it is not an N-GPU measurement
             env["GIP_DIST_BACKEND"] = "gloo"
-        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env))
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env, timeout=args.launch_timeout or None))
 
     import numpy as np
     import torch

@@ -48,11 +48,11 @@ union Frag8 {
   uint4 u;
 };
 
-// SPLIT: the online softmax advances per 32-key TILE instead of per 64-key block (maximum, deferred-raise test, exp2 and the PV
-// product of tile 0 before those of tile 1).  The S^T MFMAs of both tiles are still issued first; tile 0's maximum / exp2 then
-// depend on its own three MFMAs only, so they run while tile 1's are in the matrix pipe, and tile 1's vector work runs under
-// tile 0's PV MFMAs — the block-wide maximum made every exp2 wait for all six.  Same arithmetic per key (one more raise test).
-template <int D, bool TWO, bool SPLIT, int NW = 4>
+// TWO: 0 = one key set.  1 = a second key set of at most AT_BKV keys (the decoupled cross-attention's 4 image-prompt tokens,
+// attention_processor_faceid.py:462-466): the first set's result is normalised in place and the second set's probabilities
+// are scaled by w2 / l2 BEFORE their PV product, so both sets share ONE accumulator (the two-accumulator form spilled
+// 68-124 bytes per lane at D = 80 / 160).  2 = a second key set of any length (two accumulators).
+template <int D, int TWO, int NW = 4>
 __global__ void __launch_bounds__(64 * NW, D > 128 ? 1 : 2)   // (threads, waves per SIMD)
 attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
                 _Float16* __restrict__ o, int Nq, int Nkv, int H, float c /* scale * log2(e) */,
@@ -157,8 +157,8 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   const int k_row_off = r * AT_ROW, k_swz = kswz<AT_ROW>(r);       // tile bases are multiples of 32: swizzle term of row = of r
   const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, half16 = (lane >> 4) & 1;
 
-  f32x16 O[ND], Oacc[TWO ? ND : 1];
-  if constexpr (TWO) {
+  f32x16 O[ND], Oacc[TWO == 2 ? ND : 1];
+  if constexpr (TWO == 2) {
 #pragma unroll
     for (int dt = 0; dt < ND; dt++)
 #pragma unroll
@@ -166,7 +166,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
   }
   _Float16* op = o + ((size_t)b * Nq + q0 + r) * C + h * D;
 
-  for (int seg = 0; seg < (TWO ? 2 : 1); seg++) {
+  for (int seg = 0; seg < (TWO == 2 ? 2 : 1); seg++) {
     const int n_keys = seg == 0 ? Nkv : Nkv2;
     const size_t ld = (size_t)(seg == 0 ? ld_kv : ld_kv2);
     const _Float16* kp = (seg == 0 ? k : k2) + (size_t)b * n_keys * ld + h * D;
@@ -229,43 +229,6 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
             if (blk * AT_BKV + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= n_keys) S[t][i] = -INFINITY;
       }
 
-      if constexpr (SPLIT) {
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          // ---- online softmax of this 32-key tile on the lane's query column ----
-          float mloc = S[t][0];
-#pragma unroll
-          for (int i = 1; i < 16; i++) mloc = fmaxf(mloc, S[t][i]);
-          mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-          const bool raise = (mloc - m_run) * c > AT_DEFER;     // true on the first tile (m_run = -inf)
-          if (__any(raise)) {
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            if constexpr (!L_FROM_MFMA) l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < ND; dt++)
-#pragma unroll
-              for (int i = 0; i < 16; i++) O[dt][i] *= alpha;
-            m_run = m_new;
-          }
-          const float mc = m_run * c;
-          Frag8 P[2];
-#pragma unroll
-          for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][8 * s2 + j], c, -mc));
-              if constexpr (!L_FROM_MFMA) l_run += p;
-              P[s2].v[j] = (_Float16)p;
-            }
-          // ---- O^T += V^T P^T for this tile ----
-#pragma unroll
-          for (int dt = 0; dt < ND; dt++)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++)
-              O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[s2].v, O[dt], 0, 0, 0);
-        }
-      } else {
       // ---- online softmax on the lane's query column ----
       float mloc = S[0][0];
 #pragma unroll
@@ -307,7 +270,6 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
 #pragma unroll
           for (int s2 = 0; s2 < 2; s2++)
             O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
-      }
 
       if (blk + 1 < NB) { AT_DEPOSIT(stage ^ 1); }
       __syncthreads();
@@ -325,7 +287,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
       l_tot = l_run + __shfl_xor(l_run, 32);
     }
     const float inv = (seg == 0 ? 1.f : w2) / l_tot;
-    if constexpr (TWO) {
+    if constexpr (TWO == 2) {
 #pragma unroll
       for (int dt = 0; dt < ND; dt++)
 #pragma unroll
@@ -338,6 +300,81 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
     }
   }
 
+  if constexpr (TWO == 1) {
+    // ---- second key set, one block: O (already normalised) += (w2 / l2) * sum_k p2[k] v2[k] ----
+    const int n_keys = Nkv2;
+    const size_t ld = (size_t)ld_kv2;
+    const _Float16* kp = k2 + (size_t)b * n_keys * ld + h * D;
+    const _Float16* vp = v2 + (size_t)b * n_keys * ld + h * D;
+    AT_FETCH(0);
+    __syncthreads();        // every read of the first set's stages is done
+    AT_DEPOSIT(0);
+    __syncthreads();
+    const unsigned char* sk = smem;
+    f32x16 S[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) S[t][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const f16x8 a = *(const f16x8*)(sk + t * 32 * AT_ROW + k_row_off + (((2 * s + hh) ^ k_swz) << 4));
+        S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S[t], 0, 0, 0);
+      }
+    }
+    const unsigned char* sv = sk + AT_TILE;
+    Frag8 vt[ND][2][2];
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++) {
+      const int col = dt * 32 + 16 * half16 + 4 * p4;
+      const int lch = col >> 3, sub = (p4 & 1) * 8;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          const int row = t * 32 + 16 * s2 + 4 * hh + q4;
+          const int off = row * AT_ROW + ((lch ^ vswz<AT_ROW>(row)) << 4) + sub;
+          vt[dt][t][s2].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off));
+          vt[dt][t][s2].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sv + off + 8 * AT_ROW));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= n_keys) S[t][i] = -INFINITY;
+    float mloc = S[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, S[t][i]);
+    const float mc = at_half_max(mloc) * c;
+    float pf[2][16], l2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        pf[t][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][i], c, -mc));
+        l2 += pf[t][i];
+      }
+    l2 += __shfl_xor(l2, 32);
+    const float f = w2 / l2;
+    Frag8 P[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) P[t][s2].v[j] = (_Float16)(pf[t][8 * s2 + j] * f);
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+          O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vt[dt][t][s2].v, P[t][s2].v, O[dt], 0, 0, 0);
+  }
+
   // ---- store: lane holds O^T[d = 32 dt + 8 i + 4 hh + 0..3][query r] in registers 4i..4i+3 ----
 #pragma unroll
   for (int dt = 0; dt < ND; dt++)
@@ -347,7 +384,7 @@ attn_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k, 
       if (d < D && q_valid) {
         f16x4 w;
 #pragma unroll
-        for (int j = 0; j < 4; j++) w[j] = (_Float16)(TWO ? Oacc[dt][4 * i + j] : O[dt][4 * i + j]);
+        for (int j = 0; j < 4; j++) w[j] = (_Float16)(TWO == 2 ? Oacc[dt][4 * i + j] : O[dt][4 * i + j]);
         *(f16x4*)(op + d) = w;
       }
     }
@@ -574,14 +611,17 @@ static void launch_attn_q2(hipStream_t s, const void* q, const void* k, const vo
                      (_Float16*)o, Nq, Nkv, H, c, ld_kv, ld_q, xcd);
 }
 
-template <int D, bool SPLIT>
-static void launch_attn2(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
-                         float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
-  if (k2)
-    hipLaunchKernelGGL((attn_fwd_kernel<D, true, SPLIT>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+template <int D>
+static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
+                        float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
+  if (k2 && Nkv2 <= AT_BKV)
+    hipLaunchKernelGGL((attn_fwd_kernel<D, 1>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                       (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
+  else if (k2)
+    hipLaunchKernelGGL((attn_fwd_kernel<D, 2>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                        (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)k2, (const _Float16*)v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<D, false, SPLIT>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+    hipLaunchKernelGGL((attn_fwd_kernel<D, 0>), grid, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                        (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv, ld_kv, ld_q);
 }
 
@@ -593,19 +633,9 @@ static void launch_attn_wide(hipStream_t s, const void* q, const void* k, const 
   // every (batch, head)'s query blocks on ONE XCD (its keys / values fill one L2 instead of eight): 0.421 -> 0.4105 ms at batch 12,
   // 0.140 -> 0.137 at batch 4, same box, two alternating runs; GIP_ATTN_XCD=0 switches it off
   static const int xcd = [] { const char* e = getenv("GIP_ATTN_XCD"); return e && *e ? atoi(e) : 1; }();
-  hipLaunchKernelGGL((attn_fwd_kernel<D, false, false, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)q, (const _Float16*)k,
+  hipLaunchKernelGGL((attn_fwd_kernel<D, 0, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)q, (const _Float16*)k,
                      (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv,
                      ld_kv, ld_q, xcd);
-}
-
-template <int D>
-static void launch_attn(dim3 grid, hipStream_t s, const void* q, const void* k, const void* v, void* o, int Nq, int Nkv, int H,
-                        float c, const void* k2, const void* v2, int Nkv2, float w2, int ld_kv, int ld_kv2, int ld_q) {
-  // GIP_ATTN_SPLIT: per-tile online softmax (see attn_fwd_kernel); same-box A/B switch, read once
-  // measured and NOT adopted (round 4, two alternating runs: D = 40, N = 4096, B = 12: 0.438 ms plain, 0.446 ms split; every shape 1-2 % slower)
-  static const int split = [] { const char* e = getenv("GIP_ATTN_SPLIT"); return e && *e ? atoi(e) : 0; }();
-  if (split && D <= 80) launch_attn2<D, true>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
-  else launch_attn2<D, false>(grid, s, q, k, v, o, Nq, Nkv, H, c, k2, v2, Nkv2, w2, ld_kv, ld_kv2, ld_q);
 }
 
 extern "C" int gip_attention_fwd_strided2_f16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,

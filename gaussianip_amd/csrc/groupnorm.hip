@@ -139,45 +139,7 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
   const float inv_m = 1.f / ((float)HW * (float)cg);
   // per-group totals from the per-split partials: all 256 threads take part (group = t % G, split slice = t / G),
   // fixed summation order.  splits == 0 (forward): mean / rstd were made by gn_finalize_stats_kernel, nothing to reduce
-  if (MODE == 0 && splits < 0) {
-    // statistics straight from the producer's per-(128-row block, channel) sums (`partial` = chan_stats [N * bps][C][2], bps =
-    // -splits blocks per sample): the small tensors of the denoiser (bps * C <= 16384 pairs = 128 KB per sample, L2-resident,
-    // just written) do not get a gn_finalize_stats launch of their own — every workgroup folds its sample's sums itself, in a
-    // fixed order
-    const int bps = -splits;
-    const float rows = (float)HW / (float)bps;
-    // phase 1: per-channel totals over the sample's blocks — thread = channel PAIR (one float4 = (S, Q) of two channels), the
-    // loads of a wave are consecutive (coalesced) and independent over the blocks, the sums run in block order
-    float* s_ch = s_g + 2 * G;                      // [C][2]
-    const float4* p4 = reinterpret_cast<const float4*>(partial + (size_t)n * bps * C * 2);
-    const int cpairs = C >> 1;
-    for (int cp = threadIdx.x; cp < cpairs; cp += GN_BLOCK) {
-      float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
-      for (int b = 0; b < bps; b++) {
-        const float4 v = p4[(size_t)b * cpairs + cp];
-        sa += v.x; qa += v.y; sb += v.z; qb += v.w;
-      }
-      if (addend) {               // sum(x + a) = S + R a, sum((x + a)^2) = Q + 2 a S + R a^2 over the sample's HW rows
-        const float a0 = __half2float(addend[(long long)n * addend_stride + 2 * cp]);
-        const float a1 = __half2float(addend[(long long)n * addend_stride + 2 * cp + 1]);
-        qa += 2.f * a0 * sa + (float)HW * a0 * a0; sa += (float)HW * a0;
-        qb += 2.f * a1 * sb + (float)HW * a1 * a1; sb += (float)HW * a1;
-      }
-      s_ch[4 * cp] = sa; s_ch[4 * cp + 1] = qa; s_ch[4 * cp + 2] = sb; s_ch[4 * cp + 3] = qb;
-    }
-    (void)rows;
-    __syncthreads();
-    // phase 2: a group's channels in order
-    for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) {
-      float s0 = 0.f, s1 = 0.f;
-      for (int c = gg * cg; c < (gg + 1) * cg; c++) { s0 += s_ch[2 * c]; s1 += s_ch[2 * c + 1]; }
-      const float mu = s0 * inv_m;
-      const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
-      const float rs = rsqrtf(var + eps);
-      s_g[2 * gg] = mu; s_g[2 * gg + 1] = rs;
-      if (split == 0) { mean[n * G + gg] = mu; rstd[n * G + gg] = rs; }
-    }
-  } else if (MODE == 0 && splits == 0) {
+  if (MODE == 0 && splits == 0) {
     for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) { s_g[2 * gg] = mean[n * G + gg]; s_g[2 * gg + 1] = rstd[n * G + gg]; }
   } else if (MODE == 1 && splits == 0) {      // S1 / m, S2 / m made by gn_finalize_bwd_kernel from the data-gradient kernel's sums
     for (int gg = threadIdx.x; gg < G; gg += GN_BLOCK) { s_g[2 * gg] = partial[((long long)n * G + gg) * 2]; s_g[2 * gg + 1] = partial[((long long)n * G + gg) * 2 + 1]; }
@@ -403,19 +365,6 @@ extern "C" int gip_gn_silu_forward_stats(const void* x, const void* gamma, const
   if (!gamma || !beta || !mean || !rstd || !chan_stats || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
   hipStream_t s = (hipStream_t)stream;
   const int splits = pick_splits(N, HW, C);
-  // measured and NOT adopted, twice (round 4, same box).  First form (strided loads, every apply workgroup walking up to 128 KB of
-  // sums): 34.4 ms without, 34.9-35.0 with.  Second form (the prologue below: coalesced per-channel sums, then the groups): 35.27
-  // without, 35.37 with — neutral: the finalize launches sit in the two-stream denoise, where the other stream's kernels fill
-  // the gap a 5 us launch leaves (unlike the single-stream glue, where every removed launch showed).  Opt-in
-  static const int fold = [] { const char* v = getenv("GIP_GN_FOLD_FINALIZE"); return v && *v ? atoi(v) : 0; }();
-  if (fold && (long long)blocks_per_sample * C <= 16384 && HW % blocks_per_sample == 0 && G <= GN_BLOCK) {
-    // one launch: the apply kernel's prologue folds the producer's sums itself (see gn_apply_kernel, splits < 0)
-    hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK + C) * 2 * sizeof(float), s,
-                       (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
-                       chan_stats, (half8*)y, (long long)HW, C, G, -blocks_per_sample, splits, eps, apply_silu,
-                       (const __half*)addend, addend_stride, (const half8*)nullptr);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
-  }
   hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(G, N), dim3(GN_BLOCK), 0, s, chan_stats, blocks_per_sample, (long long)HW, C, G,
                      eps, (const __half*)addend, addend_stride, mean, rstd);
   hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,

@@ -270,60 +270,91 @@ extern "C" int gip_adam_step(const GipAdamGroup* groups, int32_t n_groups, doubl
 // the partials behind `__threadfence()` took 130 us per kernel: an agent-scope release writes the L2 back, once per workgroup).
 // Every workgroup of a consumer kernel re-derives the scalar it needs from the producer's per-workgroup partials (4 KB, same order
 // everywhere).  `ws` (float32): [0] max, [1] loss, [2] count of maxima, [4, 4 + SP_BLOCKS) maxima / backward sums per workgroup,
-// [4 + SP_BLOCKS, 4 + 3 SP_BLOCKS) (loss sum, tie count) per workgroup.
+// [4 + SP_BLOCKS, 4 + 3 SP_BLOCKS) (loss sum, tie count as uint32 bits) per workgroup.  A NaN depth propagates into the maximum
+// (and so into the loss and every gradient) like torch.max(); the tie count is integer arithmetic until its one final rounding.
 #define SP_BLOCKS 1024
 #define SP_THREADS 256
+
+// maximum that PROPAGATES NaN like torch.max() (fmaxf alone drops it: a poisoned depth map must poison the loss, as in the op chain)
+__device__ __forceinline__ float sp_max(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 
 __device__ __forceinline__ float sp_block_reduce(float v, bool is_max, float* s_red) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     const float o = __shfl_xor(v, d, 64);
-    v = is_max ? fmaxf(v, o) : v + o;
+    v = is_max ? sp_max(v, o) : v + o;
   }
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
   __syncthreads();
   float t = s_red[0];
-  for (int i = 1; i < SP_THREADS / 64; i++) t = is_max ? fmaxf(t, s_red[i]) : t + s_red[i];
+  for (int i = 1; i < SP_THREADS / 64; i++) t = is_max ? sp_max(t, s_red[i]) : t + s_red[i];
+  return t;
+}
+
+// the tie count of the maximum is an INTEGER all the way (a float32 count stops growing at 2^24 tied elements — an all-zero or
+// saturated batch of 4 x 2048^2 depths — and the maximum's gradient share would be divided by a rounded count)
+__device__ __forceinline__ unsigned long long sp_block_count(unsigned long long v, unsigned long long* s_cnt) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long t = s_cnt[0];
+  for (int i = 1; i < SP_THREADS / 64; i++) t += s_cnt[i];
   return t;
 }
 
 // the same value in every workgroup: partial[0 .. nb) combined in one fixed order
 __device__ __forceinline__ float sp_combine(const float* __restrict__ part, int nb, int stride, bool is_max, float* s_red) {
   float t = is_max ? -INFINITY : 0.f;
-  for (int i = threadIdx.x; i < nb; i += SP_THREADS) t = is_max ? fmaxf(t, part[(size_t)i * stride]) : t + part[(size_t)i * stride];
+  for (int i = threadIdx.x; i < nb; i += SP_THREADS) t = is_max ? sp_max(t, part[(size_t)i * stride]) : t + part[(size_t)i * stride];
   return sp_block_reduce(t, is_max, s_red);
 }
 
 __global__ void __launch_bounds__(SP_THREADS) sp_max_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ ws) {
   __shared__ float s_red[SP_THREADS / 64];
   float m = -INFINITY;
-  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) m = fmaxf(m, d[i]);
+  bool nan = false;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+    const float x = d[i];
+    m = fmaxf(m, x);
+    nan |= x != x;
+  }
+  if (nan) m = __builtin_nanf("");
   m = sp_block_reduce(m, true, s_red);
   if (threadIdx.x == 0) ws[4 + blockIdx.x] = m;
 }
 
 __global__ void __launch_bounds__(SP_THREADS) sp_loss_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ ws) {
   __shared__ float s_red[SP_THREADS / 64];
+  __shared__ unsigned long long s_cnt[SP_THREADS / 64];
   const float dmax = sp_combine(ws + 4, (int)gridDim.x, 1, true, s_red), den = dmax + 1e-5f;
-  float sum = 0.f, cnt = 0.f;
+  float sum = 0.f;
+  uint32_t cnt = 0;
   for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
     const float x = d[i], o = x / den;
     sum += sqrtf(o * o + 0.01f);
-    cnt += x == dmax ? 1.f : 0.f;
+    cnt += x == dmax ? 1u : 0u;
   }
   sum = sp_block_reduce(sum, false, s_red);
-  cnt = sp_block_reduce(cnt, false, s_red);
+  const unsigned long long c = sp_block_count(cnt, s_cnt);
   float* part = ws + 4 + SP_BLOCKS;
-  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sum; part[2 * blockIdx.x + 1] = cnt; }
+  // a workgroup sees at most n / gridDim.x + 256 elements: its count fits 32 bits for every n < 2^41; stored as integer bits
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sum; reinterpret_cast<uint32_t*>(part)[2 * blockIdx.x + 1] = (uint32_t)c; }
 }
 
 __global__ void __launch_bounds__(SP_THREADS) sp_finish_kernel(int nb, int64_t n, float* __restrict__ ws) {
   __shared__ float s_red[SP_THREADS / 64];
+  __shared__ unsigned long long s_cnt[SP_THREADS / 64];
   const float dmax = sp_combine(ws + 4, nb, 1, true, s_red);
   const float sum = sp_combine(ws + 4 + SP_BLOCKS, nb, 2, false, s_red);
-  const float cnt = sp_combine(ws + 4 + SP_BLOCKS + 1, nb, 2, false, s_red);
-  if (threadIdx.x == 0) { ws[0] = dmax; ws[1] = sum / (float)n; ws[2] = cnt; }
+  const uint32_t* cp = reinterpret_cast<const uint32_t*>(ws + 4 + SP_BLOCKS);
+  unsigned long long c = 0;
+  for (int i = threadIdx.x; i < nb; i += SP_THREADS) c += cp[2 * i + 1];
+  c = sp_block_count(c, s_cnt);
+  // ws[2]: the exact integer count, rounded to float ONCE (it only ever divides the maximum's gradient share)
+  if (threadIdx.x == 0) { ws[0] = dmax; ws[1] = sum / (float)n; ws[2] = (float)c; }
 }
 
 // pass 1 of the backward: g_d[i] = (g / n) (o / sqrt(o^2 + 0.01)) / den; per workgroup the sum of (d loss / d o_i) o_i, whose

@@ -63,32 +63,14 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
                           const GipRecord* __restrict__ records, const float* __restrict__ bg,
                           float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
                           uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, const uint32_t* __restrict__ ckpt_start,
-                          float* __restrict__ checkpoints, const GipRasterHeader* __restrict__ header, int xcd_order) {
+                          float* __restrict__ checkpoints) {
   // Launch position -> place in the longest-first order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
   // share one, each XCD has its own L2), and inside a size class the order is by tile index — so consecutive positions are
   // neighbouring tiles, which share most of their Gaussians, and land on 8 different L2s: every XCD fetches its own copy of
-  // the records (fabric traffic 1.87x the algorithmic bytes, profiles/r03_pmc_summary.txt).  OPTIONAL XCD-aware order
-  // (GIP_FWD_XCD_ORDER=1; measured slower, see the launcher): inside each size class XCD k takes the k-th CONTIGUOUS chunk of
-  // the class's tiles instead of every eighth one — a bijection of the class's range.
-  uint32_t pos = blockIdx.x;
-  if (xcd_order) {
-    const uint32_t n = gridDim.x;
-    const uint32_t e1 = min(header->class_end[1], n), e2 = min(max(header->class_end[2], e1), n);
-    const uint32_t e0 = min(max(header->class_end[0], e2), n), e3 = min(max(header->class_end[3], e0), n);
-    uint32_t lo, hi;
-    if (pos < e1) { lo = 0; hi = e1; } else if (pos < e2) { lo = e1; hi = e2; } else if (pos < e0) { lo = e2; hi = e0; }
-    else if (pos < e3) { lo = e0; hi = e3; } else { lo = e3; hi = n; }
-    const uint32_t r = pos & 7u;
-    uint32_t before = 0, first_r = lo;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-      const uint32_t first = lo + ((k + 8u - (lo & 7u)) & 7u);           // smallest position >= lo with residue k
-      const uint32_t cnt = first < hi ? (hi - first + 7u) >> 3 : 0u;
-      if (k < r) before += cnt;
-      if (k == r) first_r = first;
-    }
-    pos = lo + before + ((pos - first_r) >> 3);
-  }
+  // the records (fabric traffic 1.87x the algorithmic bytes, profiles/r03_pmc_summary.txt).  An XCD-contiguous order inside
+  // each size class was measured 20 % slower in round 4 (the long lists of a class are spatial neighbours, so contiguous
+  // chunks hand some XCDs all of them): tools/experiments/render_forward_xcd_order.txt.
+  const uint32_t pos = blockIdx.x;
   const uint32_t vt = tile_order[pos];   // view * T + tile
   const uint32_t v = vt / kp.T, tile = vt - v * kp.T;
   const uint32_t tx = tile % kp.tiles_x, ty = tile / kp.tiles_x;
@@ -296,11 +278,7 @@ gip_render_forward_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_
 
 void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth,
                                float* alpha, hipStream_t s) {
-  // measured and NOT adopted (round 4, three alternating runs on one box: render_fwd 0.155 ms with the interleaved order, 0.187-0.189
-  // with the XCD-contiguous one): the heavy tiles of a class are spatial neighbours (the body), so contiguous chunks give
-  // some XCDs all the long lists of the class — the imbalance costs far more than the shared record fetches save; opt-in
-  static const int xcd_order = [] { const char* v = getenv("GIP_FWD_XCD_ORDER"); return v && *v ? atoi(v) : 0; }();
   hipLaunchKernelGGL(gip_render_forward_kernel, dim3(kp.V * kp.T), dim3(FWD_THREADS), 0, s, kp, st.tile_order,
                      st.tile_start, st.keys, st.records, bg, color, depth, alpha, st.n_contrib, st.final_T, st.ckpt_start,
-                     st.checkpoints, (const GipRasterHeader*)st.header, xcd_order);
+                     st.checkpoints);
 }

@@ -102,7 +102,7 @@ _STATS_ATTR = "_gip_chan_stats"
 # scalar kernel arguments (Attention.ip_scale) and the A/B environment switches are baked in.  Everything that changes one
 # of those bumps this counter; it is part of the graph keys, so a stale graph is never replayed.
 _weights_epoch = 0
-_ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_GN_STATS", "GIP_SPLITK_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
+_ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_GN_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
               "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
               "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
 
@@ -143,20 +143,14 @@ def stats_wanted(N, H, W, cout):
     """The producer takes the next GroupNorm's statistics when a 128-pixel block never straddles two samples (whole-K
     tiles write them in their epilogue, split-K layers in their reduce kernel)."""
     return (not _DISABLED and (H * W) % 128 == 0 and cout % 8 == 0 and
-            (_conv_tiles(N, H, W, cout) >= 256 or os.environ.get("GIP_SPLITK_STATS", "0") != "0") and
+            _conv_tiles(N, H, W, cout) >= 256 and
             os.environ.get("GIP_GN_STATS", "1") != "0")
 
 
 def _stats_rows(N, H, W, cin, cout):
-    """Rows per statistics block the 3x3 convolution can deliver for this shape: 128, 64 (samples of 64 pixels — the 8 x 8
-    level — which always run split-K: 64-row blocks come out of its reduce kernel) or 0 (none)."""
-    if stats_wanted(N, H, W, cout):
-        return 128
-    if (not _DISABLED and (H * W) % 64 == 0 and (H * W) % 128 != 0 and cout % 8 == 0 and cin >= 128 and
-            _conv_tiles(N, H, W, cout) < 256 and N * H * W * cout * 8 <= _SPLITK_WS_BYTES and
-            os.environ.get("GIP_GN_STATS", "1") != "0" and os.environ.get("GIP_SPLITK_STATS", "0") != "0"):
-        return 64
-    return 0
+    """Rows per statistics block the 3x3 convolution delivers for this shape: 128 or 0 (none).  (Statistics out of the split-K
+    reduce kernel, incl. 64-row blocks at the 8 x 8 level, measured neutral in round 4 and were removed in round 5.)"""
+    return 128 if stats_wanted(N, H, W, cout) else 0
 
 
 class disabled:
@@ -280,13 +274,17 @@ class _WeightCache:
     so the allocator cannot hand the same address (at version 0, same shape) to a different weight and make the entry
     stale.  Least-recently-used entries beyond _WT_CACHE_MAX are dropped (a rebuilt network does not pin the old one's
     weights forever) — EXCEPT entries that were created or read while a HIP graph was being captured: the graph bakes
-    their device addresses into its kernel arguments, so they stay (pinned) until the graphs that use them are dropped
-    (`unpin_all`, called by StableDiffusionGuidance.invalidate_graphs)."""
+    their device addresses into its kernel arguments, so they stay (pinned, per owner of the capturing graph: capture_owner)
+    until the graphs that use them are dropped (`unpin(owner)`, called by StableDiffusionGuidance.invalidate_graphs)."""
 
     def __init__(self):
         from collections import OrderedDict
         self._d = OrderedDict()
-        self._pinned = set()
+        self._pinned = {}           # key -> set of owner tokens whose captured graphs use the entry
+        self.owner = None           # token of whoever is capturing right now (capture_owner below)
+
+    def _pin(self, key):
+        self._pinned.setdefault(key, set()).add(self.owner)
 
     def get(self, tag, w, make):
         key = (tag, w.data_ptr(), w._version, tuple(w.shape), w.dtype)
@@ -295,12 +293,12 @@ class _WeightCache:
         if hit is not None:
             self._d.move_to_end(key)
             if capturing:
-                self._pinned.add(key)
+                self._pin(key)
             return hit[1]
         wt = make(w)         # (inside a capture: the copy kernels become part of the graph and the tensor lives in its pool — still correct)
         self._d[key] = (w, wt)
         if capturing:
-            self._pinned.add(key)
+            self._pin(key)
         if len(self._d) > _WT_CACHE_MAX:
             for k in [k for k in self._d if k not in self._pinned][:len(self._d) - _WT_CACHE_MAX]:
                 del self._d[k]
@@ -312,12 +310,33 @@ class _WeightCache:
     def pinned(self):
         return len(self._pinned)
 
+    def unpin(self, owner):
+        """Release the pins of ONE owner's graphs (another guidance instance's live graphs keep theirs)."""
+        for k in [k for k, owners in self._pinned.items() if owner in owners]:
+            self._pinned[k].discard(owner)
+            if not self._pinned[k]:
+                del self._pinned[k]
+
     def unpin_all(self):
         self._pinned.clear()
 
     def clear(self):
         self._d.clear()
         self._pinned.clear()
+
+
+class capture_owner:
+    """`with capture_owner(token):` — derived weights created or read by a HIP-graph capture inside are pinned on behalf of
+    `token` (the object that owns the graph) and released by `_wt_cache.unpin(token)` when it drops its graphs."""
+
+    def __init__(self, token):
+        self.token = token
+
+    def __enter__(self):
+        self._old, _wt_cache.owner = _wt_cache.owner, self.token
+
+    def __exit__(self, *exc):
+        _wt_cache.owner = self._old
 
 
 _wt_cache = _WeightCache()

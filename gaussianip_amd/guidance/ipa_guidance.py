@@ -28,9 +28,6 @@ _TWO_STREAMS = __import__("os").environ.get("GIP_GUIDANCE_STREAMS", "2") != "1" 
 # GIP_GRAPH_VAE=0 restore the eager launches (same kernels, same values).
 _GRAPH_DENOISE = __import__("os").environ.get("GIP_GRAPH_DENOISE", "1") == "1"
 _GRAPH_VAE = __import__("os").environ.get("GIP_GRAPH_VAE", "1") == "1"
-# GIP_VAE_STREAMS=2 (experiment, measured neutral: 33.77 vs 33.70 ms per step, same box): the VAE encoder's batch as two halves on two
-# HIP streams (forward, and through stream-aware autograd the backward)
-_VAE_STREAMS = int(__import__("os").environ.get("GIP_VAE_STREAMS", "1"))
 
 
 @dataclass
@@ -154,11 +151,25 @@ class StableDiffusionGuidance:
         by whatever changes something a graph froze at capture: load_checkpoints, fold_lora, prepare_inference, an ip_scale
         change (those also bump fused._weights_epoch, which is part of the graph keys — a stale graph can never be replayed
         even when this method is not reached, e.g. when a caller edits the modules directly)."""
+        self._drop_graphs()
+        fused.bump_weights_epoch()
+
+    def _drop_graphs(self):
         self._graphs = None
         self._vae_graphs = None
         self._vae_live = None
-        fused._wt_cache.unpin_all()
-        fused.bump_weights_epoch()
+        fused._wt_cache.unpin(id(self))        # only what THIS instance's captures pinned: other instances' graphs stay valid
+
+    _graph_sig = None
+
+    def _check_graph_signature(self):
+        """Graphs captured under another weights epoch / switch setting can never be replayed again (the signature is part of
+        their keys): release them and their private pools instead of keeping them for good."""
+        sig = fused.graph_signature()
+        if self._graph_sig != sig:
+            if self._graph_sig is not None:
+                self._drop_graphs()
+            self._graph_sig = sig
 
     def set_ip_scale(self, scale):
         """IPAdapter.set_scale (ip_adapter_faceid.py:330-333): the image-prompt weight of every cross-attention."""
@@ -251,6 +262,7 @@ class StableDiffusionGuidance:
         to enqueue a training step.  On the pool's hosts the step is GPU-bound either way (43.3-44.0 eager vs 43.6-43.7 ms
         with the graph), so it is opt-in, for hosts that cannot keep the queue filled.
         First call of a shape runs eagerly (lazy one-time initialisations must not be captured), the second captures."""
+        self._check_graph_signature()
         if self._graphs is None:
             self._graphs = {}
         key = (tuple(noisy_latents.shape), noisy_latents.dtype, tuple(control_img.shape), control_img.dtype, tuple(t.shape), t.dtype,
@@ -265,7 +277,7 @@ class StableDiffusionGuidance:
             for d_, s_ in zip(static, (noisy_latents, control_img, t, ctx)):
                 d_.copy_(s_)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with fused.capture_owner(id(self)), torch.cuda.graph(graph):
                 out = self._forward_unet_eager(static[0], static[1], static[2], static[3], use_pose, None, replicas)
             ent = self._graphs[key] = (graph, static, out)
         graph, static, out = ent
@@ -337,24 +349,11 @@ class StableDiffusionGuidance:
             return self._vae_moments(x)
 
     def _vae_encode(self, x, generator):
-        """vae.encode(x, generator) (any module with that method); the two-stream form needs the moments / sample split."""
-        if _VAE_STREAMS < 2 or not hasattr(self.vae, "moments"):
-            return self.vae.encode(x, generator)
-        return self.vae.sample(self._vae_moments(x), generator)
+        return self.vae.encode(x, generator)
 
     def _vae_moments(self, x):
-        """vae.moments(x), with GIP_VAE_STREAMS=2 as two half batches on two streams (same kernels per image, same values)."""
-        if _VAE_STREAMS < 2 or not x.is_cuda or x.shape[0] < 2 or x.shape[0] % 2:
-            return self.vae.moments(x)
-        h = x.shape[0] // 2
-        cur, side = torch.cuda.current_stream(x.device), self._side_stream(x.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            m1 = self.vae.moments(x[h:])
-        m0 = self.vae.moments(x[:h])
-        cur.wait_stream(side)
-        m1.record_stream(cur)
-        return torch.cat([m0, m1], dim=0)
+        """(The batch as two halves on two streams measured neutral in round 4 — 33.77 vs 33.70 ms per step — and was removed.)"""
+        return self.vae.moments(x)
 
     _vae_graphs = None
     _vae_live = None
@@ -364,6 +363,7 @@ class StableDiffusionGuidance:
         launches: torch.cuda.make_graphed_callables captures `moments` and its backward; the stochastic part of
         latent_dist.sample() (ipa_guidance.py:522-531) stays outside the graph.  First call of a shape runs eagerly (lazy
         one-time initialisations must not be captured), the second captures."""
+        self._check_graph_signature()
         if self._vae_graphs is None:
             self._vae_graphs = {}
         key = (tuple(x.shape), x.dtype, x.device.index, fused.graph_signature())
@@ -373,7 +373,8 @@ class StableDiffusionGuidance:
             return self._vae_moments(x) if moments_only else self._vae_encode(x, generator)
         if ent == "warm":
             sample = torch.zeros_like(x, memory_format=torch.channels_last).requires_grad_(True)
-            ent = self._vae_graphs[key] = torch.cuda.make_graphed_callables(lambda t_: self._vae_moments(t_), (sample,), num_warmup_iters=2)
+            with fused.capture_owner(id(self)):
+                ent = self._vae_graphs[key] = torch.cuda.make_graphed_callables(lambda t_: self._vae_moments(t_), (sample,), num_warmup_iters=2)
         # make_graphed_callables keeps ONE set of static activations: a second forward before the first one's backward would
         # overwrite what that backward reads.  While an earlier output of this graph is still alive and has not been
         # back-propagated, the call runs eagerly instead (same kernels, same values).

@@ -210,8 +210,8 @@ class _GroupMax(torch.autograd.Function):
     EVENLY among tied elements, so a single-process step splits it between the tied pixels; here, when several RANKS tie
     (identical views, a saturated depth), the whole gradient goes to the lowest rank of the group (which splits it among
     its own tied pixels as usual) — a documented deviation that matters only for exactly equal float maxima on different
-    ranks (tests/test_distributed_cpu.py pins it).  The key's ordering needs a non-negative, non-NaN value (depths of
-    Gaussians beyond the near plane; an empty render gives 0): checked.  One collective: the ranks MAX-reduce the int64 key
+    ranks (tests/test_distributed_cpu.py pins it).  The key's ordering needs a non-negative value (depths of Gaussians beyond
+    the near plane; an empty render gives 0); a NaN local maximum makes the group maximum NaN on every rank.  One collective: the ranks MAX-reduce the int64 key
     (float bits << 32) | (world - rank); non-negative IEEE floats order like their bit patterns, so the winning key
     carries the maximum in its high word and the winner's rank in its low word."""
 
@@ -219,9 +219,13 @@ class _GroupMax(torch.autograd.Function):
     def forward(ctx, local_max, group):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         lm = local_max.detach().to(torch.float32).reshape(1)
-        if not lm.is_cuda and not bool(lm >= 0):       # (on the GPU the check would be a host synchronisation: clamp instead)
-            raise ValueError("group maximum of a negative / NaN value: the bit-pattern ordering needs a non-negative float")
-        lm = torch.nan_to_num(lm, nan=0.0).clamp_min(0.0)
+        if not lm.is_cuda and bool(lm < 0):            # (on the GPU the check would be a host synchronisation: clamp instead)
+            raise ValueError("group maximum of a negative value: the bit-pattern ordering needs a non-negative float")
+        # NaN stays observable, like depths.max() of the single-process step: it is encoded as the canonical positive quiet NaN
+        # (bits 0x7fc00000), which sorts above every finite non-negative float and +inf, so the group maximum becomes NaN on
+        # EVERY rank (and the loss with it) — not another rank's finite maximum.  Negative values cannot occur (depths of
+        # Gaussians beyond the near plane; an empty render gives 0) and are clamped.
+        lm = torch.where(torch.isnan(lm), torch.full_like(lm, float("nan")), lm.clamp_min(0.0))
         bits = lm.view(torch.int32).to(torch.int64)
         key = (bits << 32) | (world - rank)
         dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)

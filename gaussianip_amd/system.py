@@ -58,24 +58,45 @@ class _SparsityTerm(torch.autograd.Function):
 
 
 class _StepOutputs(dict):
-    """forward()'s dict; "opacity" = depth / (max + 1e-5) (GaussianIP.py:225-226) is made when somebody reads it: the fused
-    sparsity term works on the depth maps directly and the [B, H, W, 1] quotient is otherwise a dead 16 MB tensor per step."""
+    """forward()'s dict; "opacity" = depth / (max + 1e-5) (GaussianIP.py:225-226), "scale" and "visibility_filter" are made when
+    somebody reads them: the fused sparsity term works on the depth maps directly and the [B, H, W, 1] quotient is otherwise a
+    dead 16 MB tensor per step.  The thunks live in `_lazy`, OFF the mapping: iteration, copies, `{**out}` and `dict(out)` show
+    reference keys with tensor values only (a lazy key appears once it has been read; `materialize()` reads them all)."""
+
+    _LAZY_KEYS = ("opacity", "scale", "visibility_filter")
+
+    def __init__(self, mapping, lazy=None):
+        super().__init__(mapping)
+        self._lazy = dict(lazy or {})
 
     def __missing__(self, key):
-        if key == "opacity" and dict.__contains__(self, "_dmax"):
-            v = self["depth"] / (dict.__getitem__(self, "_dmax")() + 1e-5)
-            self[key] = v
+        if key == "opacity" and "dmax" in self._lazy:
+            v = self[key] = self["depth"] / (self._lazy["dmax"]() + 1e-5)
             return v
-        if key == "scale" and dict.__contains__(self, "_scale"):           # "scale": the activated scaling (GaussianIP.py:228), made when read
-            v = self[key] = dict.__getitem__(self, "_scale")()
+        if key == "scale" and "scale" in self._lazy:           # "scale": the activated scaling (GaussianIP.py:228), made when read
+            v = self[key] = self._lazy["scale"]()
             return v
         if key == "visibility_filter" and dict.__contains__(self, "radii"):
             v = self[key] = self["radii"] > 0
             return v
         raise KeyError(key)
 
+    def _available(self, key):
+        return (key == "opacity" and "dmax" in self._lazy) or (key == "scale" and "scale" in self._lazy) or \
+            (key == "visibility_filter" and dict.__contains__(self, "radii"))
+
     def __contains__(self, key):
-        return dict.__contains__(self, key) or key in ("opacity", "scale", "visibility_filter")
+        return dict.__contains__(self, key) or self._available(key)
+
+    def get(self, key, default=None):           # dict.get does not go through __missing__
+        return self[key] if key in self else default
+
+    def materialize(self):
+        """Every lazy key read once: afterwards this is a plain dict with the reference's keys."""
+        for k in self._LAZY_KEYS:
+            if self._available(k):
+                self[k]
+        return self
 
 
 @dataclass
@@ -188,8 +209,8 @@ class StageOneStep:
         if local_max and _FUSED_LOSS and depths.is_cuda and depths.dtype == torch.float32 and pkg["depth_3dgs"].is_contiguous():
             # one process, no exchange: the loss takes the sparsity term straight from the depth maps (loss()); the quotient
             # itself is only materialised if somebody asks for it
-            out = _StepOutputs({**pkg, "comp_rgb": images, "depth": depths, "_dmax": lambda d_=depths: d_.max(),
-                                "_scale": lambda g_=self.gaussian: g_.get_scaling})
+            out = _StepOutputs({**pkg, "comp_rgb": images, "depth": depths},
+                               lazy={"dmax": lambda d_=depths: d_.max(), "scale": lambda g_=self.gaussian: g_.get_scaling})
         else:
             dmax = depths.max()                                      # batch-global maximum (:225)
             if self.sharding is not None and self.sharding.active:

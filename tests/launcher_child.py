@@ -9,6 +9,14 @@ import torch
 import torch.distributed as dist
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "ok"
+if mode == "hang":
+    # every rank blocks for good and ignores SIGTERM (a rank stuck inside the driver): only the launcher's deadline + SIGKILL end it
+    import signal
+    import time
+    signal.signal(signal.SIGTERM, signal.SIG_IGN)
+    print("[noise] rank %s is stuck" % os.environ["RANK"], flush=True)
+    while True:
+        time.sleep(1)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 assert int(os.environ["LOCAL_RANK"]) == rank
 dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -10,13 +10,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = os.path.join(ROOT, "tests", "launcher_child.py")
 
 
-def _run(mode, n=2):
+def _run(mode, n=2, timeout=None):
     sys.path.insert(0, ROOT)
     import bench
     out, err = io.StringIO(), io.StringIO()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    rc = bench.spawn_ranks(n, [sys.executable, CHILD, mode], env=env, out=out, err=err)
+    rc = bench.spawn_ranks(n, [sys.executable, CHILD, mode], env=env, out=out, err=err, timeout=timeout)
     return rc, out.getvalue(), err.getvalue()
+
+
+def test_launcher_gives_up_when_every_rank_blocks(monkeypatch):
+    """all ranks blocked (no rank ever exits non-zero) used to hang the launcher for good.  With a deadline it
+    terminates the ranks, escalates to kill() for the ones that ignore SIGTERM, dumps their output and fails with 124."""
+    import time
+    t0 = time.monotonic()
+    rc, out, err = _run("hang", 2, timeout=8.0)
+    assert rc == 124 and out.strip() == ""
+    assert "no result after 8 s" in err and "[rank 0] [noise] rank 0 is stuck" in err and "[rank 1] [noise] rank 1 is stuck" in err
+    assert time.monotonic() - t0 < 60
 
 
 def test_launcher_starts_n_ranks_and_relays_one_clean_line():

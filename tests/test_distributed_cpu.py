@@ -134,8 +134,14 @@ def _scaler_worker(rank, world, port, out):
     y2.backward()
     notie = [None] * world
     dist.all_gather_object(notie, (float(y2.detach()), float(x2.grad)))
+    # a NaN local maximum (rank 1's depth map is poisoned) makes the group maximum NaN on EVERY rank, like depths.max() of the
+    # single-process step — it must not be hidden behind the other rank's finite maximum
+    x3 = torch.tensor(float("nan") if rank == 1 else 5.0)
+    y3 = parallel._GroupMax.apply(x3, None)
+    nan = [None] * world
+    dist.all_gather_object(nan, bool(torch.isnan(y3)))
     if rank == 0:
-        out.put(dict(res=res, tie=tie, notie=notie))
+        out.put(dict(res=res, tie=tie, notie=notie, nan=nan))
     dist.destroy_process_group()
 
 
@@ -158,6 +164,7 @@ def test_scaler_sees_the_exchanged_gradients_and_group_max_breaks_ties():
     assert a["scale1"] == b["scale1"]
     assert r["tie"] == [(2.0, 7.0), (2.0, 0.0)]
     assert r["notie"] == [(2.0, 0.0), (2.0, 2.0)]
+    assert r["nan"] == [True, True]
 
 
 def test_view_sharding_rejects_uneven_replication_and_keeps_the_hand_mask():

@@ -23,10 +23,14 @@ def test_step_outputs_make_opacity_scale_and_visibility_when_read():
     depth = torch.tensor([[[[0.0], [2.0]], [[4.0], [1.0]]]])      # [1, 2, 2, 1]
     radii = torch.tensor([[0, 5, 1]], dtype=torch.int32)
     scale = torch.rand(3, 3)
-    out = _StepOutputs({"depth": depth, "radii": radii, "_dmax": lambda: depth.max(), "_scale": lambda: scale})
+    out = _StepOutputs({"depth": depth, "radii": radii}, lazy={"dmax": lambda: depth.max(), "scale": lambda: scale})
     assert "opacity" in out and "scale" in out and "visibility_filter" in out
     assert not dict.__contains__(out, "opacity")
-    assert torch.allclose(out["opacity"], depth / (4.0 + 1e-5)) and dict.__contains__(out, "opacity")
+    # the thunks are not on the mapping: copies / iteration / logging see reference keys with tensor values only
+    assert set(out) == {"depth", "radii"} and all(torch.is_tensor(v) for v in {**out}.values())
+    assert out.get("no such key", 7) == 7
+    assert torch.allclose(out.get("opacity"), depth / (4.0 + 1e-5)) and dict.__contains__(out, "opacity")     # get() materialises too
+    assert torch.allclose(out["opacity"], depth / (4.0 + 1e-5))
     assert out["scale"] is scale
     assert torch.equal(out["visibility_filter"], radii > 0)
     try:
@@ -34,6 +38,10 @@ def test_step_outputs_make_opacity_scale_and_visibility_when_read():
         raise AssertionError("KeyError expected")
     except KeyError:
         pass
+    plain = _StepOutputs({"depth": depth, "radii": radii}, lazy={"dmax": lambda: depth.max(), "scale": lambda: scale}).materialize()
+    assert set(dict(plain)) == {"depth", "radii", "opacity", "scale", "visibility_filter"}
+    bare = _StepOutputs({"depth": depth})
+    assert "opacity" not in bare and "visibility_filter" not in bare and bare.get("opacity") is None
 
 
 def test_fused_glue_is_not_offered_for_cpu_tensors_or_other_dtypes():

@@ -1,4 +1,4 @@
-"""Self-attention kernel timing at the denoiser's shapes (GIP_ATTN_SPLIT is read once per process: run under both settings)."""
+"""Self-attention kernel timing at the denoiser shapes."""
 import os
 import sys
 
@@ -22,7 +22,6 @@ def timed(fn, n=30):
     return a.elapsed_time(b) / n
 
 
-print("GIP_ATTN_SPLIT=%s" % os.environ.get("GIP_ATTN_SPLIT", "1"))
 for B, H, N, D in [(12, 8, 4096, 40), (4, 8, 4096, 40), (12, 8, 1024, 80), (6, 8, 4096, 40), (3, 8, 4096, 40)]:
     q, k, v = [torch.randn(B, N, H * D, device="cuda").half() for _ in range(3)]
     with torch.no_grad():
