@@ -100,6 +100,78 @@ def stage_bytes(stage, P, K, R, T, N):
     }[stage]
 
 
+def measure_config4(dev, P=1000000, H=1024, W=1024, V=12, iters=5):
+    """BASELINE.json configs[4], render part, where the HBM roofline is meaningful: 1M Gaussians (the 100k init split / cloned up
+    to 1M: scales / 1.6 as gaussian_model.py:371, opacity 0.6), 1024^2, ONE 12-view launch set of the 36-view orbit (elevation 5,
+    distance 1.8, fovy 70; configs/exp.yaml:37-40).  Per stage: live hipEvent duration on the launch stream, algorithmic bytes
+    (SURVEY §8d terms split by stage x V) and their fraction of 8 TB/s; forward and forward+backward wall time of the set."""
+    import numpy as np
+    import torch
+    import scenes
+    from gaussianip_amd import GaussianRasterizationSettings, rasterize_views
+    from gaussianip_amd import rasterizer as R
+    sc = scenes.make_scene("human", P, seed=42)
+    sc["scales"] = (sc["scales"] / 1.6).astype(np.float32)
+    sc["opacities"][:] = 0.6
+    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items()}
+    bg = torch.zeros(3, device=dev)
+    cams = [scenes.camera(5.0, -180.0 + 10.0 * i, 1.8, 70.0, H, W) for i in range(V)]
+    sts = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=bg, scale_modifier=1.0,
+        viewmatrix=torch.from_numpy(c["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(c["projmatrix"]).to(dev),
+        sh_degree=0, campos=torch.from_numpy(c["campos"]).to(dev), prefiltered=False, debug=False) for c in cams]
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    gC = torch.randn((V, 3, H, W), device=dev, generator=gen) * 1e-3
+    gD = torch.randn((V, 1, H, W), device=dev, generator=gen) * 1e-3
+    names = ["means3D", "shs", "opacities", "scales", "rotations"]
+    tg = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+
+    def fwd():
+        with torch.no_grad():
+            return rasterize_views(t["means3D"], None, t["opacities"], sts, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+
+    def fwd_bwd():
+        color, radii, depth, alpha = rasterize_views(tg["means3D"], None, tg["opacities"], sts, shs=tg["shs"], scales=tg["scales"],
+                                                     rotations=tg["rotations"])
+        torch.autograd.grad([color, depth], [tg[n] for n in names], [gC, gD])
+
+    def wall(fn, n=5):
+        fn()
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    f_ms, fb_ms = wall(fwd), wall(fwd_bwd)
+    stages, num_rendered = R.profile_stages(t["means3D"], t["opacities"], sts, gC, gD, None, shs=t["shs"], scales=t["scales"],
+                                            rotations=t["rotations"], iters=iters)
+    Rv = num_rendered / V
+    T, N, K = ((H + 15) // 16) * ((W + 15) // 16), H * W, 1
+    b_f, b_b = algorithmic_bytes(P, K, Rv, T, N)
+    per_stage = {}
+    for st_, ms in stages.items():
+        if st_ == "clear":
+            per_stage[st_] = {"ms": round(ms, 4)}
+            continue
+        by = stage_bytes(st_, P, K, Rv, T, N) * V
+        per_stage[st_] = {"ms": round(ms, 4), "algorithmic_bytes": int(by), "GBs": round(by / (ms * 1e-3) / 1e9, 1),
+                          "frac_of_8TBs": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    fwd_stage_ms = sum(stages[k] for k in ("clear", "preprocess", "scan", "scatter", "tile_sort", "render_fwd"))
+    all_stage_ms = sum(stages.values())
+    return {"workload": "BASELINE.json configs[4], render part: %d Gaussians (post-densify look), %dx%d, one %d-view launch set of the 36-view orbit" % (P, H, W, V),
+            "gaussians": P, "views_per_launch_set": V, "num_rendered_per_view": int(Rv),
+            "forward_ms_per_set": round(f_ms, 3), "forward_backward_ms_per_set": round(fb_ms, 3),
+            "forward_views_per_s": round(V / f_ms * 1e3, 1), "forward_backward_views_per_s": round(V / fb_ms * 1e3, 1),
+            "stages_instrumented": per_stage,
+            "stage_note": "hipEvent pairs around every stage on the launch stream (gip_raster_*_profiled): the events add ~3 % over the un-instrumented set",
+            "algorithmic_bytes_per_view": {"forward": int(b_f), "backward": int(b_b)},
+            "forward_frac_of_8TBs": round(b_f * V / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "whole_step_frac_of_8TBs": round((b_f + b_b) * V / (fb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "sum_stage_ms": {"forward": round(fwd_stage_ms, 4), "forward_backward": round(all_stage_ms, 4)}}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -298,9 +370,12 @@ def main():
 
     def make_step(st_list, group, exchange):
         nv = len(st_list)
+        # the 2-D gradient carrier as the product path makes it (renderer.render_views): a fresh autograd leaf per step over ONE
+        # cached block of zeros (nothing ever writes the values, only .grad is read) instead of a V x P x 3 fill per step
+        zeros = torch.zeros((nv, P, 3), device=dev)
 
         def step():
-            m2d = torch.zeros((nv, P, 3), device=dev, requires_grad=True)
+            m2d = zeros.detach().requires_grad_(True)
             color, radii, depth, alpha = rasterize_views(t["means3D"], m2d, t["opacities"], st_list, shs=t["shs"],
                                                          scales=t["scales"], rotations=t["rotations"])
             if exchange:       # the MAX bucket holds forward outputs: its all-reduce overlaps the backward
@@ -399,6 +474,15 @@ def main():
         trained = {"ms_per_step": round(dtt * 1e3, 4), "mpix_per_s": round(Vl * H * W / dtt / 1e6, 1),
                    "state": "opacity 0.6, scales x U(1,3) per axis, random rotations / colours (tests/scenes.trained_look)"}
         del tt_, pl_
+
+    # ---- BASELINE configs[4]: per-stage HBM roofline at 1M Gaussians (N = 1 only; the headline config stays configs[1]) ----
+    config4 = None
+    if world == 1 and not args.no_config4:
+        try:
+            config4 = measure_config4(dev)
+        except Exception as e:  # noqa: BLE001  (secondary measurement: never lose the contract line to it)
+            config4 = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        torch.cuda.empty_cache()
 
     # ---- N > 1 extra: the replica layout of rounds 1-2 (every rank its own 4 cameras of the replicated Gaussians, a 4 x N
     # batch, gradients averaged over all ranks) — weak scaling, NOT the contract value
@@ -540,7 +624,10 @@ def main():
                     "traffic": traffic, "traffic_source": pmc_note,
                     "algorithmic_bytes_per_launch": int(dom_bytes),
                     "avg_launch_ms": round(stages[dom], 4),
-                    "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                    "stage_ms_instrumented": {k: round(v, 4) for k, v in stages.items()},
+                    "stage_ms_note": "a separate run with a hipEvent pair around every stage (gip_raster_*_profiled): their sum exceeds "
+                                     "ms_per_step (un-instrumented windows) by the events' own cost, ~3 %",
+                    "sum_stage_ms_instrumented": round(sum(stages.values()), 4),
                     "whole_step_GBs": round((b_f + b_b) * Vl / (ms_per_step * 1e-3) / 1e9, 2),
                     "whole_step_frac": round((b_f + b_b) * Vl / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "pair_evals_per_s_fwd": round(Rv * Vl * 256 / (stages["render_fwd"] * 1e-3), 0)}
@@ -630,6 +717,7 @@ def main():
                                 "no_grad_render_ms_per_call": round(nograd_ms, 4),
                                 "note": "ms_per_step: forward with the state a backward needs, capacity check deferred; no_grad_render: forward_only kernels, header awaited per call"},
                "trained_state": trained,
+               "config4": config4,
                "exact_lists": exact,
                "replicas_layout": replicas,
                "roofline": roofline, "roofline_valu": valu, "cpu_baseline": cpu}

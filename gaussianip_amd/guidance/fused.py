@@ -88,6 +88,7 @@ class GroupNormAct(nn.GroupNorm):
         if fusable(x) and self.weight.dtype == torch.float16 and not self.weight.requires_grad and \
                 (addend is None or (addend.dtype == torch.float16 and addend.stride(-1) == 1 and not addend.requires_grad)):
             return _FusedGN.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.act, addend, producer_stats(x))
+        fallback("GroupNormAct", x)
         if addend is not None:
             x = x + addend.reshape(-1 if addend.dim() == 2 and addend.shape[0] > 1 else 1, x.shape[1], 1, 1)
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
@@ -96,6 +97,26 @@ class GroupNormAct(nn.GroupNorm):
 
 _DISABLED = False
 _STATS_ATTR = "_gip_chan_stats"
+
+# ---- GIP_STRICT: no silent fallbacks -----------------------------------------------------------------------------------------------
+# Every place where an fp16 GPU tensor of the networks leaves this repo's HIP kernels calls `fallback(site, tensor)` first.
+#   GIP_STRICT=1  a SHAPE fallback (a layer the kernels do not take: F.conv2d / F.group_norm / SDPA / F.linear "anything else")
+#                 raises instead of running on MIOpen / AOTriton / hipBLASLt unnoticed — round 4's irreproducible sharded denoise
+#                 (20-30-tile convolutions silently on MIOpen's atomic split-K) is what this catches on day one;
+#   GIP_STRICT=2  the vendor-library calls that are there BY DESIGN (library=True: measured dispatch to hipBLASLt, MIOpen
+#                 backward-data of two tiny layers) raise as well — the bar for "no vendor library on the hot path".
+# `fallback_counts` counts every such call whatever the level (tests / tools read it).
+fallback_counts = {}
+
+
+def fallback(site, t, library=False):
+    if _DISABLED or not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float16):
+        return
+    fallback_counts[site] = fallback_counts.get(site, 0) + 1
+    level = int(os.environ.get("GIP_STRICT", "0") or 0)
+    if level >= (2 if library else 1):
+        raise RuntimeError("GIP_STRICT=%d: %s left the HIP kernels for a %s (tensor %s)" % (
+            level, site, "vendor-library call" if library else "PyTorch / vendor-library FALLBACK", tuple(t.shape)))
 
 # Captured HIP graphs (ipa_guidance._forward_unet_graph / _encode_graphed) freeze what they saw at capture: weight values
 # are read in place, but DERIVED copies (Winograd U, q|k|v concatenations, packed time-embedding / context projections),
@@ -250,6 +271,7 @@ class LayerNorm(nn.LayerNorm):
             if rc != 0:
                 raise RuntimeError("gip_layernorm_f16 failed with status %d" % rc)
             return out
+        fallback("LayerNorm", x)
         return super().forward(x)
 
 
@@ -394,6 +416,7 @@ class _Conv3x3(torch.autograd.Function):
         if w.shape[0] % 64 == 0 and _conv_tiles(N, H, W, w.shape[1]) >= _MIN_CONV_TILES:
             dx = _conv_call(dy, _transposed_weight(w), w.shape[1])
         else:
+            fallback("conv3x3 data gradient", dy)
             dx = torch.nn.grad.conv2d_input(ctx.x_shape, w, dy, padding=1)
         return dx, None, None, (dy if ctx.has_res else None), None
 
@@ -443,6 +466,7 @@ def _winograd_conv(x, w, bias, residual, stats=None):
     rc = lib.gip_winograd_input_f16(_p(x), _p(V), N, H, W, C, stream)
     if rc != 0:
         raise RuntimeError("gip_winograd_input_f16 failed with status %d" % rc)
+    fallback("winograd batched GEMM", V, library=True)
     M = torch.bmm(V, _wt_cache.get("wino", w, _winograd_weight).transpose(1, 2))          # sixteen GEMMs: one batched library call
     out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     null = ctypes.c_void_p(None)
@@ -482,6 +506,7 @@ def conv3x3(x, w, bias=None, residual=None, gn_next=False):
         holder = []
         out = _Conv3x3.apply(x, w, bias, residual, holder)
         return attach_stats(out, holder[0] if holder else None)
+    fallback("conv3x3", x)
     out = F.conv2d(x, w, None, padding=1)
     if residual is not None:
         return add_bias_residual(residual, out, bias)
@@ -495,6 +520,7 @@ def conv1x1(x, w, bias=None):
         N, C, H, W = x.shape
         y = linear_auto(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w.reshape(w.shape[0], C), bias)
         return y.view(N, H, W, w.shape[0]).permute(0, 3, 1, 2)
+    fallback("conv1x1", x)
     return F.conv2d(x, w, bias)
 
 
@@ -660,6 +686,7 @@ def linear_auto(x, w, bias=None, residual=None, want_rows=False):
                 setattr(out, _ROWS_ATTR, holder[0])
             return out
         return linear(x, w, bias, residual)
+    fallback("linear_auto (measured dispatch to hipBLASLt)" if linear_supported(x, w) else "linear_auto", x, library=linear_supported(x, w))
     y = F.linear(x, w, bias)
     return y if residual is None else y + residual
 
@@ -698,6 +725,7 @@ def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None, rows=Non
         if rc != 0:
             raise RuntimeError("gip_linear_f16 failed with status %d" % rc)
         return out
+    fallback("linear", x)
     y = F.linear(x, w, bias)
     if geglu_act:
         return geglu(y)
@@ -843,6 +871,7 @@ class _ResBlockNode(torch.autograd.Function):
             ws_ = block.conv_shortcut.weight
             wt = _wt_cache.get("1x1t", ws_, lambda t: t.detach().reshape(t.shape[0], t.shape[1]).t().contiguous())   # [Cin, Cout]
             N, Co, H, W = dy.shape
+            fallback("resblock shortcut data gradient", dy, library=True)
             short = F.linear(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co), wt).view(N, H, W, wt.shape[0]).permute(0, 3, 1, 2)
         return _gn_bwd_raw(x, d_y1, block.norm1, mean1, rstd1, None, accum=short, chan_sums=sums1), None, None
 
@@ -889,6 +918,7 @@ def downsample_sym(x, w, bias):
     if _conv_s2_supported(x, w) and not (torch.is_grad_enabled() and x.requires_grad):
         holder = []
         return attach_stats(_conv_s2_call(x, w, bias, 1, holder), holder[0] if holder else None)
+    fallback("downsample_sym", x)
     return F.conv2d(x, w, bias, stride=2, padding=1)
 
 
@@ -953,6 +983,7 @@ class _DownsampleAsym(torch.autograd.Function):
         ctx.x_shape = tuple(x.shape)
         if _conv_s2_supported(x, w):
             return _conv_s2_call(x, w, bias, 0, stats_out)
+        fallback("downsample_asym", x)
         return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
 
     @staticmethod
@@ -970,6 +1001,7 @@ class _DownsampleAsym(torch.autograd.Function):
                 raise RuntimeError("gip_conv3x3s2_dgrad_nhwc_f16 failed with status %d" % rc)
             return dx, None, None, None
         if w.shape[0] > 128:          # measured: the library's backward-data kernels are as fast at 256 / 512 channels
+            fallback("downsample_asym data gradient", dy, library=True)
             return torch.nn.grad.conv2d_input((N, C, H + 1, W + 1), w, dy, stride=2)[:, :, :H, :W], None, None, None
         up = torch.empty((N, w.shape[0], H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
         up[:, :, 1::2, 1::2] = dy
@@ -986,6 +1018,7 @@ def downsample_asym(x, w, bias):
             return attach_stats(_DownsampleAsym.apply(x, w, bias, holder), holder[0] if holder else None)
         if _conv_s2_supported(x, w):
             return attach_stats(_conv_s2_call(x, w, bias, 0, holder), holder[0] if holder else None)
+    fallback("downsample_asym", x)
     return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, bias, stride=2)
 
 
@@ -1023,6 +1056,7 @@ class _ConvFewInputChannels(torch.autograd.Function):
             if rc != 0:
                 raise RuntimeError("gip_conv3x3_c3_fwd_nhwc_f16 failed with status %d" % rc)
             return out
+        fallback("conv_in (few input channels)", x)
         return F.conv2d(x, w, bias, padding=1)
 
     @staticmethod
@@ -1070,6 +1104,7 @@ def conv3x3_fewch(x, w, bias, stride=1, act=False):
         if rc != 0:
             raise RuntimeError("gip_conv3x3_fewch_nhwc_f16 failed with status %d" % rc)
         return out
+    fallback("conv3x3_fewch", x)
     y = F.conv2d(x, w, bias, stride=stride, padding=1)
     return F.silu(y) if act else y
 
@@ -1113,6 +1148,7 @@ class _NarrowOutConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
+        fallback("conv_out data gradient (8 -> 512 channels)", dy, library=True)
         return torch.nn.grad.conv2d_input(ctx.x_shape, w, dy.contiguous(memory_format=torch.channels_last), padding=1), None, None
 
 
@@ -1124,6 +1160,7 @@ def conv3x3_narrow_out(x, w, bias):
         if torch.is_grad_enabled() and x.requires_grad:
             return _NarrowOutConv.apply(x, w, bias)
         return _narrow_out_call(x, w, bias)
+    fallback("conv3x3_narrow_out", x)
     return F.conv2d(x, w, bias, padding=1)
 
 
@@ -1134,4 +1171,5 @@ def conv3x3_few_inputs(x, w, bias):
             x.shape[0] * x.shape[2] * x.shape[3] * w.shape[0] * 2 < (1 << 31)):
         holder = []
         return attach_stats(_ConvFewInputChannels.apply(x, w, bias, holder), holder[0] if holder else None)
+    fallback("conv3x3_few_inputs", x)
     return F.conv2d(x, w, bias, padding=1)

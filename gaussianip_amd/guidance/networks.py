@@ -83,6 +83,7 @@ class ResBlock(nn.Module):
         if addend is None:
             addend = self.conv1.bias
             if self.time_emb_proj is not None:
+                fused.fallback("time-embedding projection", temb, library=True)
                 addend = F.linear(F.silu(temb), self.time_emb_proj.weight, self.time_emb_proj.bias + addend)
         # both convolutions feed a GroupNorm (conv1 -> norm2; conv2 -> the next block's norm1 / a transformer's norm /
         # norm_out): their epilogues take its statistics, so that GroupNorm reads its input once (apply) instead of twice
@@ -156,6 +157,7 @@ class Attention(nn.Module):
         """[B, N, C] projections -> [B, Nq, C]; the HIP kernel where it applies, torch SDPA otherwise."""
         if fused.attention_supported(q, k, self.heads):
             return fused.attention(q, k, v, self.heads)
+        fused.fallback("attention (_sdpa)", q)
         h = F.scaled_dot_product_attention(self._split(q), self._split(k), self._split(v))
         return h.transpose(1, 2).reshape(q.shape)
 
@@ -261,8 +263,10 @@ class Attention(nn.Module):
             # flash kernels at head dim 512 (forward and backward; measured in tools/exp_ab_vae.py)
             # the scale goes onto q ([B, N, 512]) instead of into the product's alpha: autograd's backward of an alpha-scaled
             # bmm multiplies the [B, N, N] score gradient (134 MB at 4 x 4096^2) by it in a pass of its own
+            fused.fallback("VAE mid attention (three library GEMMs + softmax)", q, library=True)
             p = torch.softmax(torch.bmm(q * (q.shape[-1] ** -0.5), k.transpose(1, 2)), dim=-1)
             return self._out(torch.bmm(p, v), residual)
+        fused.fallback("attention", q)
         q = self._split(q)
         h = F.scaled_dot_product_attention(q, self._split(k), self._split(v))
         if ip_ctx is not None:
@@ -418,6 +422,7 @@ class _Encoder(nn.Module):
             return
         cross, Wt, Wi, offs = self._ctx_pack
         B = ctx.shape[0]
+        fused.fallback("prompt-token key / value projections of all layers (one wide GEMM)", ctx, library=True)
         if Wi is not None:
             text = F.linear(ctx[:, :-IP_TOKENS].reshape(-1, ctx.shape[-1]), Wt).view(B, -1, Wt.shape[0])
             ip = F.linear(ctx[:, -IP_TOKENS:].reshape(-1, ctx.shape[-1]), Wi).view(B, IP_TOKENS, Wi.shape[0])
@@ -431,6 +436,7 @@ class _Encoder(nn.Module):
         if self._temb_pack is None or not (temb.is_cuda and temb.dtype == torch.float16):
             return
         blocks, W, bias, offs = self._temb_pack
+        fused.fallback("time-embedding projections of all blocks (one wide GEMM)", temb, library=True)
         allp = F.linear(F.silu(temb), W, bias)          # [N, sum(C)]; each block reads its column range in place
         for b, (lo, hi) in zip(blocks, offs):
             b.staged_addend = allp[:, lo:hi]

@@ -1,0 +1,162 @@
+"""Which GPU kernels does one steady-state AHDS training step launch?  
+
+One step of BASELINE.json configs[2] runs under torch.profiler and EVERY kernel name must be accounted for:
+  * OWN        — a `__global__` function of gaussianip_amd/csrc/*.hip (parsed from the sources: the hand-written HIP path);
+  * GLUE       — PyTorch element-wise / fill / copy / index / random-number kernels and runtime blits (no math library behind them);
+  * VENDOR     — kernels of a vendor math library (hipBLASLt `Cijk_*`, rocBLAS, MIOpen, AOTriton), each family listed HERE with
+                 the call site that owns it and a launch budget.  Anything else fails the test, and so does a family over budget:
+                 a layer that silently falls off the HIP path (round 4: the 20-30-tile convolutions on MIOpen's atomic split-K)
+                 shows up as a new name or a blown budget.
+The same step runs under GIP_STRICT=1 (gaussianip_amd.guidance.fused.fallback): a SHAPE fallback raises instead of running."""
+import glob
+import json
+import os
+import re
+from argparse import ArgumentParser
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, H, W, B = 100000, 1024, 1024, 4
+
+# vendor-library kernel families allowed in the step: (regex, owner, max launches per step)
+VENDOR = [
+    (r"^(Custom_)?Cijk_", "hipBLASLt GEMMs: fused.linear_auto's measured dispatch (ff_in below 64^2, q|k|v at 16^2, K >= 2560 at few rows), "
+                          "the packed time-embedding / prompt-token projections, the VAE's q / k / v / out projections and shortcut", 120),
+]
+GLUE = [r"^void at::native::", r"^at::native::", r"__amd_rocclr_(fillBuffer|copyBuffer)", r"^void \(anonymous namespace\)::", r"hiprand",
+        r"^void at_cuda_detail::", r"^void rocprim::", r"^void hipcub::"]
+
+
+def own_kernel_names():
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "gaussianip_amd", "csrc", "*.hip")):
+        src = open(f).read()
+        for m in re.finditer(r"__global__", src):
+            head = re.sub(r"__launch_bounds__\s*\([^)]*\)", "", src[m.end():m.end() + 400]).replace("void", " ", 1)
+            names.add(re.search(r"\b([A-Za-z_]\w*)\s*\(", head).group(1))
+    return names
+
+
+DENY = [r"SoftMax", r"softmax"]        # the VAE's mid attention as GEMM + softmax passes over a 134 MB score tensor (VERDICT r4 missing 5)
+
+
+def classify(name, own):
+    base = re.sub(r"^void\s+", "", name)
+    if any(re.search(rx, name) for rx in DENY):
+        return "unknown"
+    if any(re.search(r"(^|[^A-Za-z0-9_])%s([^A-Za-z0-9_]|$)" % re.escape(k), base) or base.startswith("_Z%d%s" % (len(k), k)) for k in own):
+        return "own"
+    for i, (rx, _, _) in enumerate(VENDOR):
+        if re.search(rx, base):
+            return "vendor:%d" % i
+    if any(re.search(rx, name) for rx in GLUE):
+        return "glue"
+    return "unknown"
+
+
+def test_classifier_on_recorded_names():
+    """CPU-independent sanity of the classifier on names taken from profiles/r04_ahds_step_summary.txt (runs on the GPU box with the
+    suite; needs no device)."""
+    own = own_kernel_names()
+    assert len(own) >= 55 and {"conv3x3_kernel", "attn_fwd_q2_kernel", "gip_render_forward_kernel", "gn_apply_kernel", "anpg_loss_kernel"} <= own
+    cases = {
+        "_Z14conv3x3_kernelILi128ELi2ELi9ELb0ELb0EEvPKDF16_S1_S1_S1_PDF16_iiiiiiiiPfiiiS3_9GnBwdArgsi": "own",
+        "void gn_apply_kernel<0>(half8 const*, half8 const*, __half const*)": "own",
+        "gip_render_backward_kernel(GipKernelParams, GipRasterHeader const*)": "own",
+        "Custom_Cijk_Alik_Bljk_HHS_BH_Bias_HA_S_SAV_NTD_SK3_UserArgs_MT256x256x64_MI16x16x1_shortname0_gfx950": "vendor:0",
+        "Cijk_Alik_Bljk_HHS_BH_Bias_HA_S_SAV_UserArgs_MT128x256x64_MI16x16x1_SN": "vendor:0",
+        "void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>, std::array<char*, 1ul> >(int)": "glue",
+        "__amd_rocclr_copyBuffer": "glue",
+        "igemm_fwd_gtcx35_nhwc_fp16_bx0_ex1_bt128x128x32_wt32x32x8_ws1x1_wr2x2_ta1x8x2x1_1x4x1x64_tb1x8x2x1_1x4x1x64": "unknown",
+        "naive_conv_ab_nonpacked_fwd_nhwc_half_double_half": "unknown",
+        "attn_fwd": "unknown",
+        "void at::native::(anonymous namespace)::cunn_SoftMaxForwardGmem<8, c10::Half, float, c10::Half>": "unknown",
+    }
+    for name, want in cases.items():
+        assert classify(name, own) == want, (name, classify(name, own))
+
+
+def test_every_kernel_of_a_steady_state_step_is_accounted_for(monkeypatch):
+    from torch.profiler import ProfilerActivity, profile
+    from gaussianip_amd.arguments import OptimizationParams, PipelineParams
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance, fused, ipa_guidance
+    from gaussianip_amd.guidance.prompts import PromptProcessor
+    from gaussianip_amd.poser import Skeleton
+    from gaussianip_amd.scene import GaussianModel
+    from gaussianip_amd.system import StageOneStep
+    from gaussianip_amd.utils import BasicPointCloud
+    monkeypatch.setenv("GIP_STRICT", "1")
+    dev = torch.device("cuda")
+    torch.manual_seed(42)
+    gm = GaussianModel(0)
+    gm.create_from_pcd(BasicPointCloud(scenes.human_points(P, np.random.default_rng(42)).astype(np.float32), np.full((P, 3), 0.5, np.float32), None), 4.0)
+    gm.training_setup(OptimizationParams(ArgumentParser()), fused=True)
+    skel = Skeleton(dev)
+    skel.scale(-10)
+    stage = StageOneStep(gm, PipelineParams(ArgumentParser()), torch.zeros(3, device=dev), skeleton=skel)
+    g = torch.Generator(device=dev).manual_seed(1)
+    tokens = (torch.randn(1, 4, 768, device=dev, generator=g) * 0.1, torch.zeros(1, 4, 768, device=dev),
+              torch.randn(1, 4, 768, device=dev, generator=g) * 0.1)
+    guidance = StableDiffusionGuidance(GuidanceConfig(), image_embeds_provider=lambda gd: tokens)
+    pp = PromptProcessor("a person wearing a coat", lambda texts: torch.randn(len(texts), 77, 768, device=dev, generator=g).half() * 0.1,
+                         negative_prompt="blurry")
+    guidance.prepare_for_sds(pp.prompt, pp.negative_prompt, pp.null_prompt)
+    prompt_utils = pp()
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    cam_rng = np.random.default_rng(3)
+
+    def step(i):
+        batch = scenes.train_batch(cam_rng, B, H, W, device=None)
+        loss, out, gout = stage.training_step(i, batch, guidance, prompt_utils, True)
+        stage.optimizer_step(loss, i, scaler=scaler)
+        return loss
+
+    def profiled(i):
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            step(i)
+            torch.cuda.synchronize()
+        counts = {}
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and str(ev.device_type).endswith("CUDA") and ev.name and not ev.name.startswith("Memcpy") \
+                    and not ev.name.startswith("Memset"):
+                counts[ev.name] = counts.get(ev.name, 0) + 1
+        return counts
+
+    for i in range(4):                     # eager -> capture -> replay, capacity hint settled
+        step(i)
+    own = own_kernel_names()
+    counts = profiled(4)
+    seen_own = {k for k in counts if classify(k, own) == "own"}
+    mode = "graph replay (the default step)"
+    if not any("conv3x3_kernel" in k for k in seen_own):
+        # the profiler of this build does not show kernels launched from a HIP-graph replay: the same kernels eagerly on one stream
+        monkeypatch.setattr(ipa_guidance, "_GRAPH_DENOISE", False)
+        monkeypatch.setattr(ipa_guidance, "_GRAPH_VAE", False)
+        monkeypatch.setattr(ipa_guidance, "_TWO_STREAMS", False)
+        step(5)
+        counts = profiled(6)
+        mode = "eager launches, one stream (graph replays are invisible to this profiler build)"
+    table = {}
+    for name, n in counts.items():
+        table.setdefault(classify(name, own), {})[name] = n
+    report = {"mode": mode, "launches": {k: sum(v.values()) for k, v in table.items()},
+              "vendor": {VENDOR[int(k.split(":")[1])][0]: v for k, v in table.items() if k.startswith("vendor")},
+              "unknown": table.get("unknown", {}), "fallback_counts": dict(fused.fallback_counts)}
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):                    # written BEFORE the assertions: a failing run leaves its table behind
+        json.dump(report, open(os.path.join(d, "kernel_whitelist.json"), "w"), indent=1)
+    print(json.dumps(report["launches"]), json.dumps(report["unknown"])[:2000])
+    assert any("conv3x3_kernel" in k for k in table.get("own", {})) and any("attn_fwd" in k for k in table.get("own", {})) and \
+        any("gip_render_forward_kernel" in k for k in table.get("own", {})), "the profile does not contain the step's own kernels: %s" % mode
+    assert not table.get("unknown"), "kernels outside the whitelist: %s" % json.dumps(table["unknown"], indent=1)[:3000]
+    for k, v in table.items():
+        if k.startswith("vendor"):
+            rx, owner, budget = VENDOR[int(k.split(":")[1])]
+            assert sum(v.values()) <= budget, "%d launches of %s (budget %d; owner: %s)" % (sum(v.values()), rx, budget, owner)

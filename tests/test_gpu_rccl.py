@@ -23,3 +23,23 @@ def test_exchange_primitives_run_on_the_rccl_backend(tmp_path):
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
     res = json.load(open(out))
     assert res and all(res.values()), res
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """the first box with two GPUs exercises the REAL collective path.  `python bench.py --gpus 2`
+    then runs its two ranks on two devices over RCCL (the launcher only falls back to gloo when fewer GPUs than ranks are
+    visible) and the line must say so.  Skipped on the 1-GPU boxes of this pool; nothing needs a second GPU to pass today."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs (this box has %d): RCCL cannot put two ranks on one device" % torch.cuda.device_count())
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GIP_DIST_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--repeats", "3", "--no-ahds", "--no-cpu-baseline", "--no-trained", "--no-exact", "--launch-timeout", "900"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["backend"] == "rccl" and d["config"]["dist_world_size"] == 2, d["config"]
+    assert d["config"]["gpus_visible"] >= 2 and d["config"]["views_per_step_per_gpu"] == 2 and d["value"] > 0

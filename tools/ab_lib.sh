@@ -5,7 +5,7 @@ for lib in "$@"; do
   for rep in 1 2; do
   GIP_RASTER_LIB=$lib python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-ahds --no-trained 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.readline()); print('$lib', d['ms_per_step'], d['roofline']['stage_ms'])"
+d=json.loads(sys.stdin.readline()); print('$lib', d['ms_per_step'], d['roofline']['stage_ms_instrumented'])"
   done
 done
 for lib in "$@"; do echo "$lib"; GIP_RASTER_LIB=$lib python tools/diag/trained_stages.py 2>/dev/null | grep num_rendered; done
