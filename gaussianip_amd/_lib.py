@@ -298,6 +298,10 @@ def nn_lib():
                                           ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
         lib.gip_timestep_embedding_f16.restype = ctypes.c_int
         lib.gip_timestep_embedding_f16.argtypes = [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp]
+        lib.gip_softmax_rows_f16.restype = ctypes.c_int
+        lib.gip_softmax_rows_f16.argtypes = [_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, _vp]
+        lib.gip_softmax_rows_backward_f16.restype = ctypes.c_int
+        lib.gip_softmax_rows_backward_f16.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, _vp]
         lib.gip_scale_cast_f16.restype = ctypes.c_int
         lib.gip_scale_cast_f16.argtypes = [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, _vp]
         _nn = _Counted(lib)

@@ -6,8 +6,8 @@
 // by (depth, index).  MI355X-first formulation (no global multi-pass radix sort, no host read-back):
 //
 //   1. tile histogram               (done inside preprocess, integer atomics)
-//   2. gip_scan_kernel              exclusive scan of the V*T tile counts -> ranges; scan of the
-//                                   per-workgroup tiles_touched sums -> instance offsets; header
+//   2. gip_scan_kernel              exclusive scan of the V*T tile counts -> ranges; longest-first launch order; scan of
+//                                   the per-workgroup tiles_touched sums -> instance offsets; header
 //   3. gip_scatter_kernel           every (Gaussian, tile) instance takes a slot in its tile's bucket
 //                                   (one returning integer atomic) and stores key = depth_bits<<32 | index
 //   4. gip_tile_sort_kernel /       per-tile sort of the bucket (bitonic network on u64, all-ascending "flip" form so any
@@ -20,235 +20,184 @@
 #include "gip_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// scan: three workgroups of 1024 threads (one per independent job), each thread owns a contiguous chunk
+// scan: ceil(V*T / 1024) + 1 INDEPENDENT workgroups of 1024 threads, one launch, no inter-workgroup communication
 // ------------------------------------------------------------------------------------------------
-#ifndef SCAN_SKIP
-#define SCAN_SKIP 0
-#endif
+// Round 5.  The round-2..4 kernel ran three workgroups (tile prefixes / launch order / instance offsets) whose threads each
+// walked a 16-tile chunk out of LDS: 17.5 us at V*T = 16384 with 83 % of the launch idle.  Now every
+// workgroup owns ONE 1024-tile chunk (a tile per thread) and derives everything it needs from the raw counts itself:
+//   pass 1  all V*T counts, coalesced, 8 loads in flight per thread: sums of (count, segments, checkpoint slots) over the
+//           tiles BEFORE its chunk and over all tiles, the six size-class counts before its chunk and in total (wave ballots:
+//           a 64-tile group lies entirely before, inside or behind a 1024-aligned chunk), the longest list;
+//   pass 2  its own chunk: block-wide exclusive scan of the three quantities (tile_start / seg_start / ckpt_start = before +
+//           scan), class ranks by ballot (tile_order position = class base + class-before + rank).
+// The redundant pass 1 costs V*T * 8 bytes of L2 reads per workgroup (128 KB at four 1024^2 views) and removes every
+// dependency between workgroups.  Workgroup 0 also writes the header (+ the pinned host mirror) and zeroes the per-tile sort's
+// work cursors; the extra last workgroup turns the per-256-Gaussian sums of tiles_touched into instance offsets.
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define SCAN_CHUNK 16384        // tiles per round: counts + prefixes in LDS, padded 17/16 (2 x 68 KB of the 160 KB)
-#define SCAN_LDS_WORDS(n) ((n) + ((n) >> 4) + 2)
-
-struct U3 { uint32_t a, b, c; };
-
-// exclusive scan of three quantities at once across the 1024 threads
-__device__ __forceinline__ U3 block_excl_scan3(U3 v, uint32_t (*s_wave)[SCAN_WAVES], U3* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  U3 incl = {gip_wave_incl_scan_u32(v.a), gip_wave_incl_scan_u32(v.b), gip_wave_incl_scan_u32(v.c)};
-  if (lane == 63) { s_wave[0][wave] = incl.a; s_wave[1][wave] = incl.b; s_wave[2][wave] = incl.c; }
-  __syncthreads();
-  U3 base = {0, 0, 0}, tot = {0, 0, 0};
-#pragma unroll
-  for (int w = 0; w < SCAN_WAVES; w++) {
-    const uint32_t xa = s_wave[0][w], xb = s_wave[1][w], xc = s_wave[2][w];
-    if (w < wave) { base.a += xa; base.b += xb; base.c += xc; }
-    tot.a += xa; tot.b += xb; tot.c += xc;
-  }
-  __syncthreads();
-  *total = tot;
-  return {base.a + incl.a - v.a, base.b + incl.b - v.b, base.c + incl.c - v.c};
-}
+#define SCAN_CHUNK SCAN_THREADS        // tiles per workgroup
 
 __device__ __forceinline__ uint32_t nseg_of(uint32_t count) { return (count + GIP_SEGMENT - 1) / GIP_SEGMENT; }
-__device__ __forceinline__ int bucket_of(uint32_t c) { return c ? 32 - __clz(c) : 0; }
 
 // Launch order for the per-tile kernels: tiles grouped into 6 size classes and emitted longest class first,
-// so the long lists start early and the short ones fill the tail.  Order inside a class is arbitrary (it only
-// decides which workgroup handles which tile; results do not depend on it).  Wave-aggregated: one LDS atomic
-// per (wave, class, round) — the empty-tile class would otherwise serialise 64 lanes on one LDS word.
+// so the long lists start early and the short ones fill the tail.  Inside a class: tile index order.
 //   class 0: >= 2048 | 1: 1024..2047 | 2: 512..1023 | 3: 128..511 | 4: 1..127 | 5: empty
 #define ORDER_CLASSES 6
 __device__ __forceinline__ int class_of(uint32_t c) {
   return c >= 2048 ? 0 : c >= 1024 ? 1 : c >= 512 ? 2 : c >= 128 ? 3 : c >= 1 ? 4 : 5;
 }
-// LDS image of the tile counts: one pad word per 16, so that a thread walking its own 16-word chunk (stride 17 across
-// lanes) and a wave reading 64 consecutive counts are both bank-conflict free (unpadded, the chunk walk is 16-way
-// conflicted: it made the prefix role 32 us long)
-__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
-__device__ void heavy_first_order(const uint32_t* lds_counts, const uint32_t* ca, const uint32_t* cb,
-                                  uint32_t* __restrict__ order, int n, uint32_t* s_wcnt /*[ORDER_CLASSES * SCAN_WAVES + ORDER_CLASSES]*/,
-                                  uint32_t* class_end /*[4] out, thread 0*/) {
-  // counting sort by class without atomics: every wave owns a contiguous slice of the tiles, counts its classes with
-  // ballots (pass 1), the 6 x 16 counts become write cursors (class-major, wave-minor: longest class first, index order
-  // inside a class), and pass 2 places each tile at cursor + rank inside the ballot.
-  auto count_of = [&](int i) -> uint32_t { return lds_counts ? lds_counts[pad16(i)] : ca[i] + cb[i]; };
+// exclusive scan of v over the 1024 threads; *total = the sum.  s_w: SCAN_WAVES words of LDS (reused across calls: two barriers)
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const int per_wave = ((n + SCAN_WAVES - 1) / SCAN_WAVES + 63) & ~63;
-  const int lo = wave * per_wave, hi = min(n, lo + per_wave);
-  uint32_t cnt[ORDER_CLASSES];
-#pragma unroll
-  for (int c = 0; c < ORDER_CLASSES; c++) cnt[c] = 0;
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    const int i = i0 + lane;
-    const int cls = i < hi ? class_of(count_of(i)) : -1;
-#pragma unroll
-    for (int c = 0; c < ORDER_CLASSES; c++) cnt[c] += (uint32_t)__popcll(__ballot(cls == c));
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int c = 0; c < ORDER_CLASSES; c++) s_wcnt[c * SCAN_WAVES + wave] = cnt[c];
-  }
+  const uint32_t incl = gip_wave_incl_scan_u32(v);
   __syncthreads();
-  uint32_t cur[ORDER_CLASSES];
-  {
-    uint32_t run = 0;
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int c = 0; c < ORDER_CLASSES; c++) {
-      for (int w = 0; w < SCAN_WAVES; w++) {
-        const uint32_t k = s_wcnt[c * SCAN_WAVES + w];
-        if (w == wave) cur[c] = run;
-        run += k;
-      }
-      if (threadIdx.x == 0) {
-        if (c == 0) class_end[1] = run;                  // sort phase A: lists >= 2048 = [0, class_end[1])
-        if (c == 1) class_end[2] = run;                  // (>= 1024)
-        if (c == 2) class_end[0] = run;                  // sort phase M: 512..2047 = [class_end[1], class_end[0])
-        if (c == 4) class_end[3] = run;                  // sort phase B: 1..511 = [class_end[0], class_end[3]) ; beyond: empty tiles
-      }
-    }
-  }
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    const int i = i0 + lane;
-    const int cls = i < hi ? class_of(count_of(i)) : -1;
+  for (int w = 0; w < SCAN_WAVES; w++) { const uint32_t x = s_w[w]; base += w < wave ? x : 0u; tot += x; }
+  *total = tot;
+  return base + incl - v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
-    for (int c = 0; c < ORDER_CLASSES; c++) {
-      const unsigned long long m = __ballot(cls == c);
-      if (cls == c) order[cur[c] + __popcll(m & lt)] = (uint32_t)i;
-      cur[c] += (uint32_t)__popcll(m);
-    }
-  }
+  for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+  return v;
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_count_b,
                 uint32_t* __restrict__ tile_start,
-                uint32_t* __restrict__ seg_start, uint32_t* __restrict__ ckpt_start, uint32_t* __restrict__ seg_tile,
+                uint32_t* __restrict__ seg_start, uint32_t* __restrict__ ckpt_start,
                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_offset,
                 uint32_t* __restrict__ tile_order, GipRasterHeader* __restrict__ header, uint32_t* __restrict__ host_header) {
-  __shared__ uint32_t s_wave[3][SCAN_WAVES];
-  __shared__ uint32_t s_bucket[ORDER_CLASSES * SCAN_WAVES];
-  __shared__ uint32_t s_class[4];
-  // ---- tiles: instance ranges, segment ranges, checkpoint slots (one pass, three running sums) ----
-  // counts are first staged in LDS with coalesced loads (each thread then walks its contiguous chunk
-  // out of LDS instead of issuing serial dependent global loads)
-  extern __shared__ uint32_t s_cnt[];
+  __shared__ uint32_t s_w[SCAN_WAVES];
+  __shared__ uint32_t s_acc[2][3 + ORDER_CLASSES];       // [before | total][count, segments, checkpoints, classes 0..5]
+  __shared__ uint32_t s_max;
+  __shared__ uint32_t s_cls[ORDER_CLASSES][SCAN_WAVES];
   const int n = kp.V * kp.T;
-  const int role = blockIdx.x;
-  if (role == 2) {
+  const int n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x == n_chunks) {
+    // ---- instance offsets: exclusive scan of the per-256-Gaussian sums of tiles_touched (V * nblk entries) ----
     const int nb = kp.V * kp.nblk;
-    const int ch = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int l2 = threadIdx.x * ch, h2 = min(nb, l2 + ch);
-    U3 s2 = {0, 0, 0};
-    for (int i = l2; i < h2; i++) s2.a += block_sums[i];
-    U3 t2;
-    U3 r2 = block_excl_scan3(s2, s_wave, &t2);
-    for (int i = l2; i < h2; i++) { block_offset[i] = r2.a; r2.a += block_sums[i]; }
-    if (threadIdx.x == 0) block_offset[nb] = t2.a;
+    const int per = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = tid * per, hi = min(nb, lo + per);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += block_sums[i];
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, s_w, &total);
+    for (int i = lo; i < hi; i++) { block_offset[i] = run; run += block_sums[i]; }
+    if (tid == 0) block_offset[nb] = total;
     return;
   }
-  // Three independent jobs, one workgroup each (blockIdx.x = role), so that their latency chains overlap:
-  //   role 0: tile prefixes (ranges / segments / checkpoint slots) + totals in the header
-  //   role 1: longest-first launch order + class boundaries in the header
-  //   role 2: per-workgroup tiles_touched sums -> instance offsets
-  // Counts are staged in LDS with coalesced loads, 8 independent load pairs in flight per thread (a plain loop would
-  // wait for each pair in turn), SCAN_CHUNK tiles at a time.
-  auto stage_counts = [&](int c0, int cn) {
-    for (int i0 = threadIdx.x; i0 < cn; i0 += 8 * SCAN_THREADS) {
-      uint32_t va[8], vb[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * SCAN_THREADS;
-        va[u] = i < cn ? tile_count[c0 + i] : 0u;
-        vb[u] = i < cn ? tile_count_b[c0 + i] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * SCAN_THREADS;
-        if (i < cn) s_cnt[pad16(i)] = va[u] + vb[u];
-      }
-    }
-    __syncthreads();
-  };
-  if (role == 1) {
-    const bool in_lds = SCAN_LDS_WORDS(n) <= 2 * SCAN_LDS_WORDS(SCAN_CHUNK);   // V*T <= 32768; beyond, the two passes read global memory
-    if (in_lds) stage_counts(0, n);
-#if !(SCAN_SKIP & 1)
-    heavy_first_order(in_lds ? s_cnt : nullptr, tile_count, tile_count_b, tile_order, n, s_bucket, s_class);
-#endif
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      header->class_end[0] = s_class[0]; header->class_end[1] = s_class[1];
-      header->class_end[2] = s_class[2]; header->class_end[3] = s_class[3];
-    }
-    return;
-  }
-  // role 0, SCAN_CHUNK tiles per round with the running totals carried over: every thread owns 16 consecutive tiles of
-  // the round; the prefixes go through a second LDS array so that the global stores are coalesced (a thread's own
-  // chunk written directly costs 64 separate cache lines per wave store)
-  U3 carry = {0, 0, 0};
-  uint32_t mx = 0;
-  uint32_t* s_out = s_cnt + pad16(SCAN_CHUNK) + 1;
-  for (int c0 = 0; c0 < n; c0 += SCAN_CHUNK) {
-    const int cn = min(SCAN_CHUNK, n - c0);
-    __syncthreads();
-    stage_counts(c0, cn);
-    const int per = (cn + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int lo = threadIdx.x * per, hi = min(cn, lo + per);
-    U3 sum = {0, 0, 0};
-    for (int i = lo; i < hi; i++) {
-      const uint32_t c = s_cnt[pad16(i)], a = nseg_of(c);
-      sum.a += c; sum.b += a; sum.c += a ? a - 1 : 0;
-      mx = c > mx ? c : mx;
-    }
-    U3 total;
-    const U3 run0 = block_excl_scan3(sum, s_wave, &total);
-    for (int which = 0; which < 3; which++) {
-      uint32_t r = which == 0 ? carry.a + run0.a : which == 1 ? carry.b + run0.b : carry.c + run0.c;
-      for (int i = lo; i < hi; i++) {
-        const uint32_t c = s_cnt[pad16(i)], a = nseg_of(c);
-        s_out[pad16(i)] = r;
-        r += which == 0 ? c : which == 1 ? a : (a ? a - 1 : 0);
-      }
-      __syncthreads();
-      uint32_t* dst = (which == 0 ? tile_start : which == 1 ? seg_start : ckpt_start) + c0;
-      for (int i = threadIdx.x; i < cn; i += SCAN_THREADS) dst[i] = s_out[pad16(i)];
-      __syncthreads();
-    }
-    carry.a += total.a; carry.b += total.b; carry.c += total.c;
-  }
-  const U3 total = carry;
-  if (threadIdx.x == 0) { tile_start[n] = total.a; seg_start[n] = total.b; ckpt_start[n] = total.c; }
-  mx = gip_wave_max_u32(mx);
-  if ((threadIdx.x & 63) == 0) s_wave[0][threadIdx.x >> 6] = mx;
+  const int chunk0 = (int)blockIdx.x * SCAN_CHUNK;
+  if (tid < 2 * (3 + ORDER_CLASSES)) (&s_acc[0][0])[tid] = 0u;
+  if (tid == 0) s_max = 0u;
   __syncthreads();
-  uint32_t max_tile = 0;
-  for (int w = 0; w < SCAN_WAVES; w++) max_tile = s_wave[0][w] > max_tile ? s_wave[0][w] : max_tile;
-  if (threadIdx.x == 0) {
+  // ---- pass 1: every count once; wave-uniform "before my chunk" test (64-tile groups never straddle a 1024-aligned chunk) ----
+  uint32_t b_c = 0, b_s = 0, b_k = 0, t_c = 0, t_s = 0, t_k = 0, mx = 0;      // per-lane partial sums
+  uint32_t b_cls[ORDER_CLASSES], t_cls[ORDER_CLASSES];                         // wave-uniform class counts
+#pragma unroll
+  for (int c = 0; c < ORDER_CLASSES; c++) { b_cls[c] = 0; t_cls[c] = 0; }
+  for (int i0 = wave * 64; i0 < n; i0 += 8 * SCAN_THREADS) {
+    uint32_t va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u * SCAN_THREADS + lane;
+      va[u] = i < n ? tile_count[i] : 0u;
+      vb[u] = i < n ? tile_count_b[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int g0 = i0 + u * SCAN_THREADS;          // first tile of this wave's 64-tile group (wave-uniform)
+      if (g0 >= n) break;
+      const int i = g0 + lane;
+      const uint32_t c = va[u] + vb[u], a = nseg_of(c), k = a ? a - 1 : 0;
+      const int cls = i < n ? class_of(c) : -1;
+      const bool before = g0 < chunk0;
+      t_c += c; t_s += a; t_k += k;
+      mx = c > mx ? c : mx;
+      if (before) { b_c += c; b_s += a; b_k += k; }
+#pragma unroll
+      for (int q = 0; q < ORDER_CLASSES; q++) {
+        const uint32_t m = (uint32_t)__popcll(__ballot(cls == q));
+        t_cls[q] += m;
+        if (before) b_cls[q] += m;
+      }
+    }
+  }
+  b_c = wave_sum_u32(b_c); b_s = wave_sum_u32(b_s); b_k = wave_sum_u32(b_k);
+  t_c = wave_sum_u32(t_c); t_s = wave_sum_u32(t_s); t_k = wave_sum_u32(t_k);
+  mx = gip_wave_max_u32(mx);
+  if (lane == 0) {
+    atomicAdd(&s_acc[0][0], b_c); atomicAdd(&s_acc[0][1], b_s); atomicAdd(&s_acc[0][2], b_k);
+    atomicAdd(&s_acc[1][0], t_c); atomicAdd(&s_acc[1][1], t_s); atomicAdd(&s_acc[1][2], t_k);
+#pragma unroll
+    for (int q = 0; q < ORDER_CLASSES; q++) { atomicAdd(&s_acc[0][3 + q], b_cls[q]); atomicAdd(&s_acc[1][3 + q], t_cls[q]); }
+    atomicMax(&s_max, mx);
+  }
+  __syncthreads();
+  // ---- pass 2: this workgroup's chunk, one tile per thread ----
+  const int i = chunk0 + tid;
+  uint32_t c = 0;
+  if (i < n) c = tile_count[i] + tile_count_b[i];
+  const uint32_t a = nseg_of(c), k = a ? a - 1 : 0;
+  uint32_t tot;
+  const uint32_t e_c = block_excl_scan(c, s_w, &tot);
+  const uint32_t e_s = block_excl_scan(a, s_w, &tot);
+  const uint32_t e_k = block_excl_scan(k, s_w, &tot);
+  if (i < n) {
+    tile_start[i] = s_acc[0][0] + e_c;
+    seg_start[i] = s_acc[0][1] + e_s;
+    ckpt_start[i] = s_acc[0][2] + e_k;
+  }
+  // class ranks: ballot rank inside the wave + the counts of the chunk's earlier waves
+  const int cls = i < n ? class_of(c) : -1;
+  uint32_t rank = 0;
+#pragma unroll
+  for (int q = 0; q < ORDER_CLASSES; q++) {
+    const unsigned long long m = __ballot(cls == q);
+    if (cls == q) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cls[q][wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (cls >= 0) {
+    uint32_t pos = rank + s_acc[0][3 + cls];                    // + this class's tiles in earlier chunks
+#pragma unroll
+    for (int q = 0; q < ORDER_CLASSES; q++) pos += q < cls ? s_acc[1][3 + q] : 0u;     // + all tiles of the longer classes
+    for (int w = 0; w < wave; w++) pos += s_cls[cls][w];        // + this class's tiles in earlier waves of the chunk
+    tile_order[pos] = (uint32_t)i;
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    const uint32_t total = s_acc[1][0];
+    tile_start[n] = total; seg_start[n] = s_acc[1][1]; ckpt_start[n] = s_acc[1][2];
+    const uint32_t n0 = s_acc[1][3], n1 = s_acc[1][4], n2 = s_acc[1][5], n3 = s_acc[1][6], n4 = s_acc[1][7];
+    header->class_end[1] = n0;                          // sort phase A: lists >= 2048 = [0, class_end[1])
+    header->class_end[2] = n0 + n1;                     // (>= 1024)
+    header->class_end[0] = n0 + n1 + n2;                // sort phase M: 512..2047 = [class_end[1], class_end[0])
+    header->class_end[3] = n0 + n1 + n2 + n3 + n4;      // sort phase B: 1..511 = [class_end[0], class_end[3]); beyond: empty tiles
     header->abi_version = GIP_ABI_VERSION;
-    header->num_rendered = total.a;
-    header->overflow = (total.a > kp.capacity) ? 1u : 0u;
-    header->max_tile_count = max_tile;
-    header->num_segments = total.b;
-    header->num_checkpoints = total.c;
+    header->num_rendered = total;
+    header->overflow = (total > kp.capacity) ? 1u : 0u;
+    header->max_tile_count = s_max;
+    header->num_segments = s_acc[1][1];
+    header->num_checkpoints = s_acc[1][2];
     if (host_header) {      // pinned host mirror: the caller's capacity check needs no device-to-host copy
-      host_header[0] = GIP_ABI_VERSION; host_header[1] = total.a;
-      host_header[2] = (total.a > kp.capacity) ? 1u : 0u; host_header[3] = max_tile;
+      host_header[0] = GIP_ABI_VERSION; host_header[1] = total;
+      host_header[2] = (total > kp.capacity) ? 1u : 0u; host_header[3] = s_max;
       __threadfence_system();
     }
   }
 }
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  // > 64 KB of dynamic LDS needs the per-function opt-in (idempotent, set once per process)
-  constexpr size_t lds = 2 * SCAN_LDS_WORDS(SCAN_CHUNK) * 4;
-  static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(gip_scan_kernel),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)attr_once;
-  hipLaunchKernelGGL(gip_scan_kernel, dim3(3), dim3(SCAN_THREADS), lds, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
-                     st.seg_start, st.ckpt_start, st.seg_tile, st.block_sums, st.block_offset, st.tile_order, st.header, st.host_header);
+  const int n = kp.V * kp.T;
+  const int n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  hipLaunchKernelGGL(gip_scan_kernel, dim3(n_chunks + 1), dim3(SCAN_THREADS), 0, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
+                     st.seg_start, st.ckpt_start, st.block_sums, st.block_offset, st.tile_order, st.header, st.host_header);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@
 //             address so that the 16-pixel fragment reads are conflict-free) and reused by all nine taps; the rearranged
 //             weight [3][9][128] sits in LDS; 36 K steps of 32 per 16 pixels; 6-byte stores.
 //   conv_fewch_kernel<CIN, COUT, STRIDE>   16 / 32 / 96-channel layers of the ControlNet's conditioning stem (stride 1 and
-//             2, bias + SiLU in the epilogue) and the two narrow OUTPUT convolutions 320 -> 4, 512 -> 8: input halo once
+//             2, bias + SiLU in the epilogue), the 8-channel inputs (conv_in of the U-Net / ControlNet: 4 latent channels padded
+//             to 8 -> 320; the VAE's moment gradient 8 -> 512) and the two narrow OUTPUT convolutions 320 -> 4, 512 -> 8: input halo once
 //             in LDS, weights straight from L2 one K step ahead, the weight as the MFMA A operand (documented at the kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -266,6 +267,10 @@ extern "C" int gip_conv3x3_fewch_nhwc_f16(const void* x, const void* w, const vo
   if (Cin == 32 && Cout == 96 && stride == 2) return launch_fewch<32, 96, 2, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
   if (Cin == 96 && Cout == 96 && stride == 1) return launch_fewch<96, 96, 1, 2, 8>(x, w, bias, out, N, Hin, Win, act, s);
   if (Cin == 96 && Cout == 256 && stride == 2) return launch_fewch<96, 256, 2, 4, 4>(x, w, bias, out, N, Hin, Win, act, s);
+  // 8 input channels: conv_in of the U-Net / ControlNet (4 latent channels, padded to 8 by the host: 8 -> 320) and the data
+  // gradient of the VAE encoder's (conv_out . quant_conv) (8 moment channels -> 512)
+  if (Cin == 8 && Cout == 320 && stride == 1) return launch_fewch<8, 320, 1, 4, 8>(x, w, bias, out, N, Hin, Win, act, s);
+  if (Cin == 8 && Cout == 512 && stride == 1) return launch_fewch<8, 512, 1, 4, 4>(x, w, bias, out, N, Hin, Win, act, s);
   // the narrow OUTPUT convolutions (conv_out of the U-Net: 320 -> 4, of the VAE encoder: 512 -> 8): w holds 16 rows, rows >= Cout zero
   if (Cin == 320 && Cout == 4 && stride == 1) return launch_fewch<320, 16, 1, 1, 8>(x, w, bias, out, N, Hin, Win, act, s, 4);
   if (Cin == 512 && Cout == 8 && stride == 1) return launch_fewch<512, 16, 1, 1, 4>(x, w, bias, out, N, Hin, Win, act, s, 8);

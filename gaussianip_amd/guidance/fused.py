@@ -583,6 +583,48 @@ def attention(q, k, v, heads, k2=None, v2=None, weight2=1.0):
     return o
 
 
+class _WideHeadAttention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(D)) v for ONE wide head (the VAE encoder's 512-channel mid attention, 4096 tokens): the two products
+    forward and four backward are dense GEMMs at the FLOP minimum (hipBLASLt through torch.bmm / baddbmm — a flash-style kernel
+    would re-compute the scores in the backward and a 512-wide head does not fit a wave's accumulators); the softmax between
+    them and its backward are this repo's in-place row kernels (csrc/softmax.hip): no `q * scale` pass, no second score tensor,
+    no softmax kernel of the framework.  q, k, v [B, N, D] half."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        scale = float(q.shape[-1]) ** -0.5
+        fallback("VAE mid attention (dense GEMMs around the own softmax kernels)", q, library=True)
+        p = torch.bmm(q, k.transpose(1, 2))                       # raw scores [B, N, N]; becomes P in place
+        rc = _lib.nn_lib().gip_softmax_rows_f16(_p(p), p.shape[0] * p.shape[1], p.shape[2], scale,
+                                                ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_softmax_rows_f16 failed with status %d" % rc)
+        ctx.save_for_backward(q, k, v, p)
+        ctx.scale = scale
+        return torch.bmm(p, v)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p = ctx.saved_tensors
+        do = do.contiguous()
+        dv = torch.bmm(p.transpose(1, 2), do)
+        dp = torch.bmm(do, v.transpose(1, 2))                     # becomes dL/d(raw scores) in place
+        rc = _lib.nn_lib().gip_softmax_rows_backward_f16(_p(p), _p(dp), p.shape[0] * p.shape[1], p.shape[2], ctx.scale,
+                                                         ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("gip_softmax_rows_backward_f16 failed with status %d" % rc)
+        return torch.bmm(dp, k), torch.bmm(dp.transpose(1, 2), q), dv
+
+
+def wide_head_attention_supported(q, k):
+    return (not _DISABLED and q.is_cuda and q.dtype == torch.float16 and q.dim() == 3 and q.is_contiguous() and k.is_contiguous() and
+            k.shape[1] % 8 == 0 and k.shape[1] <= 8192)
+
+
+def wide_head_attention(q, k, v):
+    return _WideHeadAttention.apply(q, k, v.contiguous())
+
+
 def linear_supported(x, w):
     return (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and w.dtype == torch.float16 and x.is_contiguous() and
             w.is_contiguous() and x.shape[-1] % 64 == 0 and x.shape[-1] >= 64 and
@@ -1083,7 +1125,8 @@ class _ConvFewInputChannels(torch.autograd.Function):
 
 
 # (Cin, Cout, stride) -> output rows per workgroup tile (the output height must be a multiple of it)
-_FEWCH_SHAPES = {(3, 16, 1): 16, (3, 128, 1): 16, (16, 16, 1): 8, (16, 32, 2): 8, (32, 32, 1): 8, (32, 96, 2): 8, (96, 96, 1): 8, (96, 256, 2): 4}
+_FEWCH_SHAPES = {(3, 16, 1): 16, (3, 128, 1): 16, (16, 16, 1): 8, (16, 32, 2): 8, (32, 32, 1): 8, (32, 96, 2): 8, (96, 96, 1): 8, (96, 256, 2): 4,
+                 (8, 320, 1): 8, (8, 512, 1): 4}
 
 
 def conv3x3_fewch(x, w, bias, stride=1, act=False):
@@ -1107,6 +1150,52 @@ def conv3x3_fewch(x, w, bias, stride=1, act=False):
     fallback("conv3x3_fewch", x)
     y = F.conv2d(x, w, bias, stride=stride, padding=1)
     return F.silu(y) if act else y
+
+
+_PAD_ZEROS = {}
+
+
+def conv3x3_latent_in(x, w, bias):
+    """conv_in of the U-Net / ControlNet: F.conv2d(x, w, bias, padding=1) on the 4-channel latents (4 -> 320).  On the GPU the
+    latents are padded to 8 channels (one concatenation with a cached block of zeros; the weight's padded copy is cached) and
+    run on csrc/conv_small.hip's few-channel kernel — the library route was a MIOpen kernel + layout copies.  Frozen weights,
+    no gradient path."""
+    N, C, H, W = x.shape
+    if (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and C == 4 and tuple(w.shape) == (320, 4, 3, 3) and w.dtype == torch.float16 and
+            x.is_contiguous(memory_format=torch.channels_last) and H % 8 == 0 and W % 16 == 0 and
+            not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and os.environ.get("GIP_CONV_FEWCH", "1") != "0"):
+        key = (N, H, W, x.device)
+        z = _PAD_ZEROS.get(key)
+        if z is None:
+            if len(_PAD_ZEROS) > 16:
+                _PAD_ZEROS.clear()
+            z = _PAD_ZEROS[key] = torch.zeros((N, 4, H, W), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        x8 = torch.cat([x, z], dim=1)
+        if not x8.is_contiguous(memory_format=torch.channels_last):
+            x8 = x8.contiguous(memory_format=torch.channels_last)
+
+        def pad8(t):
+            p = torch.zeros((t.shape[0], 8, 3, 3), dtype=t.dtype, device=t.device)
+            p[:, :4] = t.detach()
+            return p.contiguous(memory_format=torch.channels_last)
+        return conv3x3_fewch(x8, _wt_cache.get("pad8", w, pad8), bias)
+    fallback("conv_in (4 latent channels)", x)
+    return F.conv2d(x, w, bias, padding=1)
+
+
+def folded_quant_conv(conv_out, quant_conv):
+    """(W', b') of quant_conv(conv_out(x)) as ONE 3x3 convolution: the 1x1 quant_conv (8 -> 8) of the VAE encoder composed into its
+    conv_out (512 -> 8) — W'[o] = sum_m Wq[o, m] Wc[m], b' = Wq bc + bq (float32 arithmetic, one rounding to half).  Frozen weights:
+    cached with the derived convolution weights, keyed by all four tensors."""
+    wc, bc, wq, bq = conv_out.weight, conv_out.bias, quant_conv.weight, quant_conv.bias
+    tag = "quantfold:%d:%d:%d:%d:%d:%d" % (wq.data_ptr(), wq._version, bq.data_ptr(), bq._version, bc.data_ptr(), bc._version)
+
+    def make(t):
+        q = wq.detach().float().reshape(wq.shape[0], wq.shape[1])
+        w2 = torch.einsum("om,mchw->ochw", q, t.detach().float()).to(t.dtype).contiguous(memory_format=torch.channels_last)
+        b2 = (q @ bc.detach().float() + bq.detach().float()).to(t.dtype).contiguous()
+        return w2, b2
+    return _wt_cache.get(tag, wc, make)
 
 
 _NARROW_OUT_SHAPES = {(320, 4): 8, (512, 8): 4}       # (Cin, Cout) -> output rows per workgroup tile
@@ -1137,7 +1226,8 @@ def _narrow_out_call(x, w, bias):
 
 
 class _NarrowOutConv(torch.autograd.Function):
-    """The differentiable form (VAE encoder conv_out): forward on the kernel, data gradient (8 -> 512 channels, 0.03 ms) on the library."""
+    """The differentiable form (VAE encoder conv_out): forward on the kernel, data gradient (8 -> 512 channels) on the few-channel
+    kernel with the flipped-transposed weight (round 5; the library's backward-data kernel before)."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
@@ -1148,8 +1238,13 @@ class _NarrowOutConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
-        fallback("conv_out data gradient (8 -> 512 channels)", dy, library=True)
-        return torch.nn.grad.conv2d_input(ctx.x_shape, w, dy.contiguous(memory_format=torch.channels_last), padding=1), None, None
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = ctx.x_shape
+        if (tuple(w.shape[:2]), 1) == ((8, 512), 1) and H % _FEWCH_SHAPES[(8, 512, 1)] == 0 and W % 16 == 0 and dy.dtype == torch.float16 and \
+                os.environ.get("GIP_CONV_FEWCH", "1") != "0":
+            return conv3x3_fewch(dy, _transposed_weight(w), None), None, None
+        fallback("conv_out data gradient", dy, library=True)
+        return torch.nn.grad.conv2d_input(ctx.x_shape, w, dy, padding=1), None, None
 
 
 def conv3x3_narrow_out(x, w, bias):

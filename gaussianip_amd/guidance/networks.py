@@ -258,14 +258,11 @@ class Attention(nn.Module):
                 return self._out(fused.attention(q, k, v, self.heads), residual)
             # decoupled cross-attention: text and image-prompt keys in one pass over the queries
             return self._out(fused.attention(q, k, v, self.heads, self.to_k_ip(ip_ctx), self.to_v_ip(ip_ctx), self.ip_scale), residual)
-        if self.heads == 1 and ip_ctx is None and q.is_cuda and q.dtype == torch.float16 and q.shape[-1] >= 256:
-            # single wide head (the VAE's 512-channel mid attention): three dense GEMMs through hipBLASLt beat the
-            # flash kernels at head dim 512 (forward and backward; measured in tools/exp_ab_vae.py)
-            # the scale goes onto q ([B, N, 512]) instead of into the product's alpha: autograd's backward of an alpha-scaled
-            # bmm multiplies the [B, N, N] score gradient (134 MB at 4 x 4096^2) by it in a pass of its own
-            fused.fallback("VAE mid attention (three library GEMMs + softmax)", q, library=True)
-            p = torch.softmax(torch.bmm(q * (q.shape[-1] ** -0.5), k.transpose(1, 2)), dim=-1)
-            return self._out(torch.bmm(p, v), residual)
+        if self.heads == 1 and ip_ctx is None and q.shape[-1] >= 256 and fused.wide_head_attention_supported(q, k):
+            # single wide head (the VAE's 512-channel mid attention): dense GEMMs at the FLOP minimum around this repo's in-place
+            # softmax kernels (fused._WideHeadAttention); the flash kernels lose at head dim 512 (forward and backward; measured in
+            # tools/exp_ab_vae.py)
+            return self._out(fused.wide_head_attention(q, k, v), residual)
         fused.fallback("attention", q)
         q = self._split(q)
         h = F.scaled_dot_product_attention(q, self._split(k), self._split(v))
@@ -485,7 +482,7 @@ class UNet(_Encoder):
         temb = self.temb(t, x.dtype)
         self.stage_context(ctx)
         b = x.shape[0] // replicas
-        h, skips = self.encode(self.conv_in(x[:b] if replicas > 1 else x), temb, ctx, replicas)
+        h, skips = self.encode(fused.conv3x3_latent_in(x[:b] if replicas > 1 else x, self.conv_in.weight, self.conv_in.bias), temb, ctx, replicas)
         h = self.mid(h, temb, ctx)
         if callable(down_residuals):          # the ControlNet ran on another stream beside the encoder: join here
             down_residuals, mid_residual = down_residuals()
@@ -550,7 +547,7 @@ class ControlNet(_Encoder):
             x, c = x[:b], c[:b]
         elif c.shape[0] != x.shape[0]:
             c = c.repeat(x.shape[0] // c.shape[0], 1, 1, 1)
-        h, skips = self.encode(self.conv_in(x) + c, temb, ctx, replicas)
+        h, skips = self.encode(fused.conv3x3_latent_in(x, self.conv_in.weight, self.conv_in.bias) + c, temb, ctx, replicas)
         h = self.mid(h, temb, ctx)
         down = [conv1x1(s, z.weight, z.bias) for z, s in zip(self.zero_convs, skips)]
         mid = conv1x1(h, self.mid_zero.weight, self.mid_zero.bias)
@@ -591,6 +588,10 @@ class VAEEncoder(nn.Module):
         a = self.mid_attn(self.mid_norm(h).permute(0, 2, 3, 1).reshape(B, H * W, C))
         h = h + a.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = self.mid_res2(h)
+        if fusable(h) and not self.conv_out.weight.requires_grad and self.conv_out.weight.dtype == torch.float16:
+            # quant_conv (1x1, 8 -> 8) composed into conv_out: one kernel forward, one backward (no library convolution in the VAE)
+            w2, b2 = fused.folded_quant_conv(self.conv_out, self.quant_conv)
+            return fused.conv3x3_narrow_out(self.norm_out(h), w2, b2)
         return self.quant_conv(fused.conv3x3_narrow_out(self.norm_out(h), self.conv_out.weight, self.conv_out.bias))      # 512 -> 8
 
     def encode(self, x, generator=None):

@@ -82,6 +82,14 @@ int gip_cat2_stats_f16(const void* a, const void* b, const void* b_add, void* ou
 int gip_layernorm_f16(const void* x, const void* weight, const void* bias, void* y, int64_t M, int32_t C, float eps,
                       void* stream);
 
+/* Row softmax in place, and its backward in place over the upstream gradient (csrc/softmax.hip): the softmax between the two
+ * GEMMs of the VAE encoder's single-head mid attention (diffusers AttnBlock inside AutoencoderKL.encode, reference call
+ * ipa_guidance.py:522-531; scale = 512^-1/2).  s / p / dp: [rows, n] half, n % 8 == 0, n <= 8192.
+ *   forward   s[r, :] <- softmax(scale * s[r, :])
+ *   backward  dp[r, :] <- scale * p[r, :] * (dp[r, :] - sum_j dp[r, j] p[r, j])     (= dL/d(raw scores)) */
+int gip_softmax_rows_f16(void* s, int64_t rows, int32_t n, float scale, void* stream);
+int gip_softmax_rows_backward_f16(const void* p, void* dp, int64_t rows, int32_t n, float scale, void* stream);
+
 /* One LPIPS layer term against cached target features (csrc/lpips.hip); replaces, per VGG tap, the
  * normalize_tensor -> (a - b)^2 -> lin -> spatial_average chain of `lpips.LPIPS.forward` that the reference calls at
  * threestudio/systems/GaussianIP.py:435 (third-party `lpips` package; published LPIPS v0.1 algorithm).

@@ -18,8 +18,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 B = 4
-# bounds on the relative L2 distance of an fp16 latent-space ANPG gradient to the float32 one (measured: see the json)
-FP16_TO_FP32 = 0.08
+# bound on the relative L2 distance of an fp16 latent-space ANPG gradient to the float32 one.  Measured (round 5, profiles/
+# r05_anpg_sensitivity.json): 0.0340 at batch 12, 0.0340 at batch 6, 0.0441 between the two; noise_pred itself 1.16e-3 from fp32 at
+# both batch sizes; amplification 7.5 |eps_pos| / |eps_pos - eps_null| = 229 on these random-initialised networks
+FP16_TO_FP32 = 0.06
 NOISE_PRED_TO_FP32 = 5e-3
 
 

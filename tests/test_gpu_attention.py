@@ -273,3 +273,43 @@ def test_denoise_with_the_winograd_layers_equals_the_implicit_gemm_denoise(monke
     cos = float(torch.nn.functional.cosine_similarity(wino.flatten(), direct.flatten(), dim=0))
     assert rel <= 5e-3 and cos >= 0.99995, (rel, cos)
     assert float((wino - direct).abs().max()) <= 1e-2 * max(1.0, float(direct.abs().max()))
+
+
+def test_wide_head_attention_node_matches_the_op_chain_forward_and_backward():
+    """fused._WideHeadAttention (the VAE encoder's 512-channel single-head mid attention: dense GEMMs around csrc/softmax.hip's
+    in-place row softmax and its backward) against softmax(q k^T / sqrt(D)) v spelled with torch ops in float32, values and
+    all three input gradients; plus the softmax kernels alone on ragged row lengths."""
+    import ctypes
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, N, D = 2, 1024, 512
+    q, k, v = [(torch.randn(B, N, D, device="cuda", generator=g) * s).half().requires_grad_(True) for s in (1.0, 1.0, 0.5)]
+    do = (torch.randn(B, N, D, device="cuda", generator=g) * 0.1).half()
+    assert fused.wide_head_attention_supported(q, k)
+    out = fused.wide_head_attention(q, k, v)
+    out.backward(do)
+    got = [out.detach().float()] + [t.grad.float() for t in (q, k, v)]
+    q32, k32, v32 = [t.detach().float().requires_grad_(True) for t in (q, k, v)]
+    ref = torch.softmax(torch.bmm(q32, k32.transpose(1, 2)) * D ** -0.5, dim=-1) @ v32
+    ref.backward(do.float())
+    want = [ref.detach()] + [t.grad for t in (q32, k32, v32)]
+    for name, a, b in zip(("out", "dq", "dk", "dv"), got, want):
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 4e-3, (name, rel)
+    # the row kernels on their own: every chunk-count instantiation, rows that are not a multiple of the workgroup's four
+    lib = _lib.nn_lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (8, 64, 520, 1024, 2056, 4096, 8192):
+        s = (torch.randn(7, n, device="cuda", generator=g) * 3).half()
+        p = s.clone()
+        assert lib.gip_softmax_rows_f16(ctypes.c_void_p(p.data_ptr()), 7, n, 0.37, st) == 0
+        ref = torch.softmax(s.float() * 0.37, dim=-1)
+        assert float((p.float() - ref).abs().max()) < 1e-3, n
+        dp = torch.randn(7, n, device="cuda", generator=g).half()
+        gs = dp.clone()
+        assert lib.gip_softmax_rows_backward_f16(ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(gs.data_ptr()), 7, n, 0.37, st) == 0
+        pf = p.float()
+        refg = 0.37 * pf * (dp.float() - (dp.float() * pf).sum(-1, keepdim=True))
+        assert float((gs.float() - refg).abs().max()) < 2e-3 * max(1.0, float(refg.abs().max())), n
+    assert lib.gip_softmax_rows_f16(ctypes.c_void_p(p.data_ptr()), 7, 8200, 1.0, st) == 1           # longer than 8192: rejected

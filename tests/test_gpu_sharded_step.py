@@ -69,11 +69,15 @@ def test_config3_real_guidance_sharded_step_at_100k_1024(tmp_path):
                 assert g_["rel_l2"] < 1e-4 and g_["cosine"] > 0.99999, (name, g_)
         assert r["accum"]["rel_l2"] < 1e-4, r
         # (2) against the one-call 4-view step of configs[2] (denoise batch 12 / VAE batch 4: other kernels per layer, i.e. other
-        # fp16 roundings, amplified by ANPG's 7.5 x (eps_pos - eps_null)): same direction, per-cent-level difference
+        # fp16 roundings, amplified by ANPG's 7.5 x (eps_pos - eps_null)): same direction, per-cent-level difference.  The bar is
+        # what tests/test_gpu_anpg_sensitivity.py MEASURES for that amplification: each batch size's latent-space ANPG gradient
+        # lies 3.4 % from the float32 gradient and 4.4 % from the other (profiles/r05_anpg_sensitivity.json) — two fp16 paths may
+        # be as far apart as the sum of their float32 gaps, and the VAE backward in front of the parameters adds its own fp16
+        # noise (measured here: 5.8 %); 0.10 = 1.5 x the sum of the measured gaps (the bar was an unexplained 0.15 in round 4)
         assert abs(r["loss_sharded_sum"] - r["loss_one_call"]) <= 5e-3 * abs(r["loss_one_call"]), r
         for name, g_ in r["grad_vs_one_call"].items():
             if g_["ref_norm"] > 1e-6 * big:
-                assert g_["rel_l2"] < 0.15 and g_["cosine"] > 0.99, (name, g_)
+                assert g_["rel_l2"] < 0.10 and g_["cosine"] > 0.995, (name, g_)
         assert r["accum_vs_one_call"]["cosine"] > 0.99, r
 
 
