@@ -113,7 +113,7 @@ def measure_config4(dev, P=1000000, H=1024, W=1024, V=12, iters=5):
     sc = scenes.make_scene("human", P, seed=42)
     sc["scales"] = (sc["scales"] / 1.6).astype(np.float32)
     sc["opacities"][:] = 0.6
-    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items()}
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev).contiguous() for k, v in sc.items()}
     bg = torch.zeros(3, device=dev)
     cams = [scenes.camera(5.0, -180.0 + 10.0 * i, 1.8, 70.0, H, W) for i in range(V)]
     sts = [GaussianRasterizationSettings(
@@ -361,7 +361,9 @@ def main():
     cams = scenes.train_cameras(V, seed=42 + (shard.seed_id if shard is not None else 0), H=H, W=W)
     sts = settings(cams if shard is None else [c for i, c in enumerate(cams) if i in shard.views])
     Vl = len(sts)                                   # views this rank renders per step
-    t = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in sc.items()}
+    # inputs resident in HBM in the layout the interface takes (contiguous float32, as GaussianModel's getters return them): the
+    # scene generator's isotropic scales are a numpy broadcast, which the wrapper would otherwise re-pack on every call
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev).contiguous().requires_grad_(True) for k, v in sc.items()}
     gen = torch.Generator(device=dev).manual_seed(1234)
     gC = torch.randn((V, 3, H, W), device=dev, generator=gen) * 1e-3
     gD = torch.randn((V, 1, H, W), device=dev, generator=gen) * 1e-3
@@ -455,7 +457,7 @@ def main():
     trained = None
     if rank == 0 and not args.no_trained:
         sct = scenes.trained_look(scenes.make_scene("human", P, seed=42, sh_degree=0), seed=7)
-        tt_ = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in sct.items()}
+        tt_ = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev).contiguous().requires_grad_(True) for k, v in sct.items()}
         pl_ = [tt_[n] for n in names]
 
         def step_t():

@@ -298,6 +298,15 @@ def nn_lib():
                                           ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
         lib.gip_timestep_embedding_f16.restype = ctypes.c_int
         lib.gip_timestep_embedding_f16.argtypes = [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp]
+        lib.gip_gn_stats_from_partials.restype = ctypes.c_int
+        lib.gip_gn_stats_from_partials.argtypes = [_vp, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                                   _vp, ctypes.c_int32, _vp, ctypes.c_int32, _vp]
+        lib.gip_conv3x3_gnin_nhwc_f16.restype = ctypes.c_int
+        lib.gip_conv3x3_gnin_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 5 + [_vp, _vp, _vp, _vp, ctypes.c_int32,
+                                                  ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp]
+        lib.gip_linear_batched_f16.restype = ctypes.c_int
+        lib.gip_linear_batched_f16.argtypes = [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp]
         lib.gip_softmax_rows_f16.restype = ctypes.c_int
         lib.gip_softmax_rows_f16.argtypes = [_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, _vp]
         lib.gip_softmax_rows_backward_f16.restype = ctypes.c_int

@@ -135,7 +135,12 @@ __global__ void __launch_bounds__(CV_THREADS, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom,
-               float* __restrict__ chan_stats, GnBwdArgs gnb, int tapsel_in) {
+               float* __restrict__ chan_stats, GnBwdArgs gnb, int tapsel_in, long long bs_x = 0, long long bs_w = 0, long long bs_o = 0) {
+  // BATCHED GEMM (TAPS = 1, gip_linear_batched_f16): blockIdx.y = batch entry; x / w / out advance by bs_x / bs_w / bs_o elements
+  // per entry (the sixteen products of a Winograd F(2x2, 3x3) convolution in ONE launch)
+  if constexpr (TAPS == 1) {
+    x += (size_t)blockIdx.y * bs_x; w += (size_t)blockIdx.y * bs_w; out += (size_t)blockIdx.y * bs_o;
+  }
   // geom = stride | pad_top << 8 | pad_left << 16; H, W are the OUTPUT dims, Hin, Win the input dims (equal at stride 1)
   // tapsel (TAPS = 9): bits 0-8 = the taps the K loop visits (0x1ff: all nine); bit 11 = scatter: output pixel (n, a, b) is
   // written to row (n, 2 a + pi, 2 b + pj) of a [N, 2 H, 2 W, Cout] tensor, pi = bit 9, pj = bit 10 — one parity class of
@@ -355,6 +360,45 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   advance();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (HALO) {
+    if ((geom >> 30) & 1) {
+      // GN-IN (round 5): the convolution's input is y = silu?(GroupNorm(x + addend)) and y is never materialised — the halo image
+      // holds RAW x and is normalised in place here, once per tile (gnb = that GroupNorm: gamma, beta, mean, rstd, addend over
+      // the Cin = 128 input channels).  Same arithmetic as csrc/groupnorm.hip's apply pass (sc = rstd gamma, sh = beta - (mean -
+      // addend) sc, y = sc x + sh, SiLU through v_exp + v_rcp, one rounding to half), so the result equals convolving the
+      // separately normalised tensor; halo pixels outside the image stay zero (the padding applies to y, not to x).  Saves
+      // the apply pass' read + write of the activation (0.12 ms per 268 MB tensor of the VAE encoder's first level) for ~12
+      // 16-byte chunks of vector work per thread and tile.
+      float* gs = (float*)(smem + HALO_BYTES + STAGE);          // stage 1 is still free: [128 channels][scale, shift]
+      if (tid < 128) {
+        const int c = tid, g = c / (128 / gnb.G);
+        const float ga = (float)gnb.gamma[c], be = (float)gnb.beta[c];
+        const float ad = gnb.addend ? (float)gnb.addend[(size_t)h_n * gnb.addend_stride + c] : 0.f;
+        const float sc = gnb.rstd[h_n * gnb.G + g] * ga;
+        gs[2 * c] = sc;
+        gs[2 * c + 1] = be - (gnb.mean[h_n * gnb.G + g] - ad) * sc;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 2 * 180 * 8; idx += CV_THREADS) {
+        const int cbk = idx >= 180 * 8 ? 1 : 0, rem = idx - cbk * (180 * 8);
+        const int hr = rem >> 3, p = rem & 7;
+        const int hy = hr / 18, hx = hr - hy * 18;
+        const int iy = (int)h_y0 - 1 + hy, ix = (int)h_x0 - 1 + hx;
+        if (!((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)) continue;
+        const int c0 = cbk * 64 + ((p ^ ((hr >> 1) & 7)) << 3);
+        f16x8* ptr = (f16x8*)(smem + cbk * CVH_KC_BYTES + hr * 128 + p * 16);
+        const f16x8 v = *ptr;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float y = gs[2 * (c0 + j)] * (float)v[j] + gs[2 * (c0 + j) + 1];
+          o[j] = (_Float16)(gnb.silu ? y * __builtin_amdgcn_rcpf(1.f + __expf(-y)) : y);
+        }
+        *ptr = o;
+      }
+      __syncthreads();
+    }
+  }
   for (int kt = 0; kt < KT; kt++) {
     const int buf = kt & 1;
     const int tap_n = tap, cb_n = cb;
@@ -1026,13 +1070,17 @@ template <int BN, int STAGES, int TAPS, bool GEGLU>
 static int launch(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W,
                   int Cin, int Cout, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0, int Hin = 0, int Win = 0,
                   int geom = 1 | (1 << 8) | (1 << 16), float* chan_stats = nullptr, const GnBwdArgs* gnb_in = nullptr,
-                  int tapsel = 0x1ff, int stats_rows = 128) {
+                  int tapsel = 0x1ff, int stats_rows = 128, int batch = 1, long long bs_x = 0, long long bs_w = 0, long long bs_o = 0,
+                  bool gn_in = false) {
+  // gn_in: *gnb_in describes the GroupNorm (+ SiLU) applied to this convolution's INPUT (halo-resident kernel only: anything else
+  // returns 1 and the caller runs the separate apply pass)
   GnBwdArgs gnb = {};
   if (gnb_in) gnb = *gnb_in;
   if (Hin == 0) { Hin = H; Win = W; }
   const long long M = (long long)N * H * W;
+  if (batch > 1 && (TAPS != 1 || GEGLU || workspace || chan_stats || gnb_in)) return 1;
   if constexpr (!GEGLU) {
-    if (!(Cout & 7)) {
+    if (!(Cout & 7) && batch == 1 && !gn_in) {
       const int bw = big_tile_width(M, Cout);
       if (bw == 256 && !(gnb.x && gnb.HW % CVB_BM) && tapsel == 0x1ff && !gnb.ln_rows && !gnb.rows_out)
         return launch_big<256, TAPS>(x, w, bias, residual, out, N, H, W, Cin, Cout, s, Hin, Win, geom, chan_stats, gnb);
@@ -1056,13 +1104,14 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
         attr_h = true;
       }
       static const int env_res_h = env_int("GIP_CONV_RES_EARLY", 1);
-      const int geom_h = geom | (1 << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (env_res_h << 29);
+      const int geom_h = geom | (1 << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (env_res_h << 29) | ((gn_in ? 1 : 0) << 30);
       hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU, true>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds_h, s,
                          (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
                          N, H, W, Cin, Cout, m_tiles, n_tiles, 1, (float*)nullptr, Hin, Win, geom_h, chan_stats, gnb, tapsel);
       return hipGetLastError() == hipSuccess ? 0 : 3;
     }
   }
+  if (gn_in) return 1;
   const size_t lds = STAGES * (size_t)(CV_BM + BN) * 128;
   static_assert((size_t)CV_BM * (BN * 2 + 16) + (size_t)(CV_THREADS / (BN / 8)) * BN * 8 <= STAGES * (size_t)(CV_BM + BN) * 128,
                 "epilogue tile image + statistics partials must fit in the stage buffers");
@@ -1110,10 +1159,10 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   static const int env_res = env_int("GIP_CONV_RES_EARLY", 1);
   geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (env_res << 29);   // bits 26-28: timing ablations (WRONG results)
   const int classes = (tapsel >> 12) & 1 ? 4 : 1;
-  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit * classes), dim3(CV_THREADS), lds, s,
+  hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit * classes, batch), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
                      N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom,
-                     stats_in_reduce ? nullptr : chan_stats, gnb, tapsel);
+                     stats_in_reduce ? nullptr : chan_stats, gnb, tapsel, bs_x, bs_w, bs_o);
   if (stats_in_reduce) {
     if ((Cout & 3) || M % stats_rows) return 1;
     const dim3 grid((unsigned)(M / stats_rows), (unsigned)((Cout + 63) / 64));
@@ -1309,6 +1358,32 @@ extern "C" int gip_upsample2x_conv3x3_nhwc_f16(const void* x, const void* wt4, c
   const int tapsel = 0x1ff | (1 << 11) | (1 << 12) | (1 << 13);
   return wide ? launch<160, 2, 9, false>(x, wt4, bias, nullptr, out, N, Hin, Win, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel)
               : launch<128, 2, 9, false>(x, wt4, bias, nullptr, out, N, Hin, Win, Cin, Cout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, tapsel);
+}
+
+extern "C" int gip_conv3x3_gnin_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
+                                        int32_t H, int32_t W, int32_t Cin, int32_t Cout, const void* gamma, const void* beta,
+                                        const float* mean, const float* rstd, int32_t G, int32_t apply_silu, const void* addend,
+                                        int32_t addend_stride, float* chan_stats, void* stream) {
+  if (!x || !w || !out || !gamma || !beta || !mean || !rstd || N < 1 || Cin != 128 || Cout < 8 || (Cout & 7) || G < 1 || 128 % G) return 1;
+  if (!fits32((long long)N * H * W, Cin, Cout, Cout, 9)) return 1;
+  GnBwdArgs gnb = {};
+  gnb.gamma = (const _Float16*)gamma; gnb.beta = (const _Float16*)beta; gnb.addend = (const _Float16*)addend;
+  gnb.mean = mean; gnb.rstd = rstd; gnb.G = G; gnb.silu = apply_silu; gnb.addend_stride = addend_stride; gnb.HW = H * W;
+  return launch<128, 2, 9, false>(x, w, bias, residual, out, N, H, W, Cin, Cout, (hipStream_t)stream, nullptr, 0, 0, 0,
+                                  1 | (1 << 8) | (1 << 16), chan_stats, &gnb, 0x1ff, 128, 1, 0, 0, 0, true);
+}
+
+extern "C" int gip_linear_batched_f16(const void* x, const void* w, void* out, int32_t B, int64_t M, int32_t K, int32_t Nout,
+                                      int64_t bs_x, int64_t bs_w, int64_t bs_o, void* stream) {
+  if (!x || !w || !out || B < 1 || B > 65535 || M < 1 || M >= (1ll << 31) || K < CV_BK || K % CV_BK || Nout < 4 || (Nout & 3)) return 1;
+  if (!fits32(M, K, Nout, Nout, 1) || bs_x < 0 || bs_w < 0 || bs_o < 0 || (bs_x & 7) || (bs_w & 7) || (bs_o & 3)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
+  const int geom = 1 | (1 << 8) | (1 << 16);
+  return wide ? launch<160, 2, 1, false>(x, w, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, 0x1ff,
+                                         128, B, bs_x, bs_w, bs_o)
+              : launch<128, 2, 1, false>(x, w, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, 0x1ff,
+                                         128, B, bs_x, bs_w, bs_o);
 }
 
 extern "C" int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,

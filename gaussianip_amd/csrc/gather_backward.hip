@@ -2,12 +2,10 @@
 // cov2D / projection / depth / SH / cov3D backward (gfx950).
 //
 // Replaces the fork's computeCov2DCUDA + backward preprocessCUDA (SURVEY.md §2.1 "bwd 2-3") and the
-// zero-initialised per-Gaussian atomic accumulators they read.  One lane per (Gaussian, view): the VP = next power of two >= V
-// lanes of a Gaussian are neighbours in the wave; each sums its view's contiguous run of 64-byte rows (written by
-// render_backward.hip) in a fixed order and pushes the sums through the analytic backward; the 3-D gradients of the views are then
-// combined by a fixed xor-butterfly over the VP lanes and lane 0 of the group writes them — every output element is written
-// exactly once (no pre-zeroing, no atomics), bitwise reproducible.  (Rounds 1-4 ran one lane per Gaussian with a serial loop over
-// the views: 1564 waves for 1024 SIMDs at 100k Gaussians, a latency-bound 24 us; V times the lanes hide it.)
+// zero-initialised per-Gaussian atomic accumulators they read.  One lane per Gaussian; for every view
+// the lane sums its contiguous run of 64-byte rows (written by render_backward.hip) in a fixed order,
+// pushes the sums through the analytic backward, and accumulates the 3-D gradients over the views in
+// registers, so each output element is written exactly once (no pre-zeroing, no atomics).
 #include "gip_internal.h"
 
 #define SH_C0 0.28209479177387814f
@@ -26,22 +24,19 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
                            const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                            const float* __restrict__ camposs, const GipRecord* __restrict__ records,
                            const uint32_t* __restrict__ inst_offset, const float* __restrict__ partial,
-                           GipRasterGradsOut gout, const GipRasterHeader* __restrict__ header, int vp_shift) {
-  // lane -> (Gaussian, view): VP = 1 << vp_shift consecutive lanes share a Gaussian
-  const int gid = blockIdx.x * GIP_BLOCK + threadIdx.x;
-  const int idx = gid >> vp_shift, v = gid & ((1 << vp_shift) - 1);
-  if (idx >= kp.P) return;                      // whole groups leave together (the butterfly below stays inside a group)
-  const bool lead = v == 0;
+                           GipRasterGradsOut gout, const GipRasterHeader* __restrict__ header) {
+  const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
+  if (idx >= kp.P) return;
   if (header->overflow) {
     // overflowed forward (tile lists truncated at the capacity): the step degenerates to a ZERO-gradient step, the same
     // on every rank of a multi-GPU job; the host learns it from the header one step late, raises the capacity and
     // reports it (rasterizer.py).  Every output is still written exactly once.
-    if (gout.dL_dmeans2D && v < kp.V) {
-      float* d2 = gout.dL_dmeans2D + ((size_t)v * kp.P + idx) * 3;
-      d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f;
-    }
-    if (!lead) return;
     if (gout.dL_dmeans3D) { gout.dL_dmeans3D[3 * idx] = 0.f; gout.dL_dmeans3D[3 * idx + 1] = 0.f; gout.dL_dmeans3D[3 * idx + 2] = 0.f; }
+    if (gout.dL_dmeans2D)
+      for (int v = 0; v < kp.V; v++) {
+        float* d2 = gout.dL_dmeans2D + ((size_t)v * kp.P + idx) * 3;
+        d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f;
+      }
     if (gout.dL_dopacities) gout.dL_dopacities[idx] = 0.f;
     if (gout.dL_dcolors_precomp) { gout.dL_dcolors_precomp[3 * idx] = 0.f; gout.dL_dcolors_precomp[3 * idx + 1] = 0.f; gout.dL_dcolors_precomp[3 * idx + 2] = 0.f; }
     if (gout.dL_dshs) for (int k = 0; k < kp.M * 3; k++) gout.dL_dshs[(size_t)idx * kp.M * 3 + k] = 0.f;
@@ -81,18 +76,17 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
 #pragma unroll
   for (int k = 0; k < MAXM * 3; k++) dsh[k] = 0.f;
 
-  bool visible = false;
-  uint32_t ntiles = 0;
-  const GipRecord* rec = records + (size_t)(v < kp.V ? v : 0) * kp.P + idx;
-  float* d2 = (gout.dL_dmeans2D && v < kp.V) ? gout.dL_dmeans2D + ((size_t)v * kp.P + idx) * 3 : nullptr;
-  if (v < kp.V) {
+  for (int v = 0; v < kp.V; v++) {
+    const GipRecord* rec = records + (size_t)v * kp.P + idx;
     const uint4 q1 = reinterpret_cast<const uint4*>(rec)[1];
     const uint4 q2 = reinterpret_cast<const uint4*>(rec)[2];
-    ntiles = q1.w;
-    visible = (int)q2.w > 0;
-    if (!visible && d2) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; }
-  }
-  if (visible) {
+    const uint32_t ntiles = q1.w;
+    const int radius = (int)q2.w;
+    float* d2 = gout.dL_dmeans2D ? gout.dL_dmeans2D + ((size_t)v * kp.P + idx) * 3 : nullptr;
+    if (!(radius > 0)) {
+      if (d2) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; }
+      continue;
+    }
     // ---- fixed-order sum of this Gaussian's rows ----
     float a[10];
 #pragma unroll
@@ -243,21 +237,6 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
     }
   }
 
-  // ---- combine the views: xor-butterfly over the VP lanes of the Gaussian (fixed order), then lane 0 writes ----
-  for (int d = 1; d < (1 << vp_shift); d <<= 1) {
-    dmean0 += __shfl_xor(dmean0, d, 64); dmean1 += __shfl_xor(dmean1, d, 64); dmean2 += __shfl_xor(dmean2, d, 64);
-    dopac += __shfl_xor(dopac, d, 64);
-#pragma unroll
-    for (int k = 0; k < 6; k++) dcov[k] += __shfl_xor(dcov[k], d, 64);
-    if (colors_precomp) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) dcol[k] += __shfl_xor(dcol[k], d, 64);
-    } else {
-#pragma unroll
-      for (int k = 0; k < MAXM * 3; k++) dsh[k] += __shfl_xor(dsh[k], d, 64);
-    }
-  }
-  if (!lead) return;
   // ---- write-out (every element exactly once) ----
   if (gout.dL_dmeans3D) { gout.dL_dmeans3D[3 * idx] = dmean0; gout.dL_dmeans3D[3 * idx + 1] = dmean1; gout.dL_dmeans3D[3 * idx + 2] = dmean2; }
   if (gout.dL_dopacities) gout.dL_dopacities[idx] = dopac;
@@ -310,13 +289,10 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
 
 void gip_launch_gather_backward(const GipKernelParams& kp, const GipRasterInputs& in, GipStatePtrs st, const float* partial,
                                 const GipRasterGradsOut& gout, hipStream_t s) {
-  int vp_shift = 0;
-  while ((1 << vp_shift) < kp.V) vp_shift++;                 // VP lanes per Gaussian, V <= GIP_MAX_VIEWS = 16 <= 64
-  const long long lanes = (long long)kp.P << vp_shift;
-  const dim3 grid((unsigned)((lanes + GIP_BLOCK - 1) / GIP_BLOCK)), block(GIP_BLOCK);
+  const dim3 grid(kp.nblk), block(GIP_BLOCK);
 #define LAUNCH(MM) hipLaunchKernelGGL((gip_gather_backward_kernel<MM>), grid, block, 0, s, kp, in.means3D, in.shs, \
     in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, st.records, \
-    st.inst_offset, partial, gout, st.header, vp_shift)
+    st.inst_offset, partial, gout, st.header)
   const int needed = in.shs ? (kp.D + 1) * (kp.D + 1) : 1;
   if (needed <= 1) LAUNCH(1);
   else if (needed <= 4) LAUNCH(4);

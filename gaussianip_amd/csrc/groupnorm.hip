@@ -374,6 +374,15 @@ extern "C" int gip_gn_silu_forward_stats(const void* x, const void* gamma, const
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+extern "C" int gip_gn_stats_from_partials(float* mean, float* rstd, int32_t N, int64_t HW, int32_t C, int32_t G, float eps,
+                                          const void* addend, int32_t addend_stride, const float* chan_stats, int32_t blocks_per_sample,
+                                          void* stream) {
+  if (!mean || !rstd || !chan_stats || N < 1 || HW < 1 || C < 8 || G < 1 || C % G || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
+  hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(G, N), dim3(GN_BLOCK), 0, (hipStream_t)stream, chan_stats, blocks_per_sample, (long long)HW,
+                     C, G, eps, (const __half*)addend, addend_stride, mean, rstd);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 static int gn_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean, const float* rstd,
                        void* dx, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t apply_silu, const void* addend,
                        int32_t addend_stride, const void* accum, void* workspace, size_t workspace_bytes, void* stream) {

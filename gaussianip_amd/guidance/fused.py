@@ -123,9 +123,9 @@ def fallback(site, t, library=False):
 # scalar kernel arguments (Attention.ip_scale) and the A/B environment switches are baked in.  Everything that changes one
 # of those bumps this counter; it is part of the graph keys, so a stale graph is never replayed.
 _weights_epoch = 0
-_ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_GN_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
+_ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_WINOGRAD_GEMM", "GIP_GN_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
               "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
-              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
+              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_CONV_GNIN", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
 
 
 def bump_weights_epoch():
@@ -436,6 +436,11 @@ def _winograd_weight(w):
 _WINOGRAD_DEFAULT = "16:640:3072,16:1280:1536,16:1920:1536,16:2560:1536,32:960:3072,32:1280:3072,32:1920:3072"
 
 
+# "own": the sixteen Winograd products on this repo's batched MFMA GEMM; "lib": one batched hipBLASLt call (torch.bmm).  Same-box
+# A/B: tools/exp_winograd_gemm.py (profiles/r05_winograd_gemm_batched.txt)
+_WINOGRAD_GEMM_DEFAULT = "lib"
+
+
 def _winograd_shapes():
     """{(H, Cin): fewest pixels} the Winograd path takes; GIP_WINOGRAD_SHAPES="H:Cin[:pixels],..." overrides the measured
     default (experiments)."""
@@ -466,8 +471,16 @@ def _winograd_conv(x, w, bias, residual, stats=None):
     rc = lib.gip_winograd_input_f16(_p(x), _p(V), N, H, W, C, stream)
     if rc != 0:
         raise RuntimeError("gip_winograd_input_f16 failed with status %d" % rc)
-    fallback("winograd batched GEMM", V, library=True)
-    M = torch.bmm(V, _wt_cache.get("wino", w, _winograd_weight).transpose(1, 2))          # sixteen GEMMs: one batched library call
+    U = _wt_cache.get("wino", w, _winograd_weight)
+    if os.environ.get("GIP_WINOGRAD_GEMM", _WINOGRAD_GEMM_DEFAULT) == "own" and C % 64 == 0 and cout % 4 == 0 and T * max(C, cout) * 2 < (1 << 31):
+        # the sixteen products in ONE launch of this repo's MFMA GEMM (blockIdx.y = product): gip_linear_batched_f16
+        M = torch.empty((16, T, cout), dtype=x.dtype, device=x.device)
+        rc = lib.gip_linear_batched_f16(_p(V), _p(U), _p(M), 16, T, C, cout, T * C, cout * C, T * cout, stream)
+        if rc != 0:
+            raise RuntimeError("gip_linear_batched_f16 failed with status %d" % rc)
+    else:
+        fallback("winograd batched GEMM", V, library=True)
+        M = torch.bmm(V, U.transpose(1, 2))          # sixteen GEMMs: one batched library call
     out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     null = ctypes.c_void_p(None)
     if W in (16, 32) and (H * W) % 128 == 0:
@@ -800,6 +813,46 @@ def _gn_fwd_raw(x, gn, addend, chan_stats):
     return y, mean, rstd
 
 
+def _conv_gn_in(x, gn, addend, chan_stats, w, bias, residual, stats):
+    """(conv3x3(gn(x + addend)), mean, rstd) with the GroupNorm (+ SiLU) applied inside the convolution's halo load
+    (gip_conv3x3_gnin_nhwc_f16): statistics from the producer's partial sums (one tiny launch), no apply pass, no normalised tensor.
+    None when the layer does not qualify (the caller then runs the apply pass and the plain convolution).  `stats`: a list that
+    receives the OUTPUT's chan_stats.  GIP_CONV_GNIN=0 switches it off (same-box A/B)."""
+    N, C, H, W = x.shape
+    cout = w.shape[0]
+    # (Cout % 256 == 0 layers run on the 256-wide tile, which has no halo mode and is faster for them than this kernel)
+    if (chan_stats is None or _DISABLED or C != 128 or H % 8 or W % 16 or cout % 8 or cout % 256 == 0 or C % gn.num_groups or
+            _conv_tiles(N, H, W, cout) < 256 or os.environ.get("GIP_CONV_GNIN", "1") == "0" or os.environ.get("GIP_CONV_HALO", "1") == "0" or
+            x.numel() * 2 >= (1 << 31) or N * H * W * cout * 2 >= (1 << 31)):
+        return None
+    lib = _lib.nn_lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    null = ctypes.c_void_p(None)
+    ad_ptr, ad_stride = null, 0
+    if addend is not None:
+        ad_ptr, ad_stride = _p(addend), (addend.stride(0) if addend.dim() == 2 and addend.shape[0] > 1 else 0)
+    mean = torch.empty((N, gn.num_groups), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    rc = lib.gip_gn_stats_from_partials(_p(mean), _p(rstd), N, H * W, C, gn.num_groups, float(gn.eps), ad_ptr, ad_stride, _p(chan_stats),
+                                        chan_stats.shape[0] // N, stream)
+    if rc != 0:
+        raise RuntimeError("gip_gn_stats_from_partials failed with status %d" % rc)
+    out = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    st = None
+    if stats is not None and stats_wanted(N, H, W, cout):
+        st = torch.empty((N * H * W // 128, cout, 2), dtype=torch.float32, device=x.device)
+    rc = lib.gip_conv3x3_gnin_nhwc_f16(_p(x), _p(w), null if bias is None else _p(bias), null if residual is None else _p(residual), _p(out),
+                                       N, H, W, C, cout, _p(gn.weight), _p(gn.bias), _p(mean), _p(rstd), gn.num_groups, int(gn.act),
+                                       ad_ptr, ad_stride, null if st is None else _p(st), stream)
+    if rc == 1:
+        return None                      # a shape the halo kernel does not take after all
+    if rc != 0:
+        raise RuntimeError("gip_conv3x3_gnin_nhwc_f16 failed with status %d" % rc)
+    if st is not None:
+        stats.append(st)
+    return out, mean, rstd
+
+
 def _dgrad_with_gn_sums(dy, w, x_gn, gn, mean, rstd, addend):
     """(dL/dy_gn, chan_sums): the data gradient conv3x3(dy, w^T-flipped) of a convolution whose input was gn(x_gn), with the two
     reductions of that GroupNorm's backward taken in the kernel's epilogue (gip_conv3x3_gnbwd_nhwc_f16); chan_sums is None
@@ -881,16 +934,27 @@ class _ResBlockNode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, block, stats_out):
         c1, c2 = block.conv1, block.conv2
-        y1, mean1, rstd1 = _gn_fwd_raw(x, block.norm1, None, producer_stats(x))
         h1_stats = []
-        h = _conv_call(y1, c1.weight, c1.weight.shape[0], None, None, h1_stats)
-        del y1
-        y2, mean2, rstd2 = _gn_fwd_raw(h, block.norm2, c1.bias, h1_stats[0] if h1_stats else None)      # conv1's bias enters as the addend
+        # GroupNorm + SiLU applied INSIDE the convolution that consumes it where the halo-resident kernel takes the layer (Cin = 128:
+        # the VAE encoder's first level, 268 MB tensors): the normalised tensor is never written or read (_conv_gn_in)
+        r = _conv_gn_in(x, block.norm1, None, producer_stats(x), c1.weight, None, None, h1_stats)
+        if r is not None:
+            h, mean1, rstd1 = r
+        else:
+            y1, mean1, rstd1 = _gn_fwd_raw(x, block.norm1, None, producer_stats(x))
+            h = _conv_call(y1, c1.weight, c1.weight.shape[0], None, None, h1_stats)
+            del y1
         if block.conv_shortcut is None:
             res = x
         else:
             res = conv1x1(x, block.conv_shortcut.weight, block.conv_shortcut.bias)
-        out = _conv_call(y2, c2.weight, c2.weight.shape[0], c2.bias, res.contiguous(memory_format=torch.channels_last), stats_out)
+        res = res.contiguous(memory_format=torch.channels_last)
+        r = _conv_gn_in(h, block.norm2, c1.bias, h1_stats[0] if h1_stats else None, c2.weight, c2.bias, res, stats_out)
+        if r is not None:
+            out, mean2, rstd2 = r
+        else:
+            y2, mean2, rstd2 = _gn_fwd_raw(h, block.norm2, c1.bias, h1_stats[0] if h1_stats else None)      # conv1's bias enters as the addend
+            out = _conv_call(y2, c2.weight, c2.weight.shape[0], c2.bias, res, stats_out)
         ctx.save_for_backward(x, h, mean1, rstd1, mean2, rstd2)
         ctx.block = block
         return out

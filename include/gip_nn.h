@@ -123,6 +123,22 @@ int gip_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const v
  * statistics pass of the GroupNorm that reads `out` next (gip_gn_silu_forward_stats).  Never split-K.  Cout % 8 == 0. */
 int gip_conv3x3_stats_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
                                int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* chan_stats, void* stream);
+/* mean / rstd [N, G] of GroupNorm(x + addend) from the per-(128-row block, channel) sums `chan_stats` the kernel that produced x
+ * left in its epilogue — the first half of gip_gn_silu_forward_stats on its own (no apply pass: gip_conv3x3_gnin_nhwc_f16 below
+ * normalises while it loads). */
+int gip_gn_stats_from_partials(float* mean, float* rstd, int32_t N, int64_t HW, int32_t C, int32_t G, float eps,
+                               const void* addend, int32_t addend_stride, const float* chan_stats, int32_t blocks_per_sample,
+                               void* stream);
+/* out = conv3x3(silu?(GroupNorm(x + addend)), w) + bias (+ residual) WITHOUT materialising the normalised tensor: the
+ * halo-resident kernel (Cin = 128, H % 8 == 0, W % 16 == 0, >= 256 output tiles) normalises its 18 x 10 pixel halo in LDS, once per
+ * tile, with the arithmetic of the separate apply pass.  ResnetBlock2D's `conv1(silu(norm1(x)))` / `conv2(silu(norm2(h)))` of the
+ * VAE encoder's 128-channel level (diffusers resnet.py, driven from ipa_guidance.py:522-531).  chan_stats as in
+ * gip_conv3x3_stats_nhwc_f16 (may be NULL).  Returns 1 for shapes the halo kernel does not take: run gip_gn_silu_forward + the
+ * plain convolution then. */
+int gip_conv3x3_gnin_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int32_t N,
+                              int32_t H, int32_t W, int32_t Cin, int32_t Cout, const void* gamma, const void* beta,
+                              const float* mean, const float* rstd, int32_t G, int32_t apply_silu, const void* addend,
+                              int32_t addend_stride, float* chan_stats, void* stream);
 /* Data gradient of a 3x3 convolution whose INPUT was y = silu?(GroupNorm(gn_x + addend)): out = dL/dy = conv3x3(dy_in, w) with
  * w the flipped-transposed weight (no bias, no residual), and `chan_sums` [N*H*W / 128][Cout][2] = per 128-pixel block and
  * channel sum(dxh), sum(dxh xh) of that GroupNorm's backward (xh = (gn_x + addend - mean) rstd, dxh = dL/dy dsilu?(gamma xh
@@ -226,6 +242,12 @@ int gip_winograd_output_stats_f16(const void* M, const void* bias, const void* r
  * Replaces hipBLASLt + separate bias / residual / GEGLU kernels for the transformer blocks' memory-bound projections. */
 int gip_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int32_t K,
                    int32_t Nout, int32_t geglu, void* stream);
+/* B independent GEMMs in ONE launch: out[b] [M, Nout] = x[b] [M, K] . w[b]^T ([Nout, K]), entry b at x + b * bs_x, w + b * bs_w,
+ * out + b * bs_o (element strides; bs_x, bs_w multiples of 8, bs_o of 4).  The sixteen products M[i] = V[i] U[i]^T of a Winograd
+ * F(2x2, 3x3) convolution (csrc/winograd.hip) — round 4 ran them as one batched hipBLASLt call; sixteen separate launches of the
+ * own kernel left the chip under-filled (60 tiles each).  K % 64 == 0, Nout % 4 == 0, no bias / residual / split-K. */
+int gip_linear_batched_f16(const void* x, const void* w, void* out, int32_t B, int64_t M, int32_t K, int32_t Nout,
+                           int64_t bs_x, int64_t bs_w, int64_t bs_o, void* stream);
 
 /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock: norm1 -> q|k|v, norm2 -> to_q, norm3 -> GEGLU ff_in;
  * reference: diffusers BasicTransformerBlock as run by threestudio/models/guidance/ipa_guidance.py:311-358).

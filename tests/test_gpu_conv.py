@@ -544,3 +544,129 @@ def test_halo_kernel_as_data_gradient_with_groupnorm_backward_sums():
     assert torch.equal(out, plain)
     dx_ref = fused._gn_bwd_raw(xg, plain, gn, mean, rstd, None)          # its own reduction pass
     assert float((dx.float() - dx_ref.float()).abs().max()) <= 2e-3 * float(dx_ref.float().abs().max())
+
+
+# ---- round 5: GroupNorm + SiLU inside the halo-resident convolution, own kernels for the last library convolutions ----
+@pytest.mark.parametrize("cout", [128, 192])
+def test_groupnorm_inside_the_halo_convolution_equals_the_apply_pass_path(cout, monkeypatch):
+    """fused._ResBlockNode with GIP_CONV_GNIN=1 (gip_gn_stats_from_partials + gip_conv3x3_gnin_nhwc_f16: the normalised tensor is
+    never materialised) against the same node with the separate GroupNorm apply pass: the kernel repeats the apply pass'
+    arithmetic on its LDS halo, so forward output and dL/dx are bit-identical — and the fp32 block agrees to fp16 tolerance."""
+    import copy
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    from gaussianip_amd.guidance.networks import ResBlock, init_for_benchmark
+    torch.manual_seed(0)
+    blk = init_for_benchmark(ResBlock(128, cout, temb_dim=0, eps=1e-6), seed=5)
+    with torch.no_grad():
+        for m in (blk.norm1, blk.norm2):
+            m.weight.add_(torch.randn_like(m.weight) * 0.2)
+            m.bias.add_(torch.randn_like(m.bias) * 0.2)
+        blk.conv1.bias.add_(torch.randn_like(blk.conv1.bias) * 0.3)
+    ref_blk = blk.cuda().float().requires_grad_(False)
+    blk = copy.deepcopy(ref_blk).half().to(memory_format=torch.channels_last).requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    cl = dict(memory_format=torch.channels_last)
+    N, H, W = 2, 128, 144                                         # 288 / 432 output tiles, image borders on all four sides of many tiles
+    x0 = (torch.randn(N, 128, H, W, device="cuda", generator=g) * 1.5 + 0.3).half().contiguous(**cl)
+    dy = torch.randn(N, cout, H, W, device="cuda", generator=g).half().contiguous(**cl)
+    # x must carry its producer's statistics (the VAE's conv_in / the previous block leave them): make them with the statistics kernel
+    w_id = torch.zeros(128, 128, 3, 3, device="cuda").half()
+    w_id[torch.arange(128), torch.arange(128), 1, 1] = 1.0
+    w_id = w_id.contiguous(**cl)
+
+    def run(gnin):
+        monkeypatch.setenv("GIP_CONV_GNIN", "1" if gnin else "0")
+        x = fused.conv3x3(x0, w_id, gn_next=True)                # identity convolution: x0 with chan_stats attached
+        assert fused.producer_stats(x) is not None and torch.equal(x, x0)
+        st = fused.producer_stats(x)
+        xi = x.detach().requires_grad_(True)
+        fused.attach_stats(xi, st)
+        before = _lib.call_counts.get("gip_conv3x3_gnin_nhwc_f16", 0)
+        y = blk(xi)
+        n_calls = _lib.call_counts.get("gip_conv3x3_gnin_nhwc_f16", 0) - before
+        (dx,) = torch.autograd.grad(y, xi, dy)
+        return y.detach(), dx, n_calls, fused.producer_stats(y)
+
+    y1, dx1, n1, st1 = run(True)
+    y0, dx0, n0, st0 = run(False)
+    assert n1 == (2 if cout == 128 else 1) and n0 == 0, (n1, n0)      # conv2 of the 128 -> 192 block has 192 input channels: apply pass
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0), (float((y1.float() - y0.float()).abs().max()), float((dx1.float() - dx0.float()).abs().max()))
+    assert st1 is not None and st0 is not None and torch.equal(st1, st0)
+    xr = x0.float().contiguous().requires_grad_(True)
+    yr = ref_blk(xr)
+    (dxr,) = torch.autograd.grad(yr, xr, dy.float().contiguous())
+    assert float((y1.float() - yr).abs().max()) < 6e-3 * max(1.0, float(yr.abs().max()))
+    assert float((dx1.float() - dxr).abs().max()) < 8e-3 * max(1.0, float(dxr.abs().max()))
+
+
+def test_latent_conv_in_and_the_folded_quant_conv_run_on_own_kernels():
+    """conv_in of the U-Net / ControlNet (4 latent channels -> 320) and the VAE encoder's conv_out with its 1x1 quant_conv composed
+    in (512 -> 8, forward and data gradient): the last convolutions of the training step that ran on MIOpen (round 5)."""
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(12, 4, 64, 64, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(320, 4, 3, 3, device="cuda", generator=g) / 6.0).half().contiguous(**cl)
+    b = torch.randn(320, device="cuda", generator=g).half()
+    before = _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0)
+    with torch.no_grad():
+        out = fused.conv3x3_latent_in(x, w, b)
+        out4 = fused.conv3x3_latent_in(x[:4], w, b)               # the shared prefix of a replicated batch
+    assert _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0) == before + 2
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    assert float((out.float() - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max())) and torch.equal(out4, out[:4])
+    # conv_out . quant_conv of the VAE encoder
+    conv_out = torch.nn.Conv2d(512, 8, 3, padding=1).cuda().half().to(**cl).requires_grad_(False)
+    quant = torch.nn.Conv2d(8, 8, 1).cuda().half().to(**cl).requires_grad_(False)
+    with torch.no_grad():
+        quant.weight.add_(torch.eye(8, device="cuda").half().reshape(8, 8, 1, 1))
+    h = torch.randn(4, 512, 64, 64, device="cuda", generator=g).half().contiguous(**cl).requires_grad_(True)
+    w2, b2 = fused.folded_quant_conv(conv_out, quant)
+    assert fused.folded_quant_conv(conv_out, quant)[0] is w2      # cached
+    y = fused.conv3x3_narrow_out(h, w2, b2)
+    dy = torch.randn(y.shape, device="cuda", generator=g).half().contiguous(**cl)
+    c0 = _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0)
+    (dh,) = torch.autograd.grad(y, h, dy)
+    assert _lib.call_counts.get("gip_conv3x3_fewch_nhwc_f16", 0) == c0 + 1, "the data gradient did not run on the few-channel kernel"
+    hr = h.detach().float().requires_grad_(True)
+    yr = F.conv2d(F.conv2d(hr, conv_out.weight.float(), conv_out.bias.float(), padding=1), quant.weight.float(), quant.bias.float())
+    (dhr,) = torch.autograd.grad(yr, hr, dy.float())
+    assert float((y.float() - yr).abs().max()) <= 3e-3 * max(1.0, float(yr.abs().max()))
+    assert float((dh.float() - dhr).abs().max()) <= 3e-3 * max(1.0, float(dhr.abs().max()))
+
+
+def test_batched_own_gemm_equals_sixteen_products():
+    """gip_linear_batched_f16 (blockIdx.y = product): the sixteen GEMMs of a Winograd convolution in one launch of the own MFMA
+    kernel == torch.bmm in fp32 of the same half operands; both channel-tile widths, a ragged row count."""
+    import ctypes
+    from gaussianip_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for T, K, Nout in ((768, 1280, 1280), (200, 640, 320), (3072, 960, 640)):
+        V = (torch.randn(16, T, K, device="cuda", generator=g) * 0.5).half()
+        U = (torch.randn(16, Nout, K, device="cuda", generator=g) * 0.05).half()
+        M = torch.empty(16, T, Nout, device="cuda", dtype=torch.float16)
+        rc = _lib.nn_lib().gip_linear_batched_f16(ctypes.c_void_p(V.data_ptr()), ctypes.c_void_p(U.data_ptr()), ctypes.c_void_p(M.data_ptr()), 16, T, K, Nout,
+                                                  T * K, Nout * K, T * Nout, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        ref = torch.bmm(V.float(), U.float().transpose(1, 2))
+        assert float((M.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (T, K, Nout)
+
+
+def test_winograd_convolution_with_the_own_batched_gemm(monkeypatch):
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    monkeypatch.setenv("GIP_WINOGRAD_GEMM", "own")
+    g = torch.Generator(device="cuda").manual_seed(21)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(12, 1280, 16, 16, device="cuda", generator=g).half().contiguous(**cl)
+    w = (torch.randn(1280, 1280, 3, 3, device="cuda", generator=g) / (3 * 1280 ** 0.5)).half().contiguous(**cl)
+    b = torch.randn(1280, device="cuda", generator=g).half()
+    before = _lib.call_counts.get("gip_linear_batched_f16", 0)
+    with torch.no_grad():
+        assert fused._winograd_applies(x, w, None)
+        out = fused.conv3x3(x, w, b)
+    assert _lib.call_counts.get("gip_linear_batched_f16", 0) == before + 1
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    assert float((out.float() - ref).abs().max()) <= 6e-3 * max(1.0, float(ref.abs().max()))
