@@ -186,9 +186,10 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
     header->num_segments = s_acc[1][1];
     header->num_checkpoints = s_acc[1][2];
     if (host_header) {      // pinned host mirror: the caller's capacity check needs no device-to-host copy
+      // (no system-scope fence here: the host reads the mirror only after an event recorded behind this kernel, and the
+      // kernel's completion releases its stores; the fence held the last workgroup for a PCIe round trip)
       host_header[0] = GIP_ABI_VERSION; host_header[1] = total;
       host_header[2] = (total > kp.capacity) ? 1u : 0u; host_header[3] = s_max;
-      __threadfence_system();
     }
   }
 }

@@ -358,6 +358,20 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   int tap_c = tap, cb_c = cb;                      // (tap, channel block) of the step being COMPUTED (stage() runs one ahead)
   stage(tap, cb, 0);
   advance();
+  // GN-IN: this thread's eight (scale, shift) pairs are requested while the halo DMA is in flight
+  [[maybe_unused]] const int gn_cbk = (tid >> 3) & 1, gn_lch = tid & 7;
+  [[maybe_unused]] float sc8[8], sh8[8];
+  if constexpr (HALO) {
+    if ((geom >> 30) & 1) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int c = gn_cbk * 64 + gn_lch * 8 + j, g = c / (128 / gnb.G);
+        const float ad = gnb.addend ? (float)gnb.addend[(size_t)h_n * gnb.addend_stride + c] : 0.f;
+        sc8[j] = gnb.rstd[h_n * gnb.G + g] * (float)gnb.gamma[c];
+        sh8[j] = (float)gnb.beta[c] - (gnb.mean[h_n * gnb.G + g] - ad) * sc8[j];
+      }
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if constexpr (HALO) {
@@ -369,29 +383,21 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       // separately normalised tensor; halo pixels outside the image stay zero (the padding applies to y, not to x).  Saves
       // the apply pass' read + write of the activation (0.12 ms per 268 MB tensor of the VAE encoder's first level) for ~12
       // 16-byte chunks of vector work per thread and tile.
-      float* gs = (float*)(smem + HALO_BYTES + STAGE);          // stage 1 is still free: [128 channels][scale, shift]
-      if (tid < 128) {
-        const int c = tid, g = c / (128 / gnb.G);
-        const float ga = (float)gnb.gamma[c], be = (float)gnb.beta[c];
-        const float ad = gnb.addend ? (float)gnb.addend[(size_t)h_n * gnb.addend_stride + c] : 0.f;
-        const float sc = gnb.rstd[h_n * gnb.G + g] * ga;
-        gs[2 * c] = sc;
-        gs[2 * c + 1] = be - (gnb.mean[h_n * gnb.G + g] - ad) * sc;
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 2 * 180 * 8; idx += CV_THREADS) {
-        const int cbk = idx >= 180 * 8 ? 1 : 0, rem = idx - cbk * (180 * 8);
-        const int hr = rem >> 3, p = rem & 7;
+      // a thread keeps ONE 8-channel chunk (its scale / shift in registers: tid & 15 = channel block x logical chunk) and walks the
+      // halo rows tid >> 4, + 16, ...: 11-12 chunks of 16 bytes per thread, no table in LDS, one LDS round trip per chunk
+      const int lch = gn_lch;
+      unsigned char* hb = smem + gn_cbk * CVH_KC_BYTES;
+#pragma unroll 4
+      for (int hr = tid >> 4; hr < 180; hr += CV_THREADS / 16) {
         const int hy = hr / 18, hx = hr - hy * 18;
         const int iy = (int)h_y0 - 1 + hy, ix = (int)h_x0 - 1 + hx;
-        if (!((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)) continue;
-        const int c0 = cbk * 64 + ((p ^ ((hr >> 1) & 7)) << 3);
-        f16x8* ptr = (f16x8*)(smem + cbk * CVH_KC_BYTES + hr * 128 + p * 16);
+        if (!((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)) continue;      // outside the image: y is zero-padded
+        f16x8* ptr = (f16x8*)(hb + hr * 128 + ((lch ^ ((hr >> 1) & 7)) << 4));
         const f16x8 v = *ptr;
         f16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const float y = gs[2 * (c0 + j)] * (float)v[j] + gs[2 * (c0 + j) + 1];
+          const float y = sc8[j] * (float)v[j] + sh8[j];
           o[j] = (_Float16)(gnb.silu ? y * __builtin_amdgcn_rcpf(1.f + __expf(-y)) : y);
         }
         *ptr = o;
