@@ -20,7 +20,7 @@
 #include "gip_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// scan: ceil(V*T / 1024) + 1 INDEPENDENT workgroups of 1024 threads, one launch, no inter-workgroup communication
+// scan: ceil(V*T / 1024) + ceil(V*nblk / 1024) INDEPENDENT workgroups of 1024 threads, one launch, no inter-workgroup communication
 // ------------------------------------------------------------------------------------------------
 // Round 5.  The round-2..4 kernel ran three workgroups (tile prefixes / launch order / instance offsets) whose threads each
 // walked a 16-tile chunk out of LDS: 17.5 us at V*T = 16384 with 83 % of the launch idle.  Now every
@@ -31,8 +31,8 @@
 //   pass 2  its own chunk: block-wide exclusive scan of the three quantities (tile_start / seg_start / ckpt_start = before +
 //           scan), class ranks by ballot (tile_order position = class base + class-before + rank).
 // The redundant pass 1 costs V*T * 8 bytes of L2 reads per workgroup (128 KB at four 1024^2 views) and removes every
-// dependency between workgroups.  Workgroup 0 also writes the header (+ the pinned host mirror) and zeroes the per-tile sort's
-// work cursors; the extra last workgroup turns the per-256-Gaussian sums of tiles_touched into instance offsets.
+// dependency between workgroups.  Workgroup 0 also writes the header (+ the pinned host mirror); the workgroups behind the tile
+// chunks turn the per-256-Gaussian sums of tiles_touched into instance offsets the same way (a chunk each, own prefix).
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
 #define SCAN_CHUNK SCAN_THREADS        // tiles per workgroup
@@ -80,17 +80,33 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
   const int n = kp.V * kp.T;
   const int n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x == n_chunks) {
-    // ---- instance offsets: exclusive scan of the per-256-Gaussian sums of tiles_touched (V * nblk entries) ----
+  if ((int)blockIdx.x >= n_chunks) {
+    // ---- instance offsets: exclusive scan of the per-256-Gaussian sums of tiles_touched (V * nblk entries), the same way: a
+    //      workgroup per 1024-entry chunk sums everything BEFORE its chunk itself (coalesced, 8 loads in flight), then scans its
+    //      chunk.  (Until round 5 ONE workgroup walked a contiguous slice per thread with dependent loads: 46 + 46 serial round
+    //      trips at 1M Gaussians x 12 views — that, not the tile prefixes, was the 75 us of the 1M scan.)
     const int nb = kp.V * kp.nblk;
-    const int per = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int lo = tid * per, hi = min(nb, lo + per);
-    uint32_t sum = 0;
-    for (int i = lo; i < hi; i++) sum += block_sums[i];
+    const int c0 = ((int)blockIdx.x - n_chunks) * SCAN_CHUNK;
+    uint32_t before = 0;
+    for (int i0 = tid; i0 < c0; i0 += 8 * SCAN_THREADS) {
+      uint32_t v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * SCAN_THREADS; v8[u] = i < c0 ? block_sums[i] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) before += v8[u];
+    }
+    before = wave_sum_u32(before);
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&s_max, before);
+    __syncthreads();
+    const uint32_t base = s_max;
+    const int i = c0 + tid;
+    const uint32_t v = i < nb ? block_sums[i] : 0u;
     uint32_t total;
-    uint32_t run = block_excl_scan(sum, s_w, &total);
-    for (int i = lo; i < hi; i++) { block_offset[i] = run; run += block_sums[i]; }
-    if (tid == 0) block_offset[nb] = total;
+    const uint32_t e = block_excl_scan(v, s_w, &total);
+    if (i < nb) block_offset[i] = base + e;
+    if (c0 + SCAN_CHUNK >= nb && tid == 0) block_offset[nb] = base + total;      // the last chunk closes the array
     return;
   }
   const int chunk0 = (int)blockIdx.x * SCAN_CHUNK;
@@ -195,9 +211,9 @@ gip_scan_kernel(GipKernelParams kp, const uint32_t* __restrict__ tile_count, con
 }
 
 void gip_launch_scan(const GipKernelParams& kp, GipStatePtrs st, hipStream_t s) {
-  const int n = kp.V * kp.T;
-  const int n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  hipLaunchKernelGGL(gip_scan_kernel, dim3(n_chunks + 1), dim3(SCAN_THREADS), 0, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
+  const int n = kp.V * kp.T, nb = kp.V * kp.nblk;
+  const int n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK, b_chunks = nb > 0 ? (nb + SCAN_CHUNK - 1) / SCAN_CHUNK : 1;
+  hipLaunchKernelGGL(gip_scan_kernel, dim3(n_chunks + b_chunks), dim3(SCAN_THREADS), 0, s, kp, st.tile_count, st.tile_count_b, st.tile_start,
                      st.seg_start, st.ckpt_start, st.block_sums, st.block_offset, st.tile_order, st.header, st.host_header);
 }
 

@@ -121,6 +121,9 @@ gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, cons
   }
 }
 
+#ifndef GN_BWD_PIPELINE
+#define GN_BWD_PIPELINE 1
+#endif
 // apply: MODE 0 forward (writes y, and mean / rstd once per sample), MODE 1 backward (writes dx)
 template <int MODE>
 __global__ void __launch_bounds__(GN_BLOCK)
@@ -198,8 +201,9 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
     // the chunks it writes, and reads them first.
     constexpr int U = MODE == 0 ? 8 : 4;
     const long long stride = (long long)gm.rows_per_iter * gm.tpr;
-    for (long long r = r0 + ry; r < r1; r += (long long)U * gm.rows_per_iter) {
-      half8 xv[U], dv[MODE == 1 ? U : 1], av[MODE == 1 ? U : 1];
+    const long long step = (long long)U * gm.rows_per_iter;
+    // one trip = U rows of this thread's chunk: load(), then finish() (math + store)
+    auto load = [&](long long r, half8 (&xv)[U], half8 (&dv)[MODE == 1 ? U : 1], half8 (&av)[MODE == 1 ? U : 1]) {
       const long long off0 = base + r * gm.tpr;
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -211,6 +215,9 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
           }
         }
       }
+    };
+    auto finish = [&](long long r, const half8 (&xv)[U], const half8 (&dv)[MODE == 1 ? U : 1], const half8 (&av)[MODE == 1 ? U : 1]) {
+      const long long off0 = base + r * gm.tpr;
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (r + (long long)u * gm.rows_per_iter >= r1) break;
@@ -225,13 +232,22 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
         } else {
           float d[8];
           unpack8(dv[u], d);
+          // (the wave-uniform `silu` test sits OUTSIDE the element loop: inside it the compiler emitted one scalar branch per
+          // element, which also kept the eight elements' exp / rcp chains from overlapping)
+          if (silu) {
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float xh = (v[j] + ad[j] - mu[j]) * rs[j];
-            float g = d[j];
-            if (silu) g *= dsilu_f(ga[j] * xh + be[j]);
-            const float dxh = g * ga[j];
-            o[j] = rs[j] * (dxh - m1[j] - xh * m2[j]);
+            for (int j = 0; j < 8; j++) {
+              const float xh = (v[j] + ad[j] - mu[j]) * rs[j];
+              const float dxh = d[j] * dsilu_f(ga[j] * xh + be[j]) * ga[j];
+              o[j] = rs[j] * (dxh - m1[j] - xh * m2[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const float xh = (v[j] + ad[j] - mu[j]) * rs[j];
+              const float dxh = d[j] * ga[j];
+              o[j] = rs[j] * (dxh - m1[j] - xh * m2[j]);
+            }
           }
           if (accum) {      // the other gradient that reaches x (ResnetBlock2D: the shortcut's), added before the one rounding
             float a[8];
@@ -241,6 +257,55 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
           }
         }
         out[off0 + u * stride] = pack8(o);
+      }
+    };
+    if constexpr (MODE == 1 && !GN_BWD_PIPELINE) {
+      for (long long r = r0 + ry; r < r1; r += step) {      // (A/B build -DGN_BWD_PIPELINE=0: the round-4 loop)
+        half8 xv[U], dv[U], av[U];
+        load(r, xv, dv, av);
+        finish(r, xv, dv, av);
+      }
+    } else if constexpr (MODE == 1) {
+      // BACKWARD (round 5): two register sets, software-pipelined — the NEXT trip's 8-12 loads are issued before the current trip's
+      // ~700 vector instructions and its stores.  The kernel runs two waves per SIMD (nine 8-float parameter arrays + the rows); with
+      // one set a wave's loads only fly while its partner computes, and the 268 MB tensors of the VAE's first level moved at 3.6 TB/s
+      // (a plain copy: 5.4).  In-place use stays correct: a thread still reads every chunk it writes before writing it, and other
+      // threads' chunks are disjoint.
+      half8 xa[U], da[U], aa[U], xb[U], db[U], ab[U];
+      long long r = r0 + ry;
+      if (r < r1) load(r, xa, da, aa);
+      while (r < r1) {
+        long long rn = r + step;
+        if (rn < r1) load(rn, xb, db, ab);
+        finish(r, xa, da, aa);
+        r = rn;
+        if (r >= r1) break;
+        rn = r + step;
+        if (rn < r1) load(rn, xa, da, aa);
+        finish(r, xb, db, ab);
+        r = rn;
+      }
+    } else {
+      // FORWARD: one register set (five waves per SIMD already keep the memory pipe full: 4.0-4.4 TB/s); kept as the plain loop —
+      // the lambdas above cost it 45 registers (81 -> 126, four waves per SIMD)
+      for (long long r = r0 + ry; r < r1; r += step) {
+        half8 xv[U];
+        const long long off0 = base + r * gm.tpr;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (r + (long long)u * gm.rows_per_iter < r1) xv[u] = x[off0 + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (r + (long long)u * gm.rows_per_iter >= r1) break;
+          float v[8], o[8];
+          unpack8(xv[u], v);
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float y = sc[j] * v[j] + sh[j];
+            o[j] = silu ? silu_f(y) : y;
+          }
+          out[off0 + u * stride] = pack8(o);
+        }
       }
     }
   }
