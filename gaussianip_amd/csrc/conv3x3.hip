@@ -104,18 +104,26 @@ __device__ __forceinline__ void gnb_load(const GnBwdArgs& a, int n, int c0, int 
 }
 
 __device__ __forceinline__ void gnb_accumulate(const GnBwdArgs& a, const GnBwdLane& L, const f16x8& dy, const f16x8& xv, float* s8, float* q8) {
+  // (the wave-uniform `silu` test outside the element loop: one scalar branch per call instead of eight, and the eight exp / rcp
+  // chains can overlap)
+  if (a.silu) {
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const float xh = ((float)xv[j] + L.ad[j] - L.mu[j]) * L.rs[j];
-    float g = (float)dy[j];
-    if (a.silu) {
+    for (int j = 0; j < 8; j++) {
+      const float xh = ((float)xv[j] + L.ad[j] - L.mu[j]) * L.rs[j];
       const float v = L.ga[j] * xh + L.be[j];
       const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v));      // v_rcp_f32, not the IEEE division sequence
-      g *= sg * (1.f + v * (1.f - sg));
+      const float dxh = (float)dy[j] * (sg * (1.f + v * (1.f - sg))) * L.ga[j];
+      s8[j] += dxh;
+      q8[j] = fmaf(dxh, xh, q8[j]);
     }
-    const float dxh = g * L.ga[j];
-    s8[j] += dxh;
-    q8[j] = fmaf(dxh, xh, q8[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float xh = ((float)xv[j] + L.ad[j] - L.mu[j]) * L.rs[j];
+      const float dxh = (float)dy[j] * L.ga[j];
+      s8[j] += dxh;
+      q8[j] = fmaf(dxh, xh, q8[j]);
+    }
   }
 }
 
@@ -395,10 +403,15 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
         f16x8* ptr = (f16x8*)(hb + hr * 128 + ((lch ^ ((hr >> 1) & 7)) << 4));
         const f16x8 v = *ptr;
         f16x8 o;
+        if (gnb.silu) {        // wave-uniform, outside the element loop: the eight exp / rcp chains overlap
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const float y = sc8[j] * (float)v[j] + sh8[j];
-          o[j] = (_Float16)(gnb.silu ? y * __builtin_amdgcn_rcpf(1.f + __expf(-y)) : y);
+          for (int j = 0; j < 8; j++) {
+            const float y = sc8[j] * (float)v[j] + sh8[j];
+            o[j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.f + __expf(-y)));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) o[j] = (_Float16)(sc8[j] * (float)v[j] + sh8[j]);
         }
         *ptr = o;
       }

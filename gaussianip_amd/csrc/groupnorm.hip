@@ -95,13 +95,20 @@ gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, cons
       } else {
         float d[8];
         unpack8(dp[r * gm.tpr], d);
+        if (silu) {        // (wave-uniform test outside the element loop, as in the apply kernel)
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const float xh = (v[j] - mu[j]) * rs[j];
-          float g = d[j];
-          if (silu) g *= dsilu_f(ga[j] * xh + be[j]);
-          const float dxh = g * ga[j];
-          a0[j] += dxh; a1[j] += dxh * xh;
+          for (int j = 0; j < 8; j++) {
+            const float xh = (v[j] - mu[j]) * rs[j];
+            const float dxh = d[j] * dsilu_f(ga[j] * xh + be[j]) * ga[j];
+            a0[j] += dxh; a1[j] += dxh * xh;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float xh = (v[j] - mu[j]) * rs[j];
+            const float dxh = d[j] * ga[j];
+            a0[j] += dxh; a1[j] += dxh * xh;
+          }
         }
       }
     }
