@@ -128,9 +128,6 @@ gn_reduce_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, cons
   }
 }
 
-#ifndef GN_BWD_PIPELINE
-#define GN_BWD_PIPELINE 1
-#endif
 // apply: MODE 0 forward (writes y, and mean / rstd once per sample), MODE 1 backward (writes dx)
 template <int MODE>
 __global__ void __launch_bounds__(GN_BLOCK)
@@ -266,31 +263,14 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
         out[off0 + u * stride] = pack8(o);
       }
     };
-    if constexpr (MODE == 1 && !GN_BWD_PIPELINE) {
-      for (long long r = r0 + ry; r < r1; r += step) {      // (A/B build -DGN_BWD_PIPELINE=0: the round-4 loop)
+    if constexpr (MODE == 1) {
+      // (a two-register-set software pipeline — the next trip's loads issued before this trip's math — measured neutral in round 5:
+      // 13.33 vs 13.34 ms for the VAE's forward + backward; the pass already moves 4.6 TB/s against 5.07 for a plain copy of a
+      // 268 MB tensor.  tools/experiments/groupnorm_bwd_pipeline.txt)
+      for (long long r = r0 + ry; r < r1; r += step) {
         half8 xv[U], dv[U], av[U];
         load(r, xv, dv, av);
         finish(r, xv, dv, av);
-      }
-    } else if constexpr (MODE == 1) {
-      // BACKWARD (round 5): two register sets, software-pipelined — the NEXT trip's 8-12 loads are issued before the current trip's
-      // ~700 vector instructions and its stores.  The kernel runs two waves per SIMD (nine 8-float parameter arrays + the rows); with
-      // one set a wave's loads only fly while its partner computes, and the 268 MB tensors of the VAE's first level moved at 3.6 TB/s
-      // (a plain copy: 5.4).  In-place use stays correct: a thread still reads every chunk it writes before writing it, and other
-      // threads' chunks are disjoint.
-      half8 xa[U], da[U], aa[U], xb[U], db[U], ab[U];
-      long long r = r0 + ry;
-      if (r < r1) load(r, xa, da, aa);
-      while (r < r1) {
-        long long rn = r + step;
-        if (rn < r1) load(rn, xb, db, ab);
-        finish(r, xa, da, aa);
-        r = rn;
-        if (r >= r1) break;
-        rn = r + step;
-        if (rn < r1) load(rn, xa, da, aa);
-        finish(r, xb, db, ab);
-        r = rn;
       }
     } else {
       // FORWARD: one register set (five waves per SIMD already keep the memory pipe full: 4.0-4.4 TB/s); kept as the plain loop —
