@@ -45,3 +45,76 @@ def test_refine_pass_hip_path_matches_torch_path(monkeypatch):
     # measured (round 4, profiles/r04_refine_parity.json): mean 1.2e-3, median 7.9e-4, p99 5.6e-3, p99.99 1.2e-2, max 2.0e-2 — two
     # fp16 paths through 2 DDIM steps of ControlNet + U-Net and the VAE decoder; the round-3 bar was max < 0.15
     assert float(d.mean()) < 2.5e-3 and float(q[1]) < 1.2e-2 and float(d.max()) < 0.06, (float(d.mean()), float(q[1]), float(d.max()))
+
+
+def test_refine_denoise_loop_against_a_float32_statement_all_eight_steps():
+    """the comparison above is two fp16 paths over 2 of the 8 DDIM steps.  Here the LOOP the refine pass runs per
+    view — `refine_latents`: ControlNet + U-Net under classifier-free guidance 7.5, DDIM (eta 0) over all eight timesteps 142 ... 0, with
+    the nine target self-attentions in the 'refine' state (canonical views store tokens, key views attend mutually, other views blend
+    with their two neighbours) — runs on the product path (fp16, HIP kernels, graph-free eager: control_embedding is given) and on
+    float32 deep copies of the same networks through plain PyTorch ops, from IDENTICAL noisy latents, for a front -> left -> k0 -> v1
+    sequence (every branch of the state machine).  Reference: pipeline_ipa_controlnet.py:1447-1877, attention_processor_faceid.py:291-364."""
+    import copy
+    import json
+    import os
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance, fused, networks, refine as rf
+    gd = StableDiffusionGuidance(GuidanceConfig())
+    dev = gd.device
+
+    def f32(m):
+        m = copy.deepcopy(m).float().to(memory_format=torch.contiguous_format)
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+        return m
+    gd32 = StableDiffusionGuidance(GuidanceConfig(half_precision_weights=False, channels_last=False), unet=f32(gd.unet), controlnet=f32(gd.controlnet),
+                                   vae=f32(gd.vae))
+    dec = networks.init_for_benchmark(networks.VAEDecoder(), 5).to(dev, torch.float16).eval().requires_grad_(False)
+    vcr = rf.ViewConsistentRefiner(gd, dec.to(memory_format=torch.channels_last), num_steps=8)
+    vcr32 = rf.ViewConsistentRefiner(gd32, f32(dec), num_steps=8)
+    g = torch.Generator(device=dev).manual_seed(5)
+    H = W = 256
+    views = ["front", "left", "k0", "v1"]
+    lat0 = {n: (torch.randn(1, 4, H // 8, W // 8, device=dev, generator=g) * 0.9).half().float() for n in views}
+    ctrl = {n: torch.rand(1, 3, H, W, device=dev, generator=g).half().float() for n in views}
+    emb = (torch.randn(2, 81, 768, device=dev, generator=g) * 0.1).half().float()
+    ts = rf.refine_timesteps(8, 50, dev)
+    assert ts.tolist() == [142, 122, 101, 81, 61, 40, 20, 0]
+
+    def run(v, g_, disabled):
+        v.ctl.state = "refine"
+        for a in v.targets:
+            a.refine.stored_zt.clear()
+            a.refine.cur_denoise_step = 0
+        outs = {}
+        try:
+            for n in views:
+                v.ctl.cur_view_name = n
+                for a in v.targets:
+                    a.refine.stored_zt[n] = []
+                if "v" in n:
+                    v.ctl.cur_key_view_name_pair = rf.KEY_VIEW_NAME_PAIR[n]
+                    v.ctl.cur_key_view_weight_pair = rf.KEY_VIEW_WEIGHT_PAIR[n]
+                dt = g_.weights_dtype
+                if disabled:
+                    with fused.disabled():
+                        outs[n] = v.refine_latents(lat0[n].to(dt), emb.to(dt), ctrl[n].to(dt), ts).float()
+                else:
+                    outs[n] = v.refine_latents(lat0[n].to(dt), emb.to(dt), ctrl[n].to(dt), ts).float()
+        finally:
+            v.ctl.state = "normal"
+            for a in v.targets:
+                a.refine.stored_zt.clear()
+        return outs
+    hip = run(vcr, gd, False)
+    ref = run(vcr32, gd32, True)
+    rep = {}
+    for n in views:
+        a, b = hip[n].double().flatten(), ref[n].double().flatten()
+        rep[n] = dict(rel_l2=float((a - b).norm() / b.norm()), cosine=float(torch.dot(a, b) / (a.norm() * b.norm())),
+                      max_over_max=float((a - b).abs().max() / b.abs().max()))
+    print(json.dumps(rep, indent=1))
+    gout = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(gout):
+        json.dump(rep, open(os.path.join(gout, "refine_fp32_parity.json"), "w"), indent=1)
+    for n in views:
+        assert rep[n]["rel_l2"] < 3e-2 and rep[n]["cosine"] > 0.9995, (n, rep[n])
