@@ -109,6 +109,38 @@ _STATS_ATTR = "_gip_chan_stats"
 fallback_counts = {}
 
 
+_tuned_gemms = None
+
+
+def enable_tuned_gemms():
+    """The hipBLASLt solution per library-GEMM shape of the step, picked once by PyTorch's TunableOp on an MI355X box and shipped as a
+    results file (guidance/tunableop_gfx950.csv: 20 half-precision shapes — the Winograd products, ff_in / q|k|v below 64^2, the
+    prompt-token projections, the VAE's dense attention products; hipBLASLt solutions only, rocBLAS candidates dropped).  Reading it
+    switches TunableOp ON with tuning OFF: a listed shape runs its tuned solution, everything else the library's default; a file
+    taken with other library versions fails TunableOp's validators and is ignored.  Same-box A/B of the AHDS step: 33.84 / 33.65 ms
+    default, 33.56 / 33.49 tuned.  GIP_TUNABLEOP=0 switches it off.  Returns whether the tuned table is active."""
+    global _tuned_gemms
+    if _tuned_gemms is not None:
+        return _tuned_gemms
+    _tuned_gemms = False
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+    if os.environ.get("GIP_TUNABLEOP", "1") == "0" or not os.path.exists(path) or not torch.cuda.is_available():
+        return False
+    try:
+        import torch.cuda.tunable as tun
+        if tun.is_enabled():
+            return False                       # the host application drives TunableOp itself: leave its settings alone
+        tun.enable(True)
+        tun.tuning_enable(False)
+        tun.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "gip_tunableop_unused.csv"))    # never write next to the sources
+        _tuned_gemms = bool(tun.read_file(path))
+        if not _tuned_gemms:
+            tun.enable(False)
+    except Exception:      # noqa: BLE001  (an older PyTorch without the module: the library's defaults)
+        _tuned_gemms = False
+    return _tuned_gemms
+
+
 def fallback(site, t, library=False):
     if _DISABLED or not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float16):
         return
@@ -125,7 +157,7 @@ def fallback(site, t, library=False):
 _weights_epoch = 0
 _ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_WINOGRAD_GEMM", "GIP_GN_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
               "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
-              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_CONV_GNIN", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
+              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_CONV_GNIN", "GIP_TUNABLEOP", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
 
 
 def bump_weights_epoch():

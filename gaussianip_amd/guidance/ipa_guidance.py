@@ -136,6 +136,7 @@ class StableDiffusionGuidance:
             if self.cfg.channels_last:
                 m.to(memory_format=torch.channels_last)
         if self.device.type == "cuda" and self.weights_dtype == torch.float16:
+            fused.enable_tuned_gemms()             # the library GEMMs of the step on their tuned hipBLASLt solutions (once per process)
             self.unet.prepare_inference()          # one batched time-embedding projection per forward
             self.controlnet.prepare_inference()
         self.num_train_timesteps = 1000

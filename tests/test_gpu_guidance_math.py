@@ -60,3 +60,26 @@ def test_compute_grad_on_the_gpu_matches_the_reference_function(tag, over, host_
     assert grad.is_cuda and util["latents_noisy"].is_cuda
     np.testing.assert_allclose(util["latents_noisy"].cpu().numpy(), d[tag + "_latents_noisy"], atol=2e-6)
     np.testing.assert_allclose(grad.cpu().numpy(), d[tag + "_grad"], atol=4e-6, rtol=2e-5)
+
+
+def test_tuned_gemm_table_is_active_and_changes_no_values_beyond_rounding():
+    """guidance/tunableop_gfx950.csv (hipBLASLt solutions picked by PyTorch's TunableOp on an MI355X box, tuning OFF at run time):
+    constructing the guidance switches it on; a listed shape then runs its tuned solution — same product to half rounding, and
+    bitwise reproducible call to call (the table holds hipBLASLt solutions only)."""
+    import os
+    import torch
+    import torch.nn.functional as F
+    from gaussianip_amd.guidance import fused
+    if os.environ.get("GIP_TUNABLEOP", "1") == "0":
+        pytest.skip("GIP_TUNABLEOP=0")
+    assert fused.enable_tuned_gemms(), "the shipped TunableOp results were rejected (library versions differ from the file's validators?)"
+    import torch.cuda.tunable as tun
+    assert tun.is_enabled() and not tun.tuning_is_enabled()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = (torch.randn(12288, 640, device="cuda", generator=g) * 0.5).half()            # ff_in at 32^2: tn_5120_12288_640 is in the table
+    w = (torch.randn(5120, 640, device="cuda", generator=g) * 0.05).half()
+    b = torch.randn(5120, device="cuda", generator=g).half()
+    y1, y2 = F.linear(x, w, b), F.linear(x, w, b)
+    assert torch.equal(y1, y2)
+    ref = F.linear(x.float(), w.float(), b.float())
+    assert float((y1.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())

@@ -117,4 +117,5 @@ def test_refine_denoise_loop_against_a_float32_statement_all_eight_steps():
     if os.path.isdir(gout):
         json.dump(rep, open(os.path.join(gout, "refine_fp32_parity.json"), "w"), indent=1)
     for n in views:
-        assert rep[n]["rel_l2"] < 3e-2 and rep[n]["cosine"] > 0.9995, (n, rep[n])
+        # measured (round 5, profiles/r05_refine_fp32_parity.json): rel L2 9.2e-4 ... 9.3e-4, cosine 0.9999996 after all eight steps
+        assert rep[n]["rel_l2"] < 5e-3 and rep[n]["cosine"] > 0.9999, (n, rep[n])

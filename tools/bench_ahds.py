@@ -38,15 +38,16 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     import numpy as np
     import torch
     import scenes
-    if os.environ.get("GIP_TUNABLEOP"):
-        # experiment: PyTorch TunableOp picks the hipBLASLt / rocBLAS solution per GEMM shape (results file = $GIP_TUNABLEOP;
-        # GIP_TUNABLEOP_TUNE=1 tunes the shapes it has not seen — during the eager first call of every shape, before any capture)
+    if os.environ.get("GIP_TUNABLEOP_FILE"):
+        # (re-)tuning run: PyTorch TunableOp picks the hipBLASLt / rocBLAS solution per GEMM shape and writes $GIP_TUNABLEOP_FILE
+        # (GIP_TUNABLEOP_TUNE=1 tunes the shapes the file does not hold — during the eager first call of every shape, before any
+        # capture).  How gaussianip_amd/guidance/tunableop_gfx950.csv was made (then filtered to hipBLASLt solutions of half GEMMs).
         import torch.cuda.tunable as tun
         tun.enable(True)
-        tun.set_filename(os.environ["GIP_TUNABLEOP"])
+        tun.set_filename(os.environ["GIP_TUNABLEOP_FILE"])
         tun.tuning_enable(os.environ.get("GIP_TUNABLEOP_TUNE", "0") == "1")
-        if os.path.exists(os.environ["GIP_TUNABLEOP"]):
-            tun.read_file(os.environ["GIP_TUNABLEOP"])
+        if os.path.exists(os.environ["GIP_TUNABLEOP_FILE"]):
+            tun.read_file(os.environ["GIP_TUNABLEOP_FILE"])
     from gaussianip_amd.arguments import OptimizationParams, PipelineParams
     from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance
     from gaussianip_amd.guidance.prompts import PromptProcessor
