@@ -298,6 +298,9 @@ def nn_lib():
                                           ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
         lib.gip_timestep_embedding_f16.restype = ctypes.c_int
         lib.gip_timestep_embedding_f16.argtypes = [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp]
+        lib.gip_winograd_input_gn_f16.restype = ctypes.c_int
+        lib.gip_winograd_input_gn_f16.argtypes = [_vp, _vp] + [ctypes.c_int32] * 4 + [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp,
+                                                  ctypes.c_int32, _vp]
         lib.gip_gn_stats_from_partials.restype = ctypes.c_int
         lib.gip_gn_stats_from_partials.argtypes = [_vp, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                    _vp, ctypes.c_int32, _vp, ctypes.c_int32, _vp]

@@ -35,16 +35,41 @@ __device__ __forceinline__ wg_half8 wg_pack(const float* f) {
   return h;
 }
 
+// GroupNorm (+ SiLU) of the convolution's INPUT applied while the patch is loaded (round 5): x is the RAW tensor, the normalised
+// tensor y = silu?(GroupNorm(x + addend)) is never written or read.  The arithmetic of csrc/groupnorm.hip's apply pass (sc = rstd
+// gamma, sh = beta - (mean - addend) sc, y = sc x + sh, SiLU by v_exp + v_rcp) and its ONE rounding of y to half, so V is what the
+// transform of the separately normalised tensor gives; patch elements outside the image are zeros of y (the padding), not of x.
+struct WgGnArgs {
+  const __half* gamma;
+  const __half* beta;
+  const float* mean;      // [N, G]
+  const float* rstd;
+  const __half* addend;   // optional per-(sample, channel), row stride addend_stride (0 = one row)
+  int G, silu, addend_stride;
+};
+
 // V[p][t][c], p = 4 i + j of the transformed patch, t = (n, ty, tx) tile, c = channel; one thread = one tile x 8 channels
+template <bool GN>
 __global__ void __launch_bounds__(256)
 winograd_input_kernel(const wg_half8* __restrict__ x /* [N, H, W, C] */, wg_half8* __restrict__ V /* [16, T, C] */, int N, int H, int W, int C8,
-                      long long T) {
+                      long long T, WgGnArgs gn) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= T * C8) return;
   const int c = (int)(idx % C8);
   const long long t = idx / C8;
   const int tw = W >> 1, th = H >> 1;
   const int tx = (int)(t % tw), ty = (int)((t / tw) % th), n = (int)(t / ((long long)tw * th));
+  [[maybe_unused]] float sc[8], sh[8];
+  if constexpr (GN) {
+    const int cg = (C8 * 8) / gn.G;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int ch = c * 8 + k, g = ch / cg;
+      const float ad = gn.addend ? __half2float(gn.addend[(long long)n * gn.addend_stride + ch]) : 0.f;
+      sc[k] = gn.rstd[n * gn.G + g] * __half2float(gn.gamma[ch]);
+      sh[k] = __half2float(gn.beta[ch]) - (gn.mean[n * gn.G + g] - ad) * sc[k];
+    }
+  }
   float d[4][4][8];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -53,6 +78,18 @@ winograd_input_kernel(const wg_half8* __restrict__ x /* [N, H, W, C] */, wg_half
       const int y = 2 * ty - 1 + i, xx = 2 * tx - 1 + j;
       if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
         wg_unpack(x[(((long long)n * H + y) * W + xx) * C8 + c], d[i][j]);
+        if constexpr (GN) {
+          if (gn.silu) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+              const float yv = sc[k] * d[i][j][k] + sh[k];
+              d[i][j][k] = __half2float(__float2half_rn(yv * __builtin_amdgcn_rcpf(1.f + __expf(-yv))));
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) d[i][j][k] = __half2float(__float2half_rn(sc[k] * d[i][j][k] + sh[k]));
+          }
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 8; k++) d[i][j][k] = 0.f;
@@ -224,8 +261,20 @@ extern "C" int gip_winograd_input_f16(const void* x, void* V, int32_t N, int32_t
   if (!x || !V || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || (C & 7)) return 1;
   const long long T = (long long)N * (H / 2) * (W / 2), total = T * (C / 8);
   if (total > 0x7fffffffll * 256) return 1;
-  hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const wg_half8*)x, (wg_half8*)V, N, H, W, C / 8, T);
+  hipLaunchKernelGGL((winograd_input_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const wg_half8*)x, (wg_half8*)V, N, H, W, C / 8, T, WgGnArgs{});
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int gip_winograd_input_gn_f16(const void* x, void* V, int32_t N, int32_t H, int32_t W, int32_t C, const void* gamma, const void* beta,
+                                         const float* mean, const float* rstd, int32_t G, int32_t apply_silu, const void* addend,
+                                         int32_t addend_stride, void* stream) {
+  if (!x || !V || !gamma || !beta || !mean || !rstd || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || (C & 7) || G < 1 || C % G) return 1;
+  const long long T = (long long)N * (H / 2) * (W / 2), total = T * (C / 8);
+  if (total > 0x7fffffffll * 256) return 1;
+  WgGnArgs gn{(const __half*)gamma, (const __half*)beta, mean, rstd, (const __half*)addend, G, apply_silu, addend_stride};
+  hipLaunchKernelGGL((winograd_input_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const wg_half8*)x, (wg_half8*)V, N, H, W, C / 8, T, gn);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -157,7 +157,7 @@ def fallback(site, t, library=False):
 _weights_epoch = 0
 _ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_WINOGRAD_GEMM", "GIP_GN_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
               "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
-              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_CONV_GNIN", "GIP_TUNABLEOP", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
+              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_CONV_GNIN", "GIP_WINOGRAD_GN", "GIP_TUNABLEOP", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
 
 
 def bump_weights_epoch():
@@ -492,15 +492,31 @@ def _winograd_applies(x, w, residual):
             not (torch.is_grad_enabled() and x.requires_grad) and (residual is None or fusable(residual)))
 
 
-def _winograd_conv(x, w, bias, residual, stats=None):
-    """`stats`: a list that receives the output's chan_stats (see producer_stats) — the output transform takes them."""
+def _winograd_conv(x, w, bias, residual, stats=None, gn_in=None):
+    """`stats`: a list that receives the output's chan_stats (see producer_stats) — the output transform takes them.
+    `gn_in` = (GroupNormAct, addend, chan_stats of x): x is the RAW input of that GroupNorm (+ SiLU), which the input transform
+    applies while it loads the patches (gip_winograd_input_gn_f16) — no apply pass, no normalised tensor."""
     N, C, H, W = x.shape
     cout = w.shape[0]
     T = N * (H // 2) * (W // 2)
     lib = _lib.nn_lib()
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     V = torch.empty((16, T, C), dtype=x.dtype, device=x.device)
-    rc = lib.gip_winograd_input_f16(_p(x), _p(V), N, H, W, C, stream)
+    if gn_in is None:
+        rc = lib.gip_winograd_input_f16(_p(x), _p(V), N, H, W, C, stream)
+    else:
+        gn, addend, chan_stats = gn_in
+        ad_ptr, ad_stride = ctypes.c_void_p(None), 0
+        if addend is not None:
+            ad_ptr, ad_stride = _p(addend), (addend.stride(0) if addend.dim() == 2 and addend.shape[0] > 1 else 0)
+        mean = torch.empty((N, gn.num_groups), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        rc = lib.gip_gn_stats_from_partials(_p(mean), _p(rstd), N, H * W, C, gn.num_groups, float(gn.eps), ad_ptr, ad_stride, _p(chan_stats),
+                                            chan_stats.shape[0] // N, stream)
+        if rc != 0:
+            raise RuntimeError("gip_gn_stats_from_partials failed with status %d" % rc)
+        rc = lib.gip_winograd_input_gn_f16(_p(x), _p(V), N, H, W, C, _p(gn.weight), _p(gn.bias), _p(mean), _p(rstd), gn.num_groups, int(gn.act),
+                                           ad_ptr, ad_stride, stream)
     if rc != 0:
         raise RuntimeError("gip_winograd_input_f16 failed with status %d" % rc)
     U = _wt_cache.get("wino", w, _winograd_weight)
@@ -556,6 +572,21 @@ def conv3x3(x, w, bias=None, residual=None, gn_next=False):
     if residual is not None:
         return add_bias_residual(residual, out, bias)
     return out if bias is None else out + bias.reshape(1, -1, 1, 1)
+
+
+def conv3x3_gn(x, gn, addend, w, bias=None, residual=None, gn_next=False):
+    """conv3x3(gn(x, addend), w, bias, residual, gn_next) — ResnetBlock2D's conv(silu(norm(x))).  Where the convolution runs as
+    Winograd F(2x2, 3x3) and x carries its producer's per-channel sums, the GroupNorm (+ SiLU) happens inside the input transform:
+    one pass over x instead of apply (read + write) + transform (read).  GIP_WINOGRAD_GN=0 switches it off (same-box A/B)."""
+    st = producer_stats(x) if fusable(x) else None
+    if (st is not None and os.environ.get("GIP_WINOGRAD_GN", "1") != "0" and _winograd_applies(x, w, residual) and
+            (bias is None or not bias.requires_grad) and gn.weight.dtype == torch.float16 and not gn.weight.requires_grad and
+            x.shape[1] % gn.num_groups == 0 and
+            (addend is None or (addend.dtype == torch.float16 and addend.stride(-1) == 1 and not addend.requires_grad))):
+        holder = [] if gn_next else None
+        out = _winograd_conv(x, w, bias, residual, holder, gn_in=(gn, addend, st))
+        return attach_stats(out, holder[0] if holder else None)
+    return conv3x3(gn(x, addend), w, bias, residual, gn_next)
 
 
 def conv1x1(x, w, bias=None):

@@ -87,11 +87,12 @@ class ResBlock(nn.Module):
                 addend = F.linear(F.silu(temb), self.time_emb_proj.weight, self.time_emb_proj.bias + addend)
         # both convolutions feed a GroupNorm (conv1 -> norm2; conv2 -> the next block's norm1 / a transformer's norm /
         # norm_out): their epilogues take its statistics, so that GroupNorm reads its input once (apply) instead of twice
-        h = conv3x3(self.norm1(x), self.conv1.weight, gn_next=True)
+        # (conv3x3_gn: where the convolution runs as Winograd, the GroupNorm + SiLU is applied inside its input transform)
+        h = fused.conv3x3_gn(x, self.norm1, None, self.conv1.weight, gn_next=True)
         if self.conv_shortcut is None:
-            return conv3x3(self.norm2(h, addend), self.conv2.weight, self.conv2.bias, x, gn_next=True)
-        return conv3x3(self.norm2(h, addend), self.conv2.weight, self.conv2.bias,
-                       conv1x1(x, self.conv_shortcut.weight, self.conv_shortcut.bias), gn_next=True)
+            return fused.conv3x3_gn(h, self.norm2, addend, self.conv2.weight, self.conv2.bias, x, gn_next=True)
+        return fused.conv3x3_gn(h, self.norm2, addend, self.conv2.weight, self.conv2.bias,
+                                conv1x1(x, self.conv_shortcut.weight, self.conv_shortcut.bias), gn_next=True)
 
     staged_addend = None
 

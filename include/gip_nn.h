@@ -228,6 +228,12 @@ int gip_upsample2x_conv3x3_nhwc_f16(const void* x, const void* wt4, const void* 
  * gip_conv3x3_nhwc_f16 where the GEMMs dominate the transforms (measured: only the 1280 / 1920 / 2560-channel layers at
  * 16 x 16).  fp16 Winograd adds rounding of V and M: ~2x the implicit GEMM's error against fp32 (tests/test_gpu_conv.py). */
 int gip_winograd_input_f16(const void* x, void* V, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* gip_winograd_input_f16 on y = silu?(GroupNorm(x + addend)) WITHOUT materialising y: x is the raw tensor, mean / rstd [N, G] come from
+ * gip_gn_stats_from_partials (or any GroupNorm statistics pass), the normalisation — the apply pass' arithmetic, one rounding of y to
+ * half — happens while the 4 x 4 patches are loaded.  ResnetBlock2D's conv(silu(norm(x))) at the levels that run as Winograd. */
+int gip_winograd_input_gn_f16(const void* x, void* V, int32_t N, int32_t H, int32_t W, int32_t C, const void* gamma, const void* beta,
+                              const float* mean, const float* rstd, int32_t G, int32_t apply_silu, const void* addend,
+                              int32_t addend_stride, void* stream);
 int gip_winograd_output_f16(const void* M, const void* bias, const void* residual, void* out, int32_t N, int32_t H, int32_t W,
                             int32_t C, void* stream);
 /* gip_winograd_output_f16 that also writes chan_stats [N * H * W / 128][C][2] (may be NULL): the statistics of the GroupNorm

@@ -680,3 +680,61 @@ def test_winograd_convolution_with_the_own_batched_gemm(monkeypatch):
     assert _lib.call_counts.get("gip_linear_batched_f16", 0) == before + 1
     ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
     assert float((out.float() - ref).abs().max()) <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [(12, 640, 640, 1280, 16, "rows"), (8, 1280, 640, 1280, 16, None), (4, 640, 320, 640, 32, "one"),
+                                 (12, 1280, 1280, 1280, 16, "rows")])
+def test_groupnorm_inside_the_winograd_input_transform(cfg, monkeypatch):
+    """fused.conv3x3_gn: GroupNorm + SiLU applied while the Winograd input transform loads its patches (gip_winograd_input_gn_f16,
+    statistics from the producer's partial sums) against the apply pass followed by the plain transform: the same fp32 formula with
+    one rounding of the normalised value to half, so the outputs agree to the rounding of a few taps (see the halo test above);
+    groups that straddle the kernel's 8-channel chunks (1920 / 32 = 60 channels per group), per-sample / shared / no addend."""
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    N, ca, cb, cout, H, ad_kind = cfg
+    C = ca + cb
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    cl = dict(memory_format=torch.channels_last)
+    a = (torch.randn(N, ca, H, H, device="cuda", generator=g) * 1.3 + 0.2).half().contiguous(**cl)
+    b = (torch.randn(N, cb, H, H, device="cuda", generator=g) * 0.7 - 0.4).half().contiguous(**cl)
+    w = (torch.randn(cout, C, 3, 3, device="cuda", generator=g) / (3 * C ** 0.5)).half().contiguous(**cl)
+    bias = torch.randn(cout, device="cuda", generator=g).half()
+    res = torch.randn(N, cout, H, H, device="cuda", generator=g).half().contiguous(**cl)
+    gn = fused.GroupNormAct(32, C, eps=1e-5, act=True).cuda().half().requires_grad_(False)
+    with torch.no_grad():
+        gn.weight.add_(torch.randn(C, device="cuda", generator=g).half() * 0.2)
+        gn.bias.add_(torch.randn(C, device="cuda", generator=g).half() * 0.2)
+    addend = {None: None, "one": torch.randn(C, device="cuda", generator=g).half() * 0.3,
+              "rows": torch.randn(N, C, device="cuda", generator=g).half() * 0.3}[ad_kind]
+
+    def run(on):
+        monkeypatch.setenv("GIP_WINOGRAD_GN", "1" if on else "0")
+        x = fused.cat_skip(a, b)
+        assert fused.producer_stats(x) is not None
+        before = _lib.call_counts.get("gip_winograd_input_gn_f16", 0)
+        with torch.no_grad():
+            assert fused._winograd_applies(x, w, res)
+            y = fused.conv3x3_gn(x, gn, addend, w, bias, res, gn_next=True)
+        return y, _lib.call_counts.get("gip_winograd_input_gn_f16", 0) - before, x
+
+    y1, n1, x = run(True)
+    y0, n0, _ = run(False)
+    assert (n1, n0) == (1, 0)
+    d = (y1.float() - y0.float()).abs()
+    assert float(d.max()) <= 2e-3 * float(y0.float().abs().max()) and float((d > 0).float().mean()) < 0.05, \
+        (float(d.max()), float((d > 0).float().mean()))
+    st1, st0 = fused.producer_stats(y1), fused.producer_stats(y0)
+    assert st1 is not None and float((st1.double() - st0.double()).abs().max()) <= 1e-4 * float(st0.double().abs().max())
+    xf = x.float()
+    if addend is not None:
+        xf = xf + addend.float().reshape(-1 if addend.dim() == 2 else 1, C, 1, 1)
+    ref = F.conv2d(F.silu(F.group_norm(xf, 32, gn.weight.float(), gn.bias.float(), 1e-5)), w.float(), bias.float(), padding=1) + res.float()
+    assert float((y1.float() - ref).abs().max()) <= 6e-3 * max(1.0, float(ref.abs().max()))
+    # without the producer's statistics the apply-pass path runs (nothing to normalise with)
+    monkeypatch.setenv("GIP_WINOGRAD_GN", "1")
+    before = _lib.call_counts.get("gip_winograd_input_gn_f16", 0)
+    with torch.no_grad():
+        y2 = fused.conv3x3_gn(x.clone(memory_format=torch.channels_last), gn, addend, w, bias, res)
+    # (its GroupNorm then takes its own two-pass statistics: mean / rstd differ from the partial-sum ones in the last float bits)
+    assert _lib.call_counts.get("gip_winograd_input_gn_f16", 0) == before
+    assert float((y2.float() - y0.float()).abs().max()) <= 2e-3 * float(y0.float().abs().max())
