@@ -274,7 +274,7 @@ def nn_lib():
         lib.gip_conv3x3s2_nhwc_f16.restype = ctypes.c_int
         lib.gip_conv3x3s2_nhwc_f16.argtypes = [_vp, _vp, _vp, _vp] + [ctypes.c_int32] * 7 + [_vp, ctypes.c_size_t, _vp]
         lib.gip_linear_row_parts.restype = ctypes.c_int32
-        lib.gip_linear_row_parts.argtypes = [ctypes.c_int32]
+        lib.gip_linear_row_parts.argtypes = [ctypes.c_int64, ctypes.c_int32]
         lib.gip_linear_rows_f16.restype = ctypes.c_int
         lib.gip_linear_rows_f16.argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp, _vp]
         lib.gip_linear_ln_f16.restype = ctypes.c_int

@@ -25,6 +25,7 @@
 // tensor of twice the size — the data gradient of a stride-2 convolution and nearest-2x-upsample + convolution, each as
 // four small convolutions over the source grid (gip_conv3x3s2_dgrad_nhwc_f16, gip_upsample2x_conv3x3_nhwc_f16).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1036,7 +1037,7 @@ conv_splitk_reduce_stats_kernel(const float* __restrict__ partial, const _Float1
 
 // Debug / A-B knobs (tools/exp_conv*.py set them through ctypes; -1 = the shape heuristic below decides)
 extern "C" { int gip_dbg_conv_order = -1; int gip_dbg_conv_epilogue = -1; int gip_dbg_conv_ksplit = 0; int gip_dbg_conv_ablate = 0;
-             int gip_dbg_conv_big = -1; }
+             int gip_dbg_conv_big = -1; int gip_dbg_linear_narrow = -1; }
 // same-box A/B of a whole training step (tools/ab_ahds.sh): GIP_CONV_EPILOGUE=0 restores the per-lane 8-byte epilogue,
 // GIP_CONV_KSPLIT_R2=1 the round-2 split-K factor; read once
 static int env_int(const char* name, int dflt) {
@@ -1195,6 +1196,30 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+// GEMMs whose 128 x 128 (160) tiles leave most CUs with at most ONE workgroup run on 128 x 64 tiles: twice the workgroups, and a
+// lone workgroup's K step (8 LDS-DMA instructions per wave + 32 MFMAs, in series inside the wave: tools/experiments/
+// conv3x3_four_stage.diff.txt) becomes 6 + 16.  GIP_LINEAR_NARROW = the largest 128-wide grid that takes the narrow tile (0: off).
+static bool narrow_tiles(long long M, int Nout, int bn) {
+  static const int env_narrow = env_int("GIP_LINEAR_NARROW", 256);
+  const int lim = gip_dbg_linear_narrow >= 0 ? gip_dbg_linear_narrow : env_narrow;
+  return lim > 0 && !(Nout & 63) && ((M + CV_BM - 1) / CV_BM) * ((Nout + bn - 1) / bn) <= lim;
+}
+
+// channel-tile width of the plain (no GEGLU) linear for an [M, Nout] output: 160 where Nout is a multiple of 160 but not of 128
+// (320, 960), 128 otherwise, 64 on small grids (narrow_tiles)
+static int linear_width(long long M, int Nout) {
+  const int wide = (Nout % 160 == 0 && Nout % 128 != 0) ? 160 : 128;
+  return narrow_tiles(M, Nout, wide) ? 64 : wide;
+}
+template <class F>
+static int with_linear_width(long long M, int Nout, F f) {
+  switch (linear_width(M, Nout)) {
+    case 64: return f(std::integral_constant<int, 64>{});
+    case 160: return f(std::integral_constant<int, 160>{});
+    default: return f(std::integral_constant<int, 128>{});
+  }
+}
+
 static bool fits32(long long M, int Cin, int Cout, int wrows, int taps) {
   return M * (long long)(Cin > Cout ? Cin : Cout) * 2 < (1ll << 31) && (long long)wrows * taps * Cin * 2 < (1ll << 31);
 }
@@ -1260,20 +1285,20 @@ extern "C" int gip_linear_stats_f16(const void* x, const void* w, const void* bi
   if (!x || !w || !out || !chan_stats || M < 1 || M >= (1ll << 31) || K < CV_BK || K % CV_BK || Nout < 8 || (Nout & 7)) return 1;
   if (!fits32(M, K, Nout, Nout, 1)) return 1;
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
   const int geom = 1 | (1 << 8) | (1 << 16);
-  return wide ? launch<160, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, chan_stats)
-              : launch<128, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, chan_stats);
+  return with_linear_width(M, Nout, [&](auto bn) {
+    return launch<decltype(bn)::value, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, chan_stats);
+  });
 }
 
 // Number of per-row partial sums a [M, Nout] output of the linear kernel carries in rows_out (= its channel tiles).
-extern "C" int32_t gip_linear_row_parts(int32_t Nout) {
-  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
-  return (Nout + (wide ? 160 : 128) - 1) / (wide ? 160 : 128);
+extern "C" int32_t gip_linear_row_parts(int64_t M, int32_t Nout) {
+  const int bn = linear_width(M, Nout);
+  return (Nout + bn - 1) / bn;
 }
 
 // gip_linear_f16 (no GEGLU) that also leaves, per output row, the (sum, sum of squares) of the final half-rounded output over
-// each channel tile: rows_out [M][gip_linear_row_parts(Nout)][2] float32 — what the LayerNorm of that row needs.
+// each channel tile: rows_out [M][gip_linear_row_parts(M, Nout)][2] float32 — what the LayerNorm of that row needs.
 extern "C" int gip_linear_rows_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M,
                                    int32_t K, int32_t Nout, float* rows_out, void* stream) {
   if (!x || !w || !out || !rows_out || M < 1 || M >= (1ll << 31) || K < CV_BK || K % CV_BK || Nout < 8 || (Nout & 7)) return 1;
@@ -1281,10 +1306,10 @@ extern "C" int gip_linear_rows_f16(const void* x, const void* w, const void* bia
   GnBwdArgs g = {};
   g.rows_out = rows_out;
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
   const int geom = 1 | (1 << 8) | (1 << 16);
-  return wide ? launch<160, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g)
-              : launch<128, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
+  return with_linear_width(M, Nout, [&](auto bn) {
+    return launch<decltype(bn)::value, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
+  });
 }
 
 // LayerNorm(x) W^T + b (optionally GEGLU of it) WITHOUT a LayerNorm pass: x is read raw, `wg` = W * gamma (half), s_n = sum_k wg[n][k],
@@ -1302,9 +1327,9 @@ extern "C" int gip_linear_ln_f16(const void* x, const void* wg, const float* s_v
   hipStream_t s = (hipStream_t)stream;
   const int geom = 1 | (1 << 8) | (1 << 16);
   if (geglu) return launch<128, 2, 1, true>(x, wg, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
-  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
-  return wide ? launch<160, 2, 1, false>(x, wg, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g)
-              : launch<128, 2, 1, false>(x, wg, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
+  return with_linear_width(M, Nout, [&](auto bn) {
+    return launch<decltype(bn)::value, 2, 1, false>(x, wg, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, &g);
+  });
 }
 
 extern "C" int gip_conv3x3s2_nhwc_f16(const void* x, const void* w, const void* bias, void* out, int32_t N, int32_t Hin,
@@ -1406,7 +1431,7 @@ extern "C" int gip_linear_f16(const void* x, const void* w, const void* bias, co
   if (!fits32(M, K, Nout, geglu ? 2 * Nout : Nout, 1)) return 1;
   hipStream_t s = (hipStream_t)stream;
   if (geglu) return launch<128, 2, 1, true>(x, w, bias, nullptr, out, 1, 1, (int)M, K, Nout, s);
-  const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
-  return wide ? launch<160, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s)
-              : launch<128, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s);
+  return with_linear_width(M, Nout, [&](auto bn) {
+    return launch<decltype(bn)::value, 2, 1, false>(x, w, bias, residual, out, 1, 1, (int)M, K, Nout, s);
+  });
 }

@@ -826,7 +826,7 @@ def linear(x, w, bias=None, residual=None, geglu_act=False, stats=None, rows=Non
         if rows is not None and not geglu_act and stats is None and n_out % 8 == 0:
             # `rows`: a list that receives the per-row (sum, sum of squares) partials of the output [M, parts, 2]
             lib = _lib.nn_lib()
-            rt = torch.empty((M, lib.gip_linear_row_parts(n_out), 2), dtype=torch.float32, device=x.device)
+            rt = torch.empty((M, lib.gip_linear_row_parts(M, n_out), 2), dtype=torch.float32, device=x.device)
             rc = lib.gip_linear_rows_f16(_p(x), _p(w), null if bias is None else _p(bias), null if residual is None else _p(residual), _p(out),
                                          M, x.shape[-1], n_out, _p(rt), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
             if rc != 0:

@@ -259,10 +259,10 @@ int gip_linear_batched_f16(const void* x, const void* w, void* out, int32_t B, i
  * reference: diffusers BasicTransformerBlock as run by threestudio/models/guidance/ipa_guidance.py:311-358).
  *   out = LN(x) W^T + b  =  rstd_m (x_m . (W gamma)_n) - rstd_m mu_m s_n + t_n,   s_n = sum_k (W gamma)[n][k],  t_n = sum_k W[n][k] beta_k + b_n
  * gip_linear_rows_f16: gip_linear_f16 (no GEGLU) whose epilogue also leaves, per output row, the (sum, sum of squares) of the final
- *   half-rounded output over each channel tile: rows_out [M][gip_linear_row_parts(Nout)][2] float32.
+ *   half-rounded output over each channel tile: rows_out [M][gip_linear_row_parts(M, Nout)][2] float32.
  * gip_linear_ln_f16: x raw [M, K]; wg = W * gamma (half; GEGLU: [2 Nout, K] = [value | gate]); s, t float32 [Nout] ([2 Nout]);
  *   ln_rows [M][ln_parts][2] = the partial sums the producer of x left; eps = the LayerNorm's.  No LayerNorm kernel, no normalised copy. */
-int32_t gip_linear_row_parts(int32_t Nout);
+int32_t gip_linear_row_parts(int64_t M, int32_t Nout);
 int gip_linear_rows_f16(const void* x, const void* w, const void* bias, const void* residual, void* out, int64_t M, int32_t K,
                         int32_t Nout, float* rows_out, void* stream);
 int gip_linear_ln_f16(const void* x, const void* wg, const float* s, const float* t, void* out, int64_t M, int32_t K, int32_t Nout,

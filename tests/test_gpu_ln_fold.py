@@ -30,7 +30,7 @@ def _producer(M, C, seed):
 def test_row_sums_of_the_producer(M, C):
     from gaussianip_amd import _lib
     x, rows = _producer(M, C, 1)
-    parts = _lib.nn_lib().gip_linear_row_parts(C)
+    parts = _lib.nn_lib().gip_linear_row_parts(M, C)
     assert rows.shape == (M, parts, 2)
     xf = x.double()
     assert float((rows[..., 0].double().sum(1) - xf.sum(1)).abs().max()) <= 1e-4 * float(xf.abs().sum(1).max())
@@ -116,3 +116,59 @@ def test_transformer_block_with_and_without_the_fold(monkeypatch):
     r_plain = float((y_plain.float() - ref).norm() / ref.norm())
     print("transformer block vs fp32: folded %.2e, LayerNorm kernels %.2e" % (r_fold, r_plain))
     assert r_fold < 3e-3 and r_fold < 2.0 * r_plain + 1e-4
+
+
+@pytest.mark.parametrize("M,K,N", [(768, 1280, 1280), (192, 640, 640), (3072, 320, 960), (1000, 1280, 320), (3072, 640, 1920)])
+def test_narrow_channel_tiles_of_small_grids_are_bit_identical(M, K, N, monkeypatch):
+    """GEMMs whose 128-wide (160) tiles leave most CUs with at most one workgroup run on 128 x 64 tiles (csrc/conv3x3.hip:
+    narrow_tiles): same K order per element, so every entry point — plain, GroupNorm statistics, LayerNorm row sums, folded
+    LayerNorm — gives the bits of the wide tile; the row-sum parts follow the tile width (gip_linear_row_parts(M, Nout))."""
+    import ctypes
+    from gaussianip_amd import _lib
+    from gaussianip_amd.guidance import fused
+    lib = _lib.nn_lib()
+    monkeypatch.setenv("GIP_OWN_GEMM", "2")                      # every supported shape on the own kernel (the dispatch is not under test)
+    knob = ctypes.c_int.in_dll(lib._lib, "gip_dbg_linear_narrow")
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda", generator=g).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).half()
+    b = torch.randn(N, device="cuda", generator=g).half()
+    r = torch.randn(M, N, device="cuda", generator=g).half()
+    norm = fused.LayerNorm(K).cuda().half()
+    with torch.no_grad():
+        norm.weight.add_(torch.randn(K, device="cuda", generator=g).half() * 0.2)
+        norm.bias.add_(torch.randn(K, device="cuda", generator=g).half() * 0.2)
+    w_in = (torch.randn(K, K, device="cuda", generator=g) / K ** 0.5).half()
+
+    def run(lim):
+        knob.value = lim
+        try:
+            with torch.no_grad():
+                plain = fused.linear(x, w, b, r)
+                st, rows = [], []
+                with_stats = fused.linear(x, w, b, r, stats=st) if M % 128 == 0 else plain
+                h = fused.linear(x, w_in, None, None, rows=rows)              # producer of a LayerNorm input, with its row sums
+                setattr(h, fused._ROWS_ATTR, rows[0])
+                folded = fused.linear_ln(h, norm, w, b)
+            parts = lib.gip_linear_row_parts(M, K)
+            return plain, with_stats, (st[0] if st else None), h, rows[0], folded, parts
+        finally:
+            knob.value = -1
+
+    wide = run(0)
+    narrow = run(1 << 20)
+    assert narrow[6] == (K + 63) // 64 and wide[6] in ((K + 127) // 128, (K + 159) // 160)
+    assert narrow[4].shape[1] == narrow[6] and wide[4].shape[1] == wide[6]
+    for i in (0, 1, 3):
+        assert torch.equal(narrow[i], wide[i]), i
+    if wide[2] is not None:
+        # per-128-row channel sums of the same values: a thread's rows are grouped by the tile width, so the float32 order differs
+        assert float((narrow[2].double() - wide[2].double()).abs().max()) <= 1e-5 * float(wide[2].double().abs().max())
+    # row sums: more, narrower parts of the same rows
+    assert float((narrow[4].double().sum(1) - wide[4].double().sum(1)).abs().max()) <= 1e-5 * float(wide[4].double().sum(1).abs().max())
+    assert narrow[5] is not None and wide[5] is not None
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(wide[3].float(), (K,), norm.weight.float(), norm.bias.float(), norm.eps), w.float(), b.float())
+    for got in (narrow[5], wide[5]):
+        assert float((got.float() - ref).abs().max()) <= 8e-3 * max(1.0, float(ref.abs().max()))
+    ref0 = torch.nn.functional.linear(x.float(), w.float(), b.float()) + r.float()
+    assert float((narrow[0].float() - ref0).abs().max()) <= 4e-3 * max(1.0, float(ref0.abs().max()))
