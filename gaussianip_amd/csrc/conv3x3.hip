@@ -361,6 +361,16 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   int tap_c = tap, cb_c = cb;                      // (tap, channel block) of the step being COMPUTED (stage() runs one ahead)
   stage(tap, cb, 0);
   advance();
+  // the bias of this lane's output channels is requested here, under the first operand DMA, not at the head of the epilogue (where its
+  // round trip was exposed once per tile: 1 us of a 22 us tile at the VAE's first level)
+  [[maybe_unused]] f16x4 bias4[NI];
+  if constexpr (!GEGLU) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      const int cl = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+      bias4[ni] = (bias && co0 + cl < Cout) ? *(const f16x4*)(bias + co0 + cl) : (f16x4){0, 0, 0, 0};
+    }
+  }
   // GN-IN: this thread's eight (scale, shift) pairs are requested while the halo DMA is in flight
   [[maybe_unused]] const int gn_cbk = (tid >> 3) & 1, gn_lch = tid & 7;
   [[maybe_unused]] float sc8[8], sh8[8];
@@ -504,8 +514,7 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 #pragma unroll
       for (int ni = 0; ni < NI; ni++) {
         const int cl = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
-        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (bias && co0 + cl < Cout) add4(b4, bias + co0 + cl);
+        const f32x4 b4 = (f32x4){(float)bias4[ni][0], (float)bias4[ni][1], (float)bias4[ni][2], (float)bias4[ni][3]};
         f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f}, t4 = s4;
         if (ln_fold && co0 + cl < Cout) { s4 = *(const f32x4*)(gnb.ln_s + co0 + cl); t4 = *(const f32x4*)(gnb.ln_t + co0 + cl); }
 #pragma unroll
@@ -886,7 +895,7 @@ conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, 
       for (int ni = 0; ni < NI; ni++) {
         const int cl = wc * (BN / WN) + ni * 16 + (lane >> 4) * 4;
         f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (bias && co0 + cl < Cout) add4(b4, bias + co0 + cl);
+        if (bias && co0 + cl < Cout) add4(b4, bias + co0 + cl);      // (not preloaded before the K loop: this kernel's register file is full)
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) {
           const int p = (PASSES == 1 ? wr * (CVB_BM / WM) : 0) + mi * 16 + (lane & 15);
