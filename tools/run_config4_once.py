@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4] launch set for the profiler: 1M Gaussians, 1024^2, ONE 12-view set of the orbit, forward + backward,
-`n` times (argv[1], default 3) after a sizing call.  Used by tools/collect_profiles.sh (kernel stats + HBM counters at 1M)."""
+`n` times (argv[1], default 3) after a sizing call; argv[2] = views per launch set (default 12: how the record tables of a set
+compete for the caches is what round 6 measured with it).  Used by tools/collect_profiles.sh (kernel stats + HBM counters at 1M)."""
 import os
 import sys
 
@@ -16,7 +17,7 @@ def main():
     from gaussianip_amd import GaussianRasterizationSettings, rasterize_views
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     dev = torch.device("cuda")
-    P, H, W, V = 1000000, 1024, 1024, 12
+    P, H, W, V = 1000000, 1024, 1024, (int(sys.argv[2]) if len(sys.argv) > 2 else 12)
     sc = scenes.make_scene("human", P, seed=42)
     sc["scales"] = (sc["scales"] / 1.6).astype(np.float32)
     sc["opacities"][:] = 0.6
