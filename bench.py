@@ -45,7 +45,7 @@ def raster_source_hash():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "gaussianip_amd", "csrc")
-    for f in ("preprocess.hip", "binning.hip", "api.hip", "render_forward.hip", "render_backward.hip", "gather_backward.hip",
+    for f in ("preprocess.hip", "binning.hip", "api.hip", "render_forward.hip", "render_backward.hip", "gather_backward.hip", "sh_mfma.hip",
               "gip_internal.h", os.path.join("..", "..", "include", "gip_raster.h")):
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())

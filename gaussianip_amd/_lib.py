@@ -22,7 +22,8 @@ class GipRasterConfig(ctypes.Structure):
                 ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32), ("prefiltered", ctypes.c_int32),
                 ("debug", ctypes.c_int32), ("scale_modifier", ctypes.c_float),
                 ("tanfovx", ctypes.c_float * GIP_MAX_VIEWS), ("tanfovy", ctypes.c_float * GIP_MAX_VIEWS),
-                ("capacity", ctypes.c_uint64), ("exact_lists", ctypes.c_int32), ("forward_only", ctypes.c_int32)]
+                ("capacity", ctypes.c_uint64), ("exact_lists", ctypes.c_int32), ("forward_only", ctypes.c_int32),
+                ("sh_scalar", ctypes.c_int32)]
 
 
 class GipRasterInputs(ctypes.Structure):
@@ -46,7 +47,7 @@ class GipRasterGradsOut(ctypes.Structure):
 class GipRasterStateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in ("header", "records", "inst_offset", "tile_count", "tile_start",
                                                 "tile_cursor", "tile_count_b", "inst_slot", "block_sums", "block_offset", "keys", "n_contrib",
-                                                "final_T", "tile_order", "seg_start", "ckpt_start", "seg_tile", "checkpoints", "total")] + \
+                                                "final_T", "tile_order", "seg_start", "ckpt_start", "seg_tile", "checkpoints", "sh_colors", "total")] + \
                [(n, ctypes.c_uint32) for n in ("tiles_x", "tiles_y", "num_blocks", "reserved")]
 
 

@@ -5,6 +5,10 @@
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// matrix-core SH path (sh_mfma.hip): SH coefficients given (sh_coeffs > 0; 0 = colors_precomp), something to contract
+// (degree >= 1), views to batch (V >= 2), not switched off
+static bool sh_mfma_path(const GipRasterConfig* c) { return c->sh_coeffs > 0 && c->sh_degree >= 1 && c->V >= 2 && !c->sh_scalar; }
+
 static bool valid_config(const GipRasterConfig* c) {
   if (!c) return false;
   if (c->P < 0 || c->V < 1 || c->V > GIP_MAX_VIEWS || c->H < 1 || c->W < 1) return false;
@@ -56,6 +60,7 @@ extern "C" int gip_raster_state_layout(const GipRasterConfig* c, GipRasterStateL
   L->seg_tile = off;     off = align256(off + seg_cap * 4);
   L->checkpoints = off;  off = align256(off + ckpt_cap * GIP_CKPT_FLOATS * 256 * sizeof(float));
   L->keys = off;         off = align256(off + (size_t)c->capacity * 8);
+  L->sh_colors = off;    off = align256(off + (sh_mfma_path(c) ? V * P * 4 * sizeof(float) : 0));
   L->total = off;
   return GIP_OK;
 }
@@ -81,6 +86,7 @@ static void fill_params(const GipRasterConfig* c, const GipRasterStateLayout& L,
   kp->capacity = (uint32_t)c->capacity;
   kp->exact_lists = c->exact_lists ? 1 : 0;
   kp->forward_only = c->forward_only ? 1 : 0;
+  kp->sh_mfma = sh_mfma_path(c) ? 1 : 0;
   kp->ckpt_capacity = (uint32_t)(c->capacity / GIP_SEGMENT + 1);
   kp->seg_capacity = kp->ckpt_capacity + (uint32_t)(kp->V * kp->T);
   for (int v = 0; v < c->V; v++) {
@@ -112,6 +118,7 @@ static GipStatePtrs state_ptrs(void* state, const GipRasterStateLayout& L) {
   p.ckpt_start = (uint32_t*)(b + L.ckpt_start);
   p.seg_tile = (uint32_t*)(b + L.seg_tile);
   p.checkpoints = (float*)(b + L.checkpoints);
+  p.sh_colors = (float*)(b + L.sh_colors);
   p.host_header = nullptr;
   return p;
 }
@@ -180,6 +187,7 @@ static int forward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, c
   if (state_bytes < L.total) return GIP_ERR_BUFFER_TOO_SMALL;
   GipKernelParams kp;
   fill_params(cfg, L, &kp);
+  if (!in->shs) kp.sh_mfma = 0;                      // colors_precomp with a stale sh_coeffs: nothing to contract
   GipStatePtrs st = state_ptrs(state, L);
   st.host_header = out->host_header;
   hipStream_t s = (hipStream_t)stream;
@@ -191,6 +199,7 @@ static int forward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, c
   tm.end(GIP_STAGE_CLEAR);
   if (cfg->P > 0) {
     tm.begin(GIP_STAGE_PREPROCESS);
+    if (kp.sh_mfma) gip_launch_sh_forward_mfma(kp, *in, st.sh_colors, s);      // colours of all views on the matrix cores (same stage bracket)
     gip_launch_preprocess(kp, *in, out->radii, st, s);
     tm.end(GIP_STAGE_PREPROCESS);
     LAUNCH_CHECK();
@@ -240,6 +249,7 @@ static int backward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, 
   if (cfg->P == 0) return GIP_OK;
   GipKernelParams kp;
   fill_params(cfg, L, &kp);
+  if (!in->shs) kp.sh_mfma = 0;
   GipStatePtrs st = state_ptrs(const_cast<void*>(state), L);
   hipStream_t s = (hipStream_t)stream;
   StageTimer tm(s, times);
@@ -249,6 +259,9 @@ static int backward_impl(const GipRasterConfig* cfg, const GipRasterInputs* in, 
   LAUNCH_CHECK();
   tm.begin(GIP_STAGE_GATHER_BWD);
   gip_launch_gather_backward(kp, *in, st, (const float*)scratch, *gout, s);
+  // matrix-core SH path: the gather kernel left dL/dcolour per (view, Gaussian) where the forward's colours were; dL/dshs and
+  // the direction part of dL/dmeans3D follow from it (same stage bracket)
+  if (kp.sh_mfma && (gout->dL_dshs || gout->dL_dmeans3D)) gip_launch_sh_backward_mfma(kp, *in, st, st.sh_colors, *gout, s);
   tm.end(GIP_STAGE_GATHER_BWD);
   LAUNCH_CHECK();
   return tm.finish();

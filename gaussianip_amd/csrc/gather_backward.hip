@@ -24,7 +24,10 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
                            const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                            const float* __restrict__ camposs, const GipRecord* __restrict__ records,
                            const uint32_t* __restrict__ inst_offset, const float* __restrict__ partial,
-                           GipRasterGradsOut gout, const GipRasterHeader* __restrict__ header) {
+                           GipRasterGradsOut gout, const GipRasterHeader* __restrict__ header, float* __restrict__ sh_gcol) {
+  // sh_gcol != NULL (matrix-core SH path, sh_mfma.hip): this kernel stops at dL/dcolour — it leaves (dL/dr, dL/dg, dL/db, 0) of every
+  // (view, Gaussian), zeroed where the forward clamped the channel or the view does not see the Gaussian, in sh_gcol [V,P,4];
+  // dL/dshs and the direction part of dL/dmeans3D are gip_sh_backward_mfma_kernel's (launched behind this one)
   const int idx = blockIdx.x * GIP_BLOCK + threadIdx.x;
   if (idx >= kp.P) return;
   if (header->overflow) {
@@ -85,6 +88,7 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
     float* d2 = gout.dL_dmeans2D ? gout.dL_dmeans2D + ((size_t)v * kp.P + idx) * 3 : nullptr;
     if (!(radius > 0)) {
       if (d2) { d2[0] = 0.f; d2[1] = 0.f; d2[2] = 0.f; }
+      if (sh_gcol) reinterpret_cast<float4*>(sh_gcol)[(size_t)v * kp.P + idx] = make_float4(0.f, 0.f, 0.f, 0.f);
       continue;
     }
     // ---- fixed-order sum of this Gaussian's rows ----
@@ -181,6 +185,10 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
     // ---- colour ----
     if (colors_precomp) {
       dcol[0] += a[6]; dcol[1] += a[7]; dcol[2] += a[8];
+    } else if (sh_gcol) {
+      const uint32_t clamped = reinterpret_cast<const uint4*>(rec)[3].z;
+      reinterpret_cast<float4*>(sh_gcol)[(size_t)v * kp.P + idx] =
+          make_float4((clamped & 1u) ? 0.f : a[6], (clamped & 2u) ? 0.f : a[7], (clamped & 4u) ? 0.f : a[8], 0.f);
     } else {
       const uint32_t clamped = reinterpret_cast<const uint4*>(rec)[3].z;
       float gcol[3] = {(clamped & 1u) ? 0.f : a[6], (clamped & 2u) ? 0.f : a[7], (clamped & 4u) ? 0.f : a[8]};
@@ -241,7 +249,7 @@ gip_gather_backward_kernel(GipKernelParams kp, const float* __restrict__ means3D
   if (gout.dL_dmeans3D) { gout.dL_dmeans3D[3 * idx] = dmean0; gout.dL_dmeans3D[3 * idx + 1] = dmean1; gout.dL_dmeans3D[3 * idx + 2] = dmean2; }
   if (gout.dL_dopacities) gout.dL_dopacities[idx] = dopac;
   if (gout.dL_dcolors_precomp) { gout.dL_dcolors_precomp[3 * idx] = dcol[0]; gout.dL_dcolors_precomp[3 * idx + 1] = dcol[1]; gout.dL_dcolors_precomp[3 * idx + 2] = dcol[2]; }
-  if (gout.dL_dshs) {
+  if (gout.dL_dshs && !sh_gcol) {
     float* o = gout.dL_dshs + (size_t)idx * kp.M * 3;
 #pragma unroll
     for (int k = 0; k < MAXM * 3; k++) if (k < kp.M * 3) o[k] = dsh[k];
@@ -292,8 +300,8 @@ void gip_launch_gather_backward(const GipKernelParams& kp, const GipRasterInputs
   const dim3 grid(kp.nblk), block(GIP_BLOCK);
 #define LAUNCH(MM) hipLaunchKernelGGL((gip_gather_backward_kernel<MM>), grid, block, 0, s, kp, in.means3D, in.shs, \
     in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, st.records, \
-    st.inst_offset, partial, gout, st.header)
-  const int needed = in.shs ? (kp.D + 1) * (kp.D + 1) : 1;
+    st.inst_offset, partial, gout, st.header, kp.sh_mfma ? st.sh_colors : nullptr)
+  const int needed = (in.shs && !kp.sh_mfma) ? (kp.D + 1) * (kp.D + 1) : 1;      // matrix-core SH path: no dsh registers here
   if (needed <= 1) LAUNCH(1);
   else if (needed <= 4) LAUNCH(4);
   else if (needed <= 9) LAUNCH(9);

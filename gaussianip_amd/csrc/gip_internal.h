@@ -47,6 +47,7 @@ struct GipKernelParams {
   uint32_t ckpt_capacity;   // capacity / GIP_SEGMENT
   int exact_lists;          // GipRasterConfig::exact_lists
   int forward_only;         // GipRasterConfig::forward_only: nothing is kept for a backward
+  int sh_mfma;              // SH colours / their backward on the matrix cores (sh_mfma.hip): shs given, degree >= 1, V >= 2, !sh_scalar
   GipViewConst view[GIP_MAX_VIEWS];
 };
 
@@ -70,6 +71,7 @@ struct GipStatePtrs {
   uint32_t* seg_tile;       // [seg_capacity]
   float* checkpoints;       // [ckpt_capacity][5][256]
   uint32_t* host_header;    // optional pinned host mirror of the header's first words (GipRasterOutputs::host_header)
+  float* sh_colors;         // [V,P,4] (matrix-core SH path only): forward colours before the clamp / backward dL/dcolour
 };
 
 // --- launchers implemented in the .hip translation units -----------------------------------------
@@ -80,6 +82,8 @@ void gip_launch_tile_sort(const GipKernelParams& kp, GipStatePtrs st, hipStream_
 void gip_launch_render_forward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, float* color, float* depth, float* alpha, hipStream_t s);
 void gip_launch_render_backward(const GipKernelParams& kp, const float* bg, GipStatePtrs st, const GipRasterGradsIn& gin, float* partial, hipStream_t s);
 void gip_launch_gather_backward(const GipKernelParams& kp, const GipRasterInputs& in, GipStatePtrs st, const float* partial, const GipRasterGradsOut& gout, hipStream_t s);
+void gip_launch_sh_forward_mfma(const GipKernelParams& kp, const GipRasterInputs& in, float* sh_colors, hipStream_t s);
+void gip_launch_sh_backward_mfma(const GipKernelParams& kp, const GipRasterInputs& in, GipStatePtrs st, const float* sh_gcol, const GipRasterGradsOut& gout, hipStream_t s);
 void gip_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // --- device helpers ---------------------------------------------------------------------------

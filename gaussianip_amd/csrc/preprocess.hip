@@ -58,7 +58,7 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
                       int32_t* __restrict__ radii, GipRecord* __restrict__ records,
                       uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_count_b,
                       uint32_t* __restrict__ inst_slot, uint32_t* __restrict__ block_sums,
-                      GipRasterHeader* __restrict__ header) {
+                      GipRasterHeader* __restrict__ header, const float* __restrict__ sh_colors) {
   const int v = blockIdx.y;
   const int idx = blockIdx.x * PRE_THREADS + threadIdx.x;
   const float* view = viewmatrix + 16 * v;   // wave-uniform -> scalar loads
@@ -165,6 +165,12 @@ gip_preprocess_kernel(GipKernelParams kp, const float* __restrict__ means3D, con
           float cr, cg, cb;
           if (colors_precomp) {
             cr = colors_precomp[3 * idx]; cg = colors_precomp[3 * idx + 1]; cb = colors_precomp[3 * idx + 2];
+          } else if (sh_colors) {
+            // matrix-core SH path (sh_mfma.hip): sum_k basis_k sh_k + 0.5 of every view came out of one view-batched launch
+            const float4 c4 = reinterpret_cast<const float4*>(sh_colors)[(size_t)v * kp.P + idx];
+            cr = c4.x; cg = c4.y; cb = c4.z;
+            clamped = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
+            cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
           } else {
             const float d0 = p0 - campos[0], d1 = p1 - campos[1], d2 = p2 - campos[2];
             const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
@@ -349,7 +355,8 @@ void gip_launch_preprocess(const GipKernelParams& kp, const GipRasterInputs& in,
   dim3 grid((kp.nblk + PRE_THREADS / GIP_BLOCK - 1) / (PRE_THREADS / GIP_BLOCK), kp.V), block(PRE_THREADS);
   hipLaunchKernelGGL(gip_preprocess_kernel, grid, block, 0, s, kp, in.means3D, in.shs, in.colors_precomp, in.opacities,
                      in.scales, in.rotations, in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, radii,
-                     st.records, st.tile_count, st.tile_count_b, st.inst_slot, st.block_sums, st.header);
+                     st.records, st.tile_count, st.tile_count_b, st.inst_slot, st.block_sums, st.header,
+                     kp.sh_mfma ? st.sh_colors : nullptr);
 }
 
 // mark_visible: the fork's checkFrustum (view-space z > 0.2).

@@ -64,6 +64,12 @@ def _exact_lists():
     return os.environ.get("GIP_RASTER_EXACT_LISTS", "0") == "1"
 
 
+def _sh_scalar():
+    """GIP_RASTER_SH_SCALAR=1: the SH colour contraction always runs as eval_sh's scalar chain (bit-exact against the oracle's colours).
+    Default: launch sets of >= 2 views at sh_degree >= 1 contract on the matrix cores (csrc/sh_mfma.hip); colours agree to a few ulp."""
+    return os.environ.get("GIP_RASTER_SH_SCALAR", "0") == "1"
+
+
 def _strict():
     return os.environ.get("GIP_RASTER_SYNC", "0") == "1"
 
@@ -122,6 +128,7 @@ def _make_config(P, V, H, W, sh_degree, M, scale_modifier, tanfovx, tanfovy, cap
     cfg.capacity = int(capacity)
     cfg.exact_lists = 1 if _exact_lists() else 0
     cfg.forward_only = 1 if forward_only else 0
+    cfg.sh_scalar = 1 if _sh_scalar() else 0
     return cfg
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GIP_ABI_VERSION 3
+#define GIP_ABI_VERSION 4
 #define GIP_TILE 16            /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16 in the reference's rasterizer) */
 #define GIP_MAX_VIEWS 16       /* views per call */
 #define GIP_RECORD_BYTES 64    /* per-(view, Gaussian) projected record kept for backward */
@@ -84,6 +84,11 @@ typedef struct GipRasterConfig {
                              kernel then skips the per-segment blend-state checkpoints and the n_contrib / final_T images
                              (~100 MB of writes per 4 x 1024^2 launch); outputs are bit-identical, and gip_raster_backward on
                              such a state returns GIP_ERR_BAD_ARGUMENT.  (This field was `reserved`; the layout is unchanged.) */
+  int32_t sh_scalar;      /* ABI 4.  0 (default): with `shs`, sh_degree >= 1 and V >= 2 the SH colour contraction and its backward run
+                             on the matrix cores, batched over the views of the launch set (csrc/sh_mfma.hip: v_mfma_f32_4x4x1, one
+                             Gaussian's [4 views x K] . [K x 3] product per 4 x 4 block); colours then agree with the scalar sum
+                             to a few ulp — no integer buffer depends on them.  1: always the scalar chain of eval_sh
+                             (sh_utils.py:57-112), bit-exact against the oracle's colours.  V = 1 and degree 0 are always scalar. */
 } GipRasterConfig;
 
 /* Device inputs.  Exactly one of (shs, colors_precomp) and one of (scales+rotations, cov3D_precomp)
@@ -175,6 +180,8 @@ typedef struct GipRasterStateLayout {
   size_t ckpt_start;   /* [V*T+1] u32: exclusive scan of per-tile checkpoint counts (segments - 1) */
   size_t seg_tile;     /* [capacity/GIP_SEGMENT + V*T] u32: tile of each segment */
   size_t checkpoints;  /* [capacity/GIP_SEGMENT][GIP_CKPT_FLOATS][256] f32: per-pixel blend state at segment starts */
+  size_t sh_colors;    /* ABI 4: [V,P,4] f32, present (non-zero size) only on the matrix-core SH path: forward = colours before the
+                          clamp, backward = dL/dcolour after it (csrc/sh_mfma.hip) */
   size_t total;        /* total bytes */
   uint32_t tiles_x, tiles_y, num_blocks, reserved;
 } GipRasterStateLayout;

@@ -258,7 +258,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert set(decl) >= {"gip_raster_forward", "gip_raster_backward", "gip_raster_state_bytes"}
     for sym in set(decl):
         assert hasattr(lib, sym), sym
-    assert lib.gip_abi_version() == 3
+    assert lib.gip_abi_version() == 4
     cfg = _lib.GipRasterConfig()
     cfg.P, cfg.V, cfg.H, cfg.W, cfg.sh_degree, cfg.sh_coeffs, cfg.capacity = 1000, 2, 64, 48, 0, 1, 1 << 16
     import ctypes

@@ -310,8 +310,14 @@ def test_backward_is_bitwise_reproducible(oracle):
     assert torch.equal(m_a.grad, m_b.grad)
 
 
-def test_multiview_equals_single_views(oracle):
+@pytest.mark.parametrize("sh_path", ["scalar", "matrix cores"])
+def test_multiview_equals_single_views(oracle, monkeypatch, sh_path):
+    """One launch set of four views against four single-view calls.  With the scalar SH chain (GIP_RASTER_SH_SCALAR=1) the images
+    are bit-identical; by default the launch set contracts its SH colours on the matrix cores (csrc/sh_mfma.hip) while a single
+    view has nothing to batch and stays scalar: colours then differ by rounding (a few ulp), images by < 1e-5."""
     from gaussianip_amd import GaussianRasterizer, rasterize_views
+    monkeypatch.setenv("GIP_RASTER_SH_SCALAR", "1" if sh_path == "scalar" else "0")
+    same = torch.equal if sh_path == "scalar" else (lambda a, b: bool((a - b).abs().max() < 1e-5))
     P, H, W = 4000, 96, 128
     sc = scenes.make_scene("stress", P, seed=5, sh_degree=1)
     cams = scenes.train_cameras(4, 9, H, W)
@@ -333,11 +339,14 @@ def test_multiview_equals_single_views(oracle):
         m = torch.zeros(P, 3, device="cuda", requires_grad=True)
         c1, r1, d1, a1 = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m, opacities=t["opacities"], shs=t["shs"],
                                                scales=t["scales"], rotations=t["rotations"])
-        assert torch.equal(c1, color[i]) and torch.equal(d1, depth[i]) and torch.equal(a1, alpha[i])
+        assert same(c1, color[i]) and torch.equal(d1, depth[i]) and torch.equal(a1, alpha[i])
         assert torch.equal(r1, radii[i])
         ((c1 * gC[i]).sum() + (d1 * gD[i]).sum()).backward()
         singles2d.append(m.grad)
-    assert torch.equal(torch.stack(singles2d), m2g)
+    if sh_path == "scalar":
+        assert torch.equal(torch.stack(singles2d), m2g)
+    else:
+        assert float((torch.stack(singles2d) - m2g).abs().max() / m2g.abs().max()) < 1e-5
     for k in t:
         ref = t[k].grad
         scale = ref.abs().max() + 1e-20

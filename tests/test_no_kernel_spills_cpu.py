@@ -23,7 +23,7 @@ ALLOWED = {
 }
 # source -> extra flags (the Makefile's EXACT / FAST / NOSLP_* / NNFLAGS_* lines)
 SOURCES = {
-    "preprocess.hip": ["-ffp-contract=off"], "binning.hip": ["-ffp-contract=off"],
+    "preprocess.hip": ["-ffp-contract=off"], "binning.hip": ["-ffp-contract=off"], "sh_mfma.hip": ["-ffp-contract=off"],
     "render_forward.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"], "render_backward.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"],
     "gather_backward.hip": ["-ffp-contract=fast"], "conv3x3.hip": ["-ffp-contract=fast"], "groupnorm.hip": ["-ffp-contract=fast"],
     "attention.hip": ["-ffp-contract=fast"], "conv_small.hip": ["-ffp-contract=fast"], "winograd.hip": ["-ffp-contract=fast"],
