@@ -295,6 +295,7 @@ def main():
     ap.add_argument("--no-proxy", action="store_true", help="skip the 1-GPU proxy of one configs[3] rank's shard")
     ap.add_argument("--no-trained", action="store_true", help="skip the secondary raster measurement on a trained-looking state")
     ap.add_argument("--no-config4", action="store_true", help="skip the 1M-Gaussian per-stage roofline object (BASELINE configs[4])")
+    ap.add_argument("--no-refine", action="store_true", help="skip configs[4]'s refine-pass / stage-3 measurement (config4.refine, config4.stage3)")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("GIP_BENCH_LAUNCH_TIMEOUT", "3600")),
                     help="--gpus N launcher: seconds after which still-running ranks are stopped and the run fails (0 = never)")
     args = ap.parse_args()
@@ -473,7 +474,11 @@ def main():
             step_t()
         torch.cuda.synchronize()
         dtt = (time.perf_counter() - t0) / args.steps
+        # its own per-stage table (hipEvent pairs, like roofline.stage_ms_instrumented for the init state)
+        stages_t, nr_t = R.profile_stages(tt_["means3D"].detach(), tt_["opacities"].detach(), sts, gC[:Vl], gD[:Vl], None, shs=tt_["shs"].detach(),
+                                          scales=tt_["scales"].detach(), rotations=tt_["rotations"].detach(), iters=5)
         trained = {"ms_per_step": round(dtt * 1e3, 4), "mpix_per_s": round(Vl * H * W / dtt / 1e6, 1),
+                   "num_rendered_per_view": int(nr_t / Vl), "stage_ms_instrumented": {k: round(v, 4) for k, v in stages_t.items()},
                    "state": "opacity 0.6, scales x U(1,3) per axis, random rotations / colours (tests/scenes.trained_look)"}
         del tt_, pl_
 
@@ -537,8 +542,14 @@ def main():
                 ahds["layout_2_views_x_%d_seeds" % (world // 2)] = dict(alt, views_per_s=round(alt["value"] * 4, 2),
                                                                        note="ViewSharding(group_size=2): value = optimizer steps/s summed over the seed groups")
             if world == 1 and not args.no_trained:
-                tr = bench_ahds.measure(steps=max(args.ahds_steps // 2, 4), warmup=3, gaussians=P, device=dev, trained=True, pieces=False)
+                # same number of timed steps and the same warm-up as the init-state measurement above (round 5 timed 5 steps after 3:
+                # the first steps of a new Gaussian state still size the rasterizer's capacity and settle the GradScaler), then the
+                # init state ONCE MORE behind it, so that a drift of the box (clocks under sustained load) shows up as such and is not
+                # read as a property of the trained state
+                tr = bench_ahds.measure(steps=args.ahds_steps, warmup=4, gaussians=P, device=dev, trained=True, pieces=False)
+                again = bench_ahds.measure(steps=args.ahds_steps, warmup=4, gaussians=P, device=dev, pieces=False)
                 ahds["trained_state"] = {"value": tr["value"], "ms_per_step": tr["ms_per_step"],
+                                         "init_state_remeasured_after_it_ms_per_step": again["ms_per_step"],
                                          "state": "opacity 0.6, scales x U(1,3) per axis, random rotations / colours (tests/scenes.trained_look)"}
             if world == 1 and not args.no_proxy:
                 # 1-GPU proxy of ONE rank of BASELINE.json configs[3] (no 8-GPU node here): the shard of a rank in a 4-rank
@@ -559,6 +570,17 @@ def main():
                 ahds["config3_proxy"] = prox
         except Exception as e:  # the raster line above is the contract metric: never lose it to the secondary measurement
             ahds = dict(ahds or {}, error="%s: %s" % (type(e).__name__, str(e)[:300]))
+        # ---- BASELINE configs[4], the other half: the VCR refine pass (32 views x 8 DDIM steps at 1024^2; a bounded sample of 12 views)
+        # and the stage-3 reconstruction step (refine.py:115-239, GaussianIP.py:424-436).  LAST: the refine pass changes the
+        # IP-Adapter scale, which invalidates the captured graphs of the AHDS measurements above
+        if world == 1 and isinstance(config4, dict) and not args.no_refine:
+            try:
+                import bench_refine
+                import bench_stage3
+                config4["refine"] = bench_refine.measure(bench_ahds.cached_guidance())
+                config4["stage3"] = bench_stage3.measure()
+            except Exception as e:  # noqa: BLE001
+                config4["refine_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
     out = None
     if rank == 0:
         # ---- roofline: live per-kernel durations (hipEvents on the launch stream) ----

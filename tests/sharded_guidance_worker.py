@@ -20,6 +20,7 @@ def main():
     rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     P = int(sys.argv[5]) if len(sys.argv) > 5 else 100000
     H = W = int(sys.argv[6]) if len(sys.argv) > 6 else 1024
+    strong = len(sys.argv) > 7 and sys.argv[7] == "strong"       # tests/conditioning.py: a conditioning that matters (meaningful fp16 floor)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -49,6 +50,9 @@ def main():
     pp = PromptProcessor("a person wearing a coat", encode, negative_prompt="blurry")
     guidance.prepare_for_sds(pp.prompt, pp.negative_prompt, pp.null_prompt)
     prompt_utils = pp()
+    if strong:
+        from conditioning import strengthen_conditioning
+        strengthen_conditioning(guidance)
 
     def guided(step, rgb, control, pu, use_pose, all_vis_all, view_id=None, **batch):
         gens = [torch.Generator(device=dev).manual_seed(100000 + 1000 * int(step) + int(v)) for v in view_id.tolist()]

@@ -34,18 +34,25 @@ def test_view_sharded_step_equals_the_single_process_step(tmp_path):
         assert r["state_mismatch_frac"] < 1e-3 and r["state_max_over_lr"] <= 4.5 and r["ranks_agree"], r
 
 
-def test_config3_real_guidance_sharded_step_at_100k_1024(tmp_path):
+@pytest.mark.parametrize("conditioning", ["as initialised", "strong"])
+def test_config3_real_guidance_sharded_step_at_100k_1024(tmp_path, conditioning):
     """BASELINE.json configs[3] exercised for real on one GPU: 100k Gaussians, 1024^2, the REAL
     StableDiffusionGuidance (VAE + ControlNet + U-Net ANPG), 2 gloo ranks x 2 views against the single-process 4-view step.
     Integers bitwise; gradients / statistics to fp16-network tolerance (the sharded denoise runs at batch 6 instead of 12 and the
     VAE at batch 2 instead of 4: other tile counts, split-K factors and Winograd choices, i.e. other fp16 roundings — the
-    exchange itself is exact, tests/test_gpu_sharded_step.py::test_view_sharded_step_equals_the_single_process_step)."""
+    exchange itself is exact, tests/test_gpu_sharded_step.py::test_view_sharded_step_equals_the_single_process_step).
+    "strong" (round 6): the same step on networks whose conditioning matters (tests/conditioning.py) — the fp16 floor of the ANPG
+    gradient is then a few 1e-3 instead of 3.4 %, and the sharded step must match the ONE-CALL 4-view step to 1 % in every parameter
+    gradient (measured 0.40 %, profiles/r06_config3_sharded_guidance_strong.json; 5.7 % as initialised): a bar that a 5 % sharding
+    bug cannot pass, which the 10 % bar of the pathological case could."""
+    strong = conditioning == "strong"
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = str(s.getsockname()[1])
     s.close()
     outs = [str(tmp_path / ("g%d.json" % r)) for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_guidance_worker.py"), str(r), "2", port, outs[r]],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_guidance_worker.py"), str(r), "2", port, outs[r]] +
+                              (["100000", "1024", "strong"] if strong else []),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     logs = [p.communicate(timeout=1500)[0].decode(errors="replace") for p in procs]
     for p, log in zip(procs, logs):
@@ -53,7 +60,7 @@ def test_config3_real_guidance_sharded_step_at_100k_1024(tmp_path):
     report = [json.load(open(path)) for path in outs]
     d = os.path.join(os.path.dirname(HERE), "gpurun_out")
     if os.path.isdir(d):                      # written BEFORE the assertions: a failing run leaves its numbers behind
-        json.dump(report, open(os.path.join(d, "config3_sharded_guidance.json"), "w"), indent=1)
+        json.dump(report, open(os.path.join(d, "config3_sharded_guidance%s.json" % ("_strong" if strong else "")), "w"), indent=1)
     for r in report:
         print(json.dumps(r))
         assert r["views_ref"] == 4 and r["views_local"] == 2
@@ -77,7 +84,10 @@ def test_config3_real_guidance_sharded_step_at_100k_1024(tmp_path):
         assert abs(r["loss_sharded_sum"] - r["loss_one_call"]) <= 5e-3 * abs(r["loss_one_call"]), r
         for name, g_ in r["grad_vs_one_call"].items():
             if g_["ref_norm"] > 1e-6 * big:
-                assert g_["rel_l2"] < 0.10 and g_["cosine"] > 0.995, (name, g_)
+                if strong:
+                    assert g_["rel_l2"] < 0.01 and g_["cosine"] > 0.9999, (name, g_)       # measured (round 6): 0.39-0.41 %, cosine 0.999992
+                else:
+                    assert g_["rel_l2"] < 0.10 and g_["cosine"] > 0.995, (name, g_)
         assert r["accum_vs_one_call"]["cosine"] > 0.99, r
 
 

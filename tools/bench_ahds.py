@@ -18,6 +18,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+_guidance_cache = {}     # (channels_last, device) -> StableDiffusionGuidance: the measurements of one process share ONE set of networks
+                         # (deterministic seeds: a second instance would hold identical weights; building it costs ~24 s)
+
+
+def cached_guidance():
+    """The guidance object the measurements of this process have built (None before the first one): bench.py hands it to the
+    configs[4] refine measurement."""
+    return next(iter(_guidance_cache.values()), None)
+
+
 def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=False, rank=0, world=1, device=None, amp=True,
             fused_adam=True, layout="views", trained=False, proxy_group=0, pieces=True, group_size=None):
     """Runs the step `warmup + steps` times and returns the result dict.  The timed step is the reference's
@@ -88,7 +98,10 @@ def measure(steps=20, warmup=5, gaussians=100000, channels_last=True, flops=Fals
     g = torch.Generator(device=dev).manual_seed(1)
     tokens = (torch.randn(1, 4, 768, device=dev, generator=g) * 0.1, torch.zeros(1, 4, 768, device=dev),
               torch.randn(1, 4, 768, device=dev, generator=g) * 0.1)
-    guidance = StableDiffusionGuidance(GuidanceConfig(channels_last=channels_last), image_embeds_provider=lambda gd: tokens)
+    gkey = (bool(channels_last), str(dev))
+    guidance = _guidance_cache.get(gkey)
+    if guidance is None:
+        guidance = _guidance_cache[gkey] = StableDiffusionGuidance(GuidanceConfig(channels_last=channels_last), image_embeds_provider=lambda gd: tokens)
     pp = PromptProcessor("a person wearing a coat", lambda texts: torch.randn(len(texts), 77, 768, device=dev, generator=g).half() * 0.1,
                          negative_prompt="blurry")
     guidance.prepare_for_sds(pp.prompt, pp.negative_prompt, pp.null_prompt)
