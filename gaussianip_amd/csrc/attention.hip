@@ -605,7 +605,7 @@ attn_fwd_q2_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ 
 template <int D, int NW>
 static void launch_attn_q2(hipStream_t s, const void* q, const void* k, const void* v, void* o, int BH, int Nq, int Nkv, int H, float c,
                            int ld_kv, int ld_q) {
-  static const int xcd = [] { const char* e = getenv("GIP_ATTN_XCD"); return e && *e ? atoi(e) : 1; }();
+  const int xcd = 1;      // every (batch, head)'s query blocks on one XCD (see launch_attn_wide)
   const dim3 grid((Nq + 64 * NW - 1) / (64 * NW), BH);
   hipLaunchKernelGGL((attn_fwd_q2_kernel<D, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                      (_Float16*)o, Nq, Nkv, H, c, ld_kv, ld_q, xcd);
@@ -631,8 +631,8 @@ static void launch_attn_wide(hipStream_t s, const void* q, const void* k, const 
                              int ld_kv, int ld_q) {
   const dim3 grid((Nq + 32 * NW - 1) / (32 * NW), BH);
   // every (batch, head)'s query blocks on ONE XCD (its keys / values fill one L2 instead of eight): 0.421 -> 0.4105 ms at batch 12,
-  // 0.140 -> 0.137 at batch 4, same box, two alternating runs; GIP_ATTN_XCD=0 switches it off
-  static const int xcd = [] { const char* e = getenv("GIP_ATTN_XCD"); return e && *e ? atoi(e) : 1; }();
+  // 0.140 -> 0.137 at batch 4, same box, two alternating runs
+  const int xcd = 1;
   hipLaunchKernelGGL((attn_fwd_kernel<D, 0, NW>), grid, dim3(64 * NW), 0, s, (const _Float16*)q, (const _Float16*)k,
                      (const _Float16*)v, (_Float16*)o, Nq, Nkv, H, c, (const _Float16*)nullptr, (const _Float16*)nullptr, 0, 0.f, ld_kv,
                      ld_kv, ld_q, xcd);

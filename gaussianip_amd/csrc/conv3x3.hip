@@ -1047,8 +1047,9 @@ conv_splitk_reduce_stats_kernel(const float* __restrict__ partial, const _Float1
 // Debug / A-B knobs (tools/exp_conv*.py set them through ctypes; -1 = the shape heuristic below decides)
 extern "C" { int gip_dbg_conv_order = -1; int gip_dbg_conv_epilogue = -1; int gip_dbg_conv_ksplit = 0; int gip_dbg_conv_ablate = 0;
              int gip_dbg_conv_big = -1; int gip_dbg_linear_narrow = -1; }
-// same-box A/B of a whole training step (tools/ab_ahds.sh): GIP_CONV_EPILOGUE=0 restores the per-lane 8-byte epilogue,
-// GIP_CONV_KSPLIT_R2=1 the round-2 split-K factor; read once
+// same-box A/B of a whole training step (tools/ab_ahds.sh); read once.  (Rounds 3-5 also had GIP_CONV_EPILOGUE / _RES_EARLY / _BIG /
+// _KSPLIT_R2: the per-lane 8-byte epilogue, residual rows requested late, no 256-row tile, the round-2 split-K factor — each measured
+// slower in DESIGN §4c and retired in round 6; the gip_dbg_* knobs above still reach them from tools/exp_conv*.py.)
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -1068,8 +1069,7 @@ static int launch_big(const void* x, const void* w, const void* bias, const void
       return 3;
     attr_set = true;
   }
-  static const int env_res = env_int("GIP_CONV_RES_EARLY", 1);
-  geom |= env_res << 29;
+  geom |= 1 << 29;                                  // residual rows requested before the epilogue staging
   hipLaunchKernelGGL((conv_big_kernel<BN, TAPS>), dim3(m_tiles * n_tiles), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin, Cout,
                      m_tiles, n_tiles, Hin, Win, geom, chan_stats, gnb);
@@ -1079,8 +1079,7 @@ static int launch_big(const void* x, const void* w, const void* bias, const void
 // The 256-row tile is used where its tiles still fill the chip at ONE workgroup per CU (>= 7/8 of a round of 256) and
 // Cout is a multiple of its channel width; everything else stays on the 128-row kernel (two workgroups per CU, split-K).
 static int big_tile_width(long long M, int Cout) {
-  static const int env_big = env_int("GIP_CONV_BIG", 1);
-  int use = env_big;
+  int use = 1;
   if (gip_dbg_conv_big >= 0) use = gip_dbg_conv_big;
   if (!use || (Cout & 127)) return 0;
   const long long m_tiles = (M + CVB_BM - 1) / CVB_BM;
@@ -1113,8 +1112,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   if constexpr (BN == 128 && TAPS == 9 && !GEGLU) {
     // halo-resident pixel tile (see conv3x3_kernel): Cin = 128, plain 3x3 / stride 1 / pad 1, whole-K tiles that fill the chip
     static const int env_halo = env_int("GIP_CONV_HALO", 1);
-    static const int env_epi_h = env_int("GIP_CONV_EPILOGUE", 1);
-    if (env_halo && env_epi_h && gip_dbg_conv_epilogue != 0 && gip_dbg_conv_ksplit <= 0 && Cin == 128 && (geom & 0xffffff) == (1 | (1 << 8) | (1 << 16)) &&
+    if (env_halo && gip_dbg_conv_epilogue != 0 && gip_dbg_conv_ksplit <= 0 && Cin == 128 && (geom & 0xffffff) == (1 | (1 << 8) | (1 << 16)) &&
         tapsel == 0x1ff && !(H & 7) && !(W & 15) && Hin == H && Win == W && !(Cout & 7) && stats_rows == 128 &&
         (long long)m_tiles * n_tiles >= 256 && !(gnb.x && gnb.HW != H * W)) {
       constexpr size_t lds_h = 2 * (size_t)CVH_KC_BYTES + STAGES * (size_t)BN * 128;
@@ -1126,8 +1124,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
           return 3;
         attr_h = true;
       }
-      static const int env_res_h = env_int("GIP_CONV_RES_EARLY", 1);
-      const int geom_h = geom | (1 << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (env_res_h << 29) | ((gn_in ? 1 : 0) << 30);
+      const int geom_h = geom | (1 << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (1 << 29) | ((gn_in ? 1 : 0) << 30);
       hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU, true>), dim3(m_tiles * n_tiles), dim3(CV_THREADS), lds_h, s,
                          (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
                          N, H, W, Cin, Cout, m_tiles, n_tiles, 1, (float*)nullptr, Hin, Win, geom_h, chan_stats, gnb, tapsel);
@@ -1151,8 +1148,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   int ksplit = 1;
   const int tiles = m_tiles * n_tiles, KT = (TAPS == 9 ? __builtin_popcount(tapsel & 0x1ff) : TAPS) * (Cin / CV_BK);
   if (!GEGLU && workspace && tiles < 256 && !((tapsel >> 11) & 1)) {
-    static const int r2 = env_int("GIP_CONV_KSPLIT_R2", 0);
-    ksplit = r2 ? (512 + tiles - 1) / tiles : 512 / tiles;
+    ksplit = 512 / tiles;
     if (ksplit > KT / 8) ksplit = KT / 8;
     if (ksplit > 16) ksplit = 16;
     while (ksplit > 1 && (size_t)ksplit * M * Cout * sizeof(float) > workspace_bytes) ksplit--;
@@ -1166,8 +1162,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   // of weights: 55 -> 50 us); measured slower everywhere else, also at 16x16 (tools/exp_conv5.py)
   int nmajor = m_tiles <= 8 && n_tiles > 1 ? 1 : 0;
   if (gip_dbg_conv_order >= 0) nmajor = gip_dbg_conv_order;
-  static const int env_epi = env_int("GIP_CONV_EPILOGUE", 1);
-  int lds_epi = env_epi;
+  int lds_epi = 1;
   if (gip_dbg_conv_epilogue >= 0) lds_epi = gip_dbg_conv_epilogue;
   const bool stats_in_reduce = chan_stats && ksplit > 1 && !gnb.x;      // split-K: the reduce kernel makes the statistics
   if (chan_stats && !stats_in_reduce) {            // statistics come out of the LDS epilogue of whole-K tiles (128-row blocks)
@@ -1179,8 +1174,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
     if (TAPS != 1 || ksplit != 1 || (!GEGLU && (Cout & 7)) || (gnb.rows_out && (GEGLU || chan_stats))) return 1;
     lds_epi = 1;
   }
-  static const int env_res = env_int("GIP_CONV_RES_EARLY", 1);
-  geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (env_res << 29);   // bits 26-28: timing ablations (WRONG results)
+  geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (1 << 29);   // bits 26-28: timing ablations (WRONG results)
   const int classes = (tapsel >> 12) & 1 ? 4 : 1;
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit * classes, batch), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,

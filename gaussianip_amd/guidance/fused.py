@@ -155,9 +155,8 @@ def fallback(site, t, library=False):
 # scalar kernel arguments (Attention.ip_scale) and the A/B environment switches are baked in.  Everything that changes one
 # of those bumps this counter; it is part of the graph keys, so a stale graph is never replayed.
 _weights_epoch = 0
-_ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_WINOGRAD_GEMM", "GIP_GN_STATS", "GIP_CAT_SKIP", "GIP_FUSE_QKV", "GIP_CONV_FEWCH",
-              "GIP_CONV_NARROW", "GIP_UPCONV", "GIP_UPCONV_MIN_TILES", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE", "GIP_CONV_S2_DGRAD",
-              "GIP_CONV_C3", "GIP_OWN_GEMM", "GIP_GEGLU_MIN_ROWS", "GIP_CONV_HALO", "GIP_CONV_GNIN", "GIP_WINOGRAD_GN", "GIP_TUNABLEOP", "GIP_MIN_CONV_TILES", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
+_ENV_KNOBS = ("GIP_WINOGRAD", "GIP_WINOGRAD_SHAPES", "GIP_WINOGRAD_GEMM", "GIP_GN_STATS", "GIP_FUSE_QKV", "GIP_GN_BWD_SUMS", "GIP_RESBLOCK_NODE",
+              "GIP_OWN_GEMM", "GIP_CONV_HALO", "GIP_CONV_GNIN", "GIP_WINOGRAD_GN", "GIP_TUNABLEOP", "GIP_LN_FOLD", "GIP_CONV_S2_STATS")
 
 
 def bump_weights_epoch():
@@ -256,8 +255,7 @@ def cat_skip(h, skip, residual=None):
     separate add rounds it."""
     if (fusable(h) and fusable(skip) and (residual is None or (fusable(residual) and residual.shape == skip.shape)) and
             h.shape[0] == skip.shape[0] and h.shape[2:] == skip.shape[2:] and h.shape[1] % 64 == 0 and skip.shape[1] % 64 == 0 and
-            not (torch.is_grad_enabled() and (h.requires_grad or skip.requires_grad or (residual is not None and residual.requires_grad))) and
-            os.environ.get("GIP_CAT_SKIP", "1") != "0"):
+            not (torch.is_grad_enabled() and (h.requires_grad or skip.requires_grad or (residual is not None and residual.requires_grad)))):
         N, Ca, H, W = h.shape
         Cb = skip.shape[1]
         out = torch.empty((N, Ca + Cb, H, W), dtype=h.dtype, device=h.device, memory_format=torch.channels_last)
@@ -317,7 +315,8 @@ _GN_SUMS_MIN_TILES = 256    # below it the data gradient runs split-K, whose red
 # step was NOT reproducible run to run (tools/diag/denoise_bisect.py: first differing module down_sample.2 at batch 6,
 # down_sample.1 at batch 3; 2.4e-3 of the output) and slow.  The MFMA kernel with split-K 16 takes them all (bitwise
 # reproducible: fixed summation order); only single-tile problems stay on the library.
-_MIN_CONV_TILES = int(os.environ.get("GIP_MIN_CONV_TILES", "2"))
+_MIN_CONV_TILES = 2
+_UPCONV_MIN_TILES = 256      # smallest grid (128-row tiles over the four parity classes) upsample + convolution takes as one launch
 _SPLITK_WS_BYTES = 64 << 20
 _WT_CACHE_MAX = 512
 
@@ -1118,9 +1117,8 @@ def upsample2x_conv3x3(x, w, bias):
     by fp16 weight rounding (~2^-11 relative per weight), inside the tolerance of the fp16 convolution itself."""
     if (fusable(x) and x.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and w.dtype == torch.float16 and not w.requires_grad and
             (bias is None or not bias.requires_grad) and not (torch.is_grad_enabled() and x.requires_grad) and
-            4 * _conv_tiles(x.shape[0], x.shape[2], x.shape[3], w.shape[0]) >= int(os.environ.get("GIP_UPCONV_MIN_TILES", "256")) and
-            x.shape[0] * 4 * x.shape[2] * x.shape[3] * max(x.shape[1], w.shape[0]) * 2 < (1 << 31) and
-            os.environ.get("GIP_UPCONV", "1") != "0"):
+            4 * _conv_tiles(x.shape[0], x.shape[2], x.shape[3], w.shape[0]) >= _UPCONV_MIN_TILES and
+            x.shape[0] * 4 * x.shape[2] * x.shape[3] * max(x.shape[1], w.shape[0]) * 2 < (1 << 31)):
         N, C, H, W = x.shape
         out = torch.empty((N, w.shape[0], 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         rc = _lib.nn_lib().gip_upsample2x_conv3x3_nhwc_f16(_p(x), _p(_wt_cache.get("up4", w, _upsample_conv_weight)),
@@ -1164,8 +1162,7 @@ class _DownsampleAsym(torch.autograd.Function):
     def backward(ctx, dy):
         (w,) = ctx.saved_tensors
         N, C, H, W = ctx.x_shape
-        if (w.shape[0] % 64 == 0 and C % 8 == 0 and N * H * W * max(C, w.shape[0]) * 2 < (1 << 31) and
-                os.environ.get("GIP_CONV_S2_DGRAD", "1") != "0"):
+        if (w.shape[0] % 64 == 0 and C % 8 == 0 and N * H * W * max(C, w.shape[0]) * 2 < (1 << 31)):
             # four parity classes of dx, each a small convolution over dy's grid (4 / 2 / 2 / 1 taps): minimal FLOPs
             dy = dy.contiguous(memory_format=torch.channels_last)
             dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
@@ -1200,7 +1197,7 @@ def _c3_kernels_apply(x, w):
     """conv_in of the VAE encoder on its dedicated kernels (csrc/conv_small.hip): 3 input channels, 128 output channels, NHWC."""
     return (x.shape[1] == 3 and w.shape[0] == 128 and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0 and
             x.is_contiguous(memory_format=torch.channels_last) and w.is_contiguous(memory_format=torch.channels_last) and
-            x.numel() // 3 * 128 * 2 < (1 << 31) and os.environ.get("GIP_CONV_C3", "1") != "0")
+            x.numel() // 3 * 128 * 2 < (1 << 31))
 
 
 class _ConvFewInputChannels(torch.autograd.Function):
@@ -1271,7 +1268,7 @@ def conv3x3_fewch(x, w, bias, stride=1, act=False):
             w.dtype == torch.float16 and tuple(w.shape[1:]) == (cin, 3, 3) and
             x.is_contiguous(memory_format=torch.channels_last) and w.is_contiguous(memory_format=torch.channels_last) and
             x.shape[2] % stride == 0 and x.shape[3] % stride == 0 and Wo % 16 == 0 and Ho % _FEWCH_SHAPES[(cin, cout, stride)] == 0 and
-            not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and os.environ.get("GIP_CONV_FEWCH", "1") != "0"):
+            not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))):
         out = torch.empty((x.shape[0], cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         rc = _lib.nn_lib().gip_conv3x3_fewch_nhwc_f16(_p(x), _p(w), ctypes.c_void_p(None) if bias is None else _p(bias), _p(out),
                                                       x.shape[0], x.shape[2], x.shape[3], cin, cout, stride, int(bool(act)),
@@ -1295,7 +1292,7 @@ def conv3x3_latent_in(x, w, bias):
     N, C, H, W = x.shape
     if (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and C == 4 and tuple(w.shape) == (320, 4, 3, 3) and w.dtype == torch.float16 and
             x.is_contiguous(memory_format=torch.channels_last) and H % 8 == 0 and W % 16 == 0 and
-            not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and os.environ.get("GIP_CONV_FEWCH", "1") != "0"):
+            not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))):
         key = (N, H, W, x.device)
         z = _PAD_ZEROS.get(key)
         if z is None:
@@ -1338,7 +1335,7 @@ def _narrow_out_applies(x, w):
     return (not _DISABLED and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and (cin, cout) in _NARROW_OUT_SHAPES and
             w.dtype == torch.float16 and tuple(w.shape[1:]) == (cin, 3, 3) and not w.requires_grad and
             x.is_contiguous(memory_format=torch.channels_last) and x.shape[3] % 16 == 0 and
-            x.shape[2] % _NARROW_OUT_SHAPES[(cin, cout)] == 0 and os.environ.get("GIP_CONV_NARROW", "1") != "0")
+            x.shape[2] % _NARROW_OUT_SHAPES[(cin, cout)] == 0)
 
 
 def _narrow_out_call(x, w, bias):
@@ -1372,8 +1369,7 @@ class _NarrowOutConv(torch.autograd.Function):
         (w,) = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         N, C, H, W = ctx.x_shape
-        if (tuple(w.shape[:2]), 1) == ((8, 512), 1) and H % _FEWCH_SHAPES[(8, 512, 1)] == 0 and W % 16 == 0 and dy.dtype == torch.float16 and \
-                os.environ.get("GIP_CONV_FEWCH", "1") != "0":
+        if (tuple(w.shape[:2]), 1) == ((8, 512), 1) and H % _FEWCH_SHAPES[(8, 512, 1)] == 0 and W % 16 == 0 and dy.dtype == torch.float16:
             return conv3x3_fewch(dy, _transposed_weight(w), None), None, None
         fallback("conv_out data gradient", dy, library=True)
         return torch.nn.grad.conv2d_input(ctx.x_shape, w, dy, padding=1), None, None

@@ -21,7 +21,7 @@ from .ahds import AHDSSchedule
 from .networks import IP_TOKENS, TEXT_TOKENS, ControlNet, UNet, VAEEncoder, init_for_benchmark
 
 
-_NO_SHARED_PREFIX = __import__("os").environ.get("GIP_SHARE_PREFIX", "1") == "0"      # A/B switch (tools/)
+_NO_SHARED_PREFIX = False      # True: the layers in front of the first cross-attention run on the full ANPG / CFG batch (measured: +1.25 ms, §4b)
 _TWO_STREAMS = __import__("os").environ.get("GIP_GUIDANCE_STREAMS", "2") != "1"    # A/B switch: ControlNet beside the U-Net encoder
 # The frozen, fixed-shape networks replay from HIP graphs (round 3 default): the Python host needs ~28 us per launch, which
 # made a ONE-view shard of configs[3] (1305 launches, 20 ms of GPU work) launch-bound at 30 ms.  GIP_GRAPH_DENOISE=0 /

@@ -29,8 +29,8 @@ from . import fused
 from .fused import GroupNormAct, add_bias_residual, conv1x1, conv3x3, fusable, geglu
 
 TEXT_TOKENS = 77
-# measured: the fused GEGLU projection wins at the 64x64 level, hipBLASLt + geglu below (GIP_GEGLU_MIN_ROWS: A/B knob)
-_GEGLU_FUSE_MIN_ROWS = int(__import__("os").environ.get("GIP_GEGLU_MIN_ROWS", "32768"))
+# measured: the fused GEGLU projection wins at the 64x64 level, hipBLASLt + geglu below (12288 rows = the 32x32 level: neutral)
+_GEGLU_FUSE_MIN_ROWS = 32768
 IP_TOKENS = 4
 
 

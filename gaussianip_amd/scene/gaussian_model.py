@@ -31,7 +31,7 @@ def _covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
     return strip_symmetric(L @ L.transpose(1, 2))
 
 
-_FUSED_ACT = os.environ.get("GIP_FUSED_ACTIVATIONS", "1") != "0"     # 0: the three getters' op chains (same-box A/B)
+_FUSED_ACT = True     # False: the three getters' op chains (the same-box A/B of DESIGN §4d; tests flip the attribute)
 
 
 class _Activate(torch.autograd.Function):
@@ -186,7 +186,7 @@ class GaussianModel:
                "f_rest": training_args.feature_lr / 20.0, "opacity": training_args.opacity_lr,
                "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
         self.params_list = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in _GROUPS]
-        if fused and dev.type == "cuda" and os.environ.get("GIP_ADAM", "gip") == "gip":
+        if fused and dev.type == "cuda":
             from .adam import GipAdam          # the same update as torch's fused Adam, all six groups in ONE launch
             self.optimizer = GipAdam(self.params_list, lr=0.0, eps=1e-15)
         else:

@@ -20,8 +20,8 @@ import torch
 from .renderer import render_views
 from .scene.cameras import Camera
 
-_POSE_STREAM = os.environ.get("GIP_POSE_STREAM", "1") != "0"      # 0: pose maps on the main stream (same-box A/B)
-_FUSED_LOSS = os.environ.get("GIP_FUSED_LOSS", "1") != "0"        # 0: the sparsity term as the reference's op chain (same-box A/B)
+_POSE_STREAM = True      # False: pose maps on the main stream (the same-box A/B of DESIGN §4d; tests flip the attribute)
+_FUSED_LOSS = True       # False: the sparsity term as the reference's op chain
 
 
 class _SparsityTerm(torch.autograd.Function):

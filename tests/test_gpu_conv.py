@@ -368,7 +368,7 @@ def test_stride2_data_gradient_by_parity_classes(N, C, Co, H, W, monkeypatch):
 def test_upsample_then_convolution_by_parity_classes(N, C, Co, H, W, monkeypatch):
     from gaussianip_amd import _lib
     from gaussianip_amd.guidance import fused
-    monkeypatch.setenv("GIP_UPCONV_MIN_TILES", "0")
+    monkeypatch.setattr(fused, "_UPCONV_MIN_TILES", 0)
     g = torch.Generator(device="cuda").manual_seed(C + Co + H)
     cl = dict(memory_format=torch.channels_last)
     x = torch.randn(N, C, H, W, device="cuda", generator=g).half().contiguous(**cl)
