@@ -513,7 +513,9 @@ def main():
             stages_e, nr_e = R.profile_stages(t["means3D"].detach(), t["opacities"].detach(), sts, gC[:Vl], gD[:Vl], None, shs=t["shs"].detach(),
                                               scales=t["scales"].detach(), rotations=t["rotations"].detach(), iters=3)
             exact = {"ms_per_step": round(dte * 1e3, 4), "mpix_per_s": round(V * H * W / dte / 1e6, 1),
-                     "num_rendered_per_view": int(nr_e / V), "slowdown_vs_default": round(dte * 1e3 / ms_per_step, 4)}
+                     "num_rendered_per_view": int(nr_e / V), "slowdown_vs_default": round(dte * 1e3 / ms_per_step, 4),
+                     # where the 32 % more instances cost: every stage's own hipEvent time in this mode (compare roofline.stage_ms_instrumented)
+                     "stage_ms_instrumented": {k_: round(v_, 4) for k_, v_ in stages_e.items()}}
         finally:
             os.environ["GIP_RASTER_EXACT_LISTS"] = "0"
         for _ in range(3):

@@ -301,23 +301,54 @@ gn_apply_kernel(const half8* __restrict__ x, const half8* __restrict__ dy, const
 // GroupNorm statistics from the per-(128-row block, channel) sums the producing convolution / linear kernel wrote in its
 // epilogue (csrc/conv3x3.hip, chan_stats [blocks][C][2]): one workgroup per (sample, group), fixed summation order.
 // With an addend a_c (added to x on load by the apply pass): sum(x + a) = S_c + P a_c, sum((x + a)^2) = Q_c + 2 a_c S_c + P a_c^2.
-__global__ void __launch_bounds__(GN_BLOCK)
-gn_finalize_stats_kernel(const float* __restrict__ chan_stats, int blocks_per_sample, long long HW, int C, int G, float eps,
-                         const __half* __restrict__ addend, int addend_stride, float* __restrict__ mean, float* __restrict__ rstd) {
-  __shared__ float s_part[GN_BLOCK * 2];
-  __shared__ float s_ch[GN_BLOCK * 2];
-  const int n = blockIdx.y, g = blockIdx.x, cg = C / G;         // cg <= GN_BLOCK (checked on the host)
-  const int j = threadIdx.x % cg, k = threadIdx.x / cg, K = GN_BLOCK / cg;
-  float S = 0.f, Q = 0.f;
+// BLOCK = 256, or 1024 where a sample has >= 256 blocks (the VAE encoder's first level: 2048 blocks x 128 channels = 8 MB of sums per
+// launch): a thread then walks 8 instead of 32 blocks of its channel, all of its loads in flight at once (round 6: 17 -> ~5 us per
+// launch on the single-stream VAE path).  Two-step combine of the per-thread sums in LDS, fixed order.
+template <int BLOCK>
+__device__ __forceinline__ void gn_block_channel_sums(const float* __restrict__ chan_sums, int blocks_per_sample, int C, int cg, int n, int g,
+                                                      float* s_part, float* s_mid, float& S, float& Q) {
+  const int j = threadIdx.x % cg, k = threadIdx.x / cg, K = BLOCK / cg;
+  S = 0.f; Q = 0.f;
   if (k < K) {
-    const float* p = chan_stats + ((size_t)n * blocks_per_sample * C + (size_t)g * cg + j) * 2;
-    for (int b = k; b < blocks_per_sample; b += K) { S += p[(size_t)b * C * 2]; Q += p[(size_t)b * C * 2 + 1]; }
+    const float* p = chan_sums + ((size_t)n * blocks_per_sample * C + (size_t)g * cg + j) * 2;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f, s2 = 0.f, q2 = 0.f, s3 = 0.f, q3 = 0.f;
+    int b = k;
+    for (; b + 3 * K < blocks_per_sample; b += 4 * K) {           // four independent loads per trip
+      const float2 a0 = *(const float2*)(p + (size_t)b * C * 2), a1 = *(const float2*)(p + (size_t)(b + K) * C * 2);
+      const float2 a2 = *(const float2*)(p + (size_t)(b + 2 * K) * C * 2), a3 = *(const float2*)(p + (size_t)(b + 3 * K) * C * 2);
+      s0 += a0.x; q0 += a0.y; s1 += a1.x; q1 += a1.y; s2 += a2.x; q2 += a2.y; s3 += a3.x; q3 += a3.y;
+    }
+    for (; b < blocks_per_sample; b += K) { const float2 a0 = *(const float2*)(p + (size_t)b * C * 2); s0 += a0.x; q0 += a0.y; }
+    S = (s0 + s1) + (s2 + s3); Q = (q0 + q1) + (q2 + q3);
   }
   s_part[2 * threadIdx.x] = S; s_part[2 * threadIdx.x + 1] = Q;
   __syncthreads();
-  if (threadIdx.x < cg) {
-    S = 0.f; Q = 0.f;
-    for (int kk = 0; kk < K; kk++) { S += s_part[2 * (kk * cg + threadIdx.x)]; Q += s_part[2 * (kk * cg + threadIdx.x) + 1]; }
+  // step A: cg x 16 threads each add every 16th slice of their channel; step B: cg threads add those 16
+  const int S2 = K < 16 ? K : 16;
+  if ((int)threadIdx.x < cg * S2) {
+    const int jj = threadIdx.x % cg, q = threadIdx.x / cg;
+    float a = 0.f, c = 0.f;
+    for (int kk = q; kk < K; kk += S2) { a += s_part[2 * (kk * cg + jj)]; c += s_part[2 * (kk * cg + jj) + 1]; }
+    s_mid[2 * threadIdx.x] = a; s_mid[2 * threadIdx.x + 1] = c;
+  }
+  __syncthreads();
+  S = 0.f; Q = 0.f;
+  if ((int)threadIdx.x < cg) {
+    for (int q = 0; q < S2; q++) { S += s_mid[2 * (q * cg + threadIdx.x)]; Q += s_mid[2 * (q * cg + threadIdx.x) + 1]; }
+  }
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+gn_finalize_stats_kernel(const float* __restrict__ chan_stats, int blocks_per_sample, long long HW, int C, int G, float eps,
+                         const __half* __restrict__ addend, int addend_stride, float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ float s_part[BLOCK * 2];
+  __shared__ float s_mid[BLOCK * 2];                             // step A's cg x S2 <= BLOCK partial sums
+  __shared__ float s_ch[GN_BLOCK * 2];
+  const int n = blockIdx.y, g = blockIdx.x, cg = C / G;         // cg <= GN_BLOCK (checked on the host)
+  float S, Q;
+  gn_block_channel_sums<BLOCK>(chan_stats, blocks_per_sample, C, cg, n, g, s_part, s_mid, S, Q);
+  if ((int)threadIdx.x < cg) {
     if (addend) {
       const float a = __half2float(addend[(long long)n * addend_stride + g * cg + threadIdx.x]);
       Q += 2.f * a * S + (float)HW * a * a;
@@ -339,25 +370,38 @@ gn_finalize_stats_kernel(const float* __restrict__ chan_stats, int blocks_per_sa
 
 // The two reductions of the GroupNorm backward from the per-(128-row block, channel) sums that the data-gradient convolution
 // wrote in its epilogue (csrc/conv3x3.hip, GnBwdArgs): out[n][g] = (sum dxh, sum dxh xh) / (HW * C / G).  Fixed order.
-__global__ void __launch_bounds__(GN_BLOCK)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 gn_finalize_bwd_kernel(const float* __restrict__ chan_sums, int blocks_per_sample, long long HW, int C, int G, float* __restrict__ out) {
-  __shared__ float s_part[GN_BLOCK * 2];
+  __shared__ float s_part[BLOCK * 2];
+  __shared__ float s_mid[BLOCK * 2];                             // step A's cg x S2 <= BLOCK partial sums
+  __shared__ float s_ch[GN_BLOCK * 2];
   const int n = blockIdx.y, g = blockIdx.x, cg = C / G;
-  const int j = threadIdx.x % cg, k = threadIdx.x / cg, K = GN_BLOCK / cg;
-  float S = 0.f, Q = 0.f;
-  if (k < K) {
-    const float* p = chan_sums + ((size_t)n * blocks_per_sample * C + (size_t)g * cg + j) * 2;
-    for (int b = k; b < blocks_per_sample; b += K) { S += p[(size_t)b * C * 2]; Q += p[(size_t)b * C * 2 + 1]; }
-  }
-  s_part[2 * threadIdx.x] = S; s_part[2 * threadIdx.x + 1] = Q;
+  float S, Q;
+  gn_block_channel_sums<BLOCK>(chan_sums, blocks_per_sample, C, cg, n, g, s_part, s_mid, S, Q);
+  if ((int)threadIdx.x < cg) { s_ch[2 * threadIdx.x] = S; s_ch[2 * threadIdx.x + 1] = Q; }
   __syncthreads();
   if (threadIdx.x == 0) {
     S = 0.f; Q = 0.f;
-    for (int i = 0; i < K * cg; i++) { S += s_part[2 * i]; Q += s_part[2 * i + 1]; }
+    for (int c = 0; c < cg; c++) { S += s_ch[2 * c]; Q += s_ch[2 * c + 1]; }
     const float inv_m = 1.f / ((float)HW * (float)cg);
     out[((long long)n * G + g) * 2] = S * inv_m;
     out[((long long)n * G + g) * 2 + 1] = Q * inv_m;
   }
+}
+
+static void launch_finalize_stats(int G, int N, hipStream_t s, const float* chan_stats, int blocks_per_sample, long long HW, int C, float eps,
+                                  const __half* addend, int addend_stride, float* mean, float* rstd) {
+  if (blocks_per_sample >= 256)
+    hipLaunchKernelGGL((gn_finalize_stats_kernel<1024>), dim3(G, N), dim3(1024), 0, s, chan_stats, blocks_per_sample, HW, C, G, eps, addend, addend_stride, mean, rstd);
+  else
+    hipLaunchKernelGGL((gn_finalize_stats_kernel<GN_BLOCK>), dim3(G, N), dim3(GN_BLOCK), 0, s, chan_stats, blocks_per_sample, HW, C, G, eps, addend, addend_stride, mean, rstd);
+}
+static void launch_finalize_bwd(int G, int N, hipStream_t s, const float* chan_sums, int blocks_per_sample, long long HW, int C, float* out) {
+  if (blocks_per_sample >= 256)
+    hipLaunchKernelGGL((gn_finalize_bwd_kernel<1024>), dim3(G, N), dim3(1024), 0, s, chan_sums, blocks_per_sample, HW, C, G, out);
+  else
+    hipLaunchKernelGGL((gn_finalize_bwd_kernel<GN_BLOCK>), dim3(G, N), dim3(GN_BLOCK), 0, s, chan_sums, blocks_per_sample, HW, C, G, out);
 }
 
 static size_t reduce_lds_bytes(int C) {
@@ -417,8 +461,7 @@ extern "C" int gip_gn_silu_forward_stats(const void* x, const void* gamma, const
   if (!gamma || !beta || !mean || !rstd || !chan_stats || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
   hipStream_t s = (hipStream_t)stream;
   const int splits = pick_splits(N, HW, C);
-  hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(G, N), dim3(GN_BLOCK), 0, s, chan_stats, blocks_per_sample, (long long)HW, C, G,
-                     eps, (const __half*)addend, addend_stride, mean, rstd);
+  launch_finalize_stats(G, N, s, chan_stats, blocks_per_sample, (long long)HW, C, eps, (const __half*)addend, addend_stride, mean, rstd);
   hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)nullptr, (const __half*)gamma, (const __half*)beta, mean, rstd,
                      (const float*)nullptr, (half8*)y, (long long)HW, C, G, 0, splits, eps, apply_silu,
@@ -430,8 +473,7 @@ extern "C" int gip_gn_stats_from_partials(float* mean, float* rstd, int32_t N, i
                                           const void* addend, int32_t addend_stride, const float* chan_stats, int32_t blocks_per_sample,
                                           void* stream) {
   if (!mean || !rstd || !chan_stats || N < 1 || HW < 1 || C < 8 || G < 1 || C % G || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
-  hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(G, N), dim3(GN_BLOCK), 0, (hipStream_t)stream, chan_stats, blocks_per_sample, (long long)HW,
-                     C, G, eps, (const __half*)addend, addend_stride, mean, rstd);
+  launch_finalize_stats(G, N, (hipStream_t)stream, chan_stats, blocks_per_sample, (long long)HW, C, eps, (const __half*)addend, addend_stride, mean, rstd);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -466,7 +508,7 @@ extern "C" int gip_gn_silu_backward_sums(const void* x, const void* dy, const vo
   if (!dy || !gamma || !beta || !mean || !rstd || !workspace || !chan_sums || blocks_per_sample < 1 || C / G > GN_BLOCK) return 1;
   hipStream_t s = (hipStream_t)stream;
   float* sums = (float*)workspace;                       // [N, G, 2]
-  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(G, N), dim3(GN_BLOCK), 0, s, chan_sums, blocks_per_sample, (long long)HW, C, G, sums);
+  launch_finalize_bwd(G, N, s, chan_sums, blocks_per_sample, (long long)HW, C, sums);
   const int splits = pick_splits(N, HW, C);
   hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(splits, N), dim3(GN_BLOCK), (size_t)(G + GN_BLOCK) * 2 * sizeof(float), s,
                      (const half8*)x, (const half8*)dy, (const __half*)gamma, (const __half*)beta,
