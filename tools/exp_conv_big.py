@@ -17,7 +17,13 @@ BIG = ctypes.c_int.in_dll(lib._lib, "gip_dbg_conv_big")
 dev = "cuda"
 shapes = [(4, 128, 128, 512, 512), (4, 128, 256, 256, 256), (4, 256, 256, 256, 256), (4, 256, 512, 128, 128), (4, 512, 512, 128, 128),
           (12, 640, 640, 32, 32), (12, 1280, 640, 32, 32), (12, 1920, 640, 32, 32), (4, 512, 512, 64, 64), (12, 320, 640, 32, 32)]
-if len(sys.argv) > 1:
+# round 6: the 384 x 160 tile (Cout = 320 at 12 x 64^2: 256 tiles) against the 128 x 160 tile (768 workgroups)
+shapes_320 = [(12, 320, 320, 64, 64), (12, 640, 320, 64, 64), (12, 960, 320, 64, 64)]
+if len(sys.argv) > 1 and sys.argv[1] == "320":
+    shapes = shapes_320
+elif len(sys.argv) > 1 and sys.argv[1] == "512":      # the 128 x 256 tile (VAE 512 channels at 4 x 64^2): run with GIP_CONV_384=3
+    shapes = [(4, 512, 512, 64, 64)]
+elif len(sys.argv) > 1:
     shapes = shapes[:int(sys.argv[1])]
 for N, ci, co, H, W in shapes:
     g = torch.Generator(device=dev).manual_seed(ci + co + H)
