@@ -9,7 +9,10 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(8, 320, 64, 64), (8, 640, 32, 32), (8, 1280, 16, 16), (8, 1280, 8, 8), (8, 2560, 8, 8), (8, 1920, 32, 32),
-          (8, 960, 64, 64), (4, 128, 512, 512), (4, 256, 256, 256), (4, 512, 64, 64), (1, 32, 4, 4), (2, 64, 7, 5)]
+          (8, 960, 64, 64), (4, 128, 512, 512), (4, 256, 256, 256), (4, 512, 64, 64), (1, 32, 4, 4), (2, 64, 7, 5),
+          # round 6: samples of <= 256 rows take the one-launch kernel (gn_small_fwd_kernel): groups that straddle the 8-channel
+          # chunks (1920 / 32 = 60, 640 / 32 = 20), the widest concatenations, the batch of a 1-view shard
+          (12, 1920, 16, 16), (3, 2560, 16, 16), (3, 640, 16, 16), (12, 2560, 8, 8), (3, 1280, 8, 8)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
