@@ -352,9 +352,13 @@ class _WeightCache:
         self._d[key] = (w, wt)
         if capturing:
             self._pin(key)
-        if len(self._d) > _WT_CACHE_MAX:
-            for k in [k for k in self._d if k not in self._pinned][:len(self._d) - _WT_CACHE_MAX]:
-                del self._d[k]
+        # the budget counts UNPINNED entries only (round 6): with several guidance instances alive (a pytest process) the entries their
+        # graphs pin used to eat the whole budget, so that what the eager warm-up call of a NEW instance derived was evicted again
+        # before its capturing call — which then derived it inside the capture (and the Winograd transform's constants could not
+        # be uploaded there: hipErrorStreamCaptureUnsupported)
+        loose = [k for k in self._d if k not in self._pinned]
+        for k in loose[:max(0, len(loose) - _WT_CACHE_MAX)]:
+            del self._d[k]
         return wt
 
     def __len__(self):
@@ -452,9 +456,14 @@ class _Conv3x3(torch.autograd.Function):
         return dx, None, None, (dy if ctx.has_res else None), None
 
 
+_WINOGRAD_G = {}
+
+
 def _winograd_weight(w):
     """U [16][Cout][Cin] = (G g G^T)[i][j] of the 3x3 weight, fp32 arithmetic, one rounding to half."""
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32, device=w.device)
+    G = _WINOGRAD_G.get(w.device)          # per device, uploaded once: a derivation inside a graph capture must not copy from the host
+    if G is None:
+        G = _WINOGRAD_G[w.device] = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32, device=w.device)
     g = w.detach().float()                                     # [co, ci, 3, 3]
     U = torch.einsum("ik,ockl,jl->ijoc", G, g, G)             # [4, 4, co, ci]
     return U.reshape(16, w.shape[0], w.shape[1]).to(w.dtype).contiguous()

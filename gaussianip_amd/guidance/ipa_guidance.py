@@ -28,6 +28,9 @@ _TWO_STREAMS = __import__("os").environ.get("GIP_GUIDANCE_STREAMS", "2") != "1" 
 # GIP_GRAPH_VAE=0 restore the eager launches (same kernels, same values).
 _GRAPH_DENOISE = __import__("os").environ.get("GIP_GRAPH_DENOISE", "1") == "1"
 _GRAPH_VAE = __import__("os").environ.get("GIP_GRAPH_VAE", "1") == "1"
+# round 6: the latents-independent head of the denoise as its own graph on the side stream, beside the VAE encoder (launch_denoise_prologue);
+# 0 = one graph as in round 5 (temporary same-box A/B switch)
+_PROLOGUE_GRAPH = __import__("os").environ.get("GIP_DENOISE_PROLOGUE", "1") == "1"
 
 
 @dataclass
@@ -161,6 +164,13 @@ class StableDiffusionGuidance:
         self._vae_live = None
         fused._wt_cache.unpin(id(self))        # only what THIS instance's captures pinned: other instances' graphs stay valid
 
+    def __del__(self):
+        # an instance that goes away with live graphs must not leave its derived weights pinned for the rest of the process
+        try:
+            fused._wt_cache.unpin(id(self))
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
     _graph_sig = None
 
     def _check_graph_signature(self):
@@ -242,7 +252,7 @@ class StableDiffusionGuidance:
             return self.controlnet.embed_condition(cond)
 
     def forward_unet(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet=True,
-                     control_embedding=None, replicas=1, borrow_output=False, **_unused):
+                     control_embedding=None, replicas=1, borrow_output=False, prologue=None, **_unused):
         """`replicas` = r: the batch is r copies of the same (latents, t, pose map) with different prompt embeddings
         (ANPG: 3, classifier-free guidance: 2); the layers in front of the first cross-attention then run on one copy
         (networks._Encoder.encode) — identical algebra."""
@@ -251,13 +261,43 @@ class StableDiffusionGuidance:
         if (_GRAPH_DENOISE and noisy_latents.is_cuda and control_embedding is None and control_img is not None and
                 not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
             return self._forward_unet_graph(noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet, replicas,
-                                            borrow_output)
+                                            borrow_output, prologue)
         return self._forward_unet_eager(noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet,
                                         control_embedding, replicas)
 
     _graphs = None
 
-    def _forward_unet_graph(self, noisy_latents, control_img, t, ctx, use_pose, replicas, borrow_output=False):
+    def _graph_key(self, noisy_shape, noisy_dtype, control_img, t, ctx, use_pose, replicas, dev_index):
+        return (tuple(noisy_shape), noisy_dtype, tuple(control_img.shape), control_img.dtype, tuple(t.shape), t.dtype,
+                tuple(ctx.shape), ctx.dtype, bool(use_pose), int(replicas), dev_index, fused.graph_signature(),
+                bool(glue.timestep_embedding_supported(t, self.weights_dtype)))
+
+    def launch_denoise_prologue(self, noisy_shape, noisy_dtype, control_img, t, ctx, use_pose, replicas):
+        """Round 6.  What the denoise needs that does NOT depend on the latents — the ControlNet's hint stem, both networks' time
+        embeddings / ResnetBlock2D addends and prompt-token keys / values (~0.2 ms of small launches at the head of the ControlNet's
+        chain, i.e. of the critical path) — is its own captured graph, launched HERE on the side stream.  The fused plugin call
+        invokes this before it enqueues the VAE encoder, whose large kernels the small ones then run beside; forward_unet(...,
+        prologue=token) joins the side stream and replays the rest.  Returns None (nothing launched: forward_unet does everything
+        itself) until the graphs of this shape exist."""
+        if not (_GRAPH_DENOISE and use_pose and _TWO_STREAMS and control_img.is_cuda and self._graphs):
+            return None
+        self._check_graph_signature()
+        if self._graphs is None:
+            return None
+        key = self._graph_key(noisy_shape, noisy_dtype, control_img, t, ctx, use_pose, replicas, control_img.device.index)
+        ent = self._graphs.get(key)
+        if not isinstance(ent, tuple) or ent[3] is None:
+            return None
+        graph, static, out, g0 = ent[:4]
+        main, side = torch.cuda.current_stream(control_img.device), self._side_stream(control_img.device)
+        side.wait_stream(main)          # the inputs come from the main stream; the previous replay of the main graph (which reads the
+        with torch.cuda.stream(side):   # prologue's outputs) was enqueued there too
+            for d_, s_ in zip(static[1:], (control_img, t, ctx)):
+                d_.copy_(s_)
+            g0.replay()
+        return key
+
+    def _forward_unet_graph(self, noisy_latents, control_img, t, ctx, use_pose, replicas, borrow_output=False, prologue=None):
         """GIP_GRAPH_DENOISE=1: the frozen, fixed-shape denoise (~700 launches on two streams) as ONE HIP-graph launch per call.
         The GPU time is the same (measured: 24.7 vs 24.6 ms); it saves host time — 16.5 -> 9 ms of the 40 ms the host needs
         to enqueue a training step.  On the pool's hosts the step is GPU-bound either way (43.3-44.0 eager vs 43.6-43.7 ms
@@ -266,9 +306,7 @@ class StableDiffusionGuidance:
         self._check_graph_signature()
         if self._graphs is None:
             self._graphs = {}
-        key = (tuple(noisy_latents.shape), noisy_latents.dtype, tuple(control_img.shape), control_img.dtype, tuple(t.shape), t.dtype,
-               tuple(ctx.shape), ctx.dtype, bool(use_pose), int(replicas), noisy_latents.device.index, fused.graph_signature(),
-               bool(glue.timestep_embedding_supported(t, self.weights_dtype)))
+        key = self._graph_key(noisy_latents.shape, noisy_latents.dtype, control_img, t, ctx, use_pose, replicas, noisy_latents.device.index)
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs[key] = "warm"
@@ -277,20 +315,41 @@ class StableDiffusionGuidance:
             static = [torch.empty_like(a) for a in (noisy_latents, control_img, t, ctx)]
             for d_, s_ in zip(static, (noisy_latents, control_img, t, ctx)):
                 d_.copy_(s_)
+            g0, pro = None, None
+            if use_pose and _TWO_STREAMS and _PROLOGUE_GRAPH:
+                # graph 0: hint stem + both networks' latents-independent staging (launch_denoise_prologue); its outputs live in
+                # its private pool and are read in place by graph 1
+                g0 = torch.cuda.CUDAGraph()
+                with fused.capture_owner(id(self)), torch.cuda.graph(g0):
+                    pro = self._denoise_prologue_eager(static[1], static[2], static[3])
             graph = torch.cuda.CUDAGraph()
             with fused.capture_owner(id(self)), torch.cuda.graph(graph):
-                out = self._forward_unet_eager(static[0], static[1], static[2], static[3], use_pose, None, replicas)
-            ent = self._graphs[key] = (graph, static, out)
-        graph, static, out = ent
-        for d_, s_ in zip(static, (noisy_latents, control_img, t, ctx)):
-            d_.copy_(s_)
+                out = self._forward_unet_eager(static[0], static[1], static[2], static[3], use_pose, None, replicas, pro=pro)
+            ent = self._graphs[key] = (graph, static, out, g0, pro)
+        graph, static, out, g0 = ent[:4]
+        if prologue is not None and prologue == key and g0 is not None:
+            # graph 0 of THIS call is already running on the side stream (launch_denoise_prologue): join it, hand over the latents
+            torch.cuda.current_stream(noisy_latents.device).wait_stream(self._side_stream(noisy_latents.device))
+            static[0].copy_(noisy_latents)
+        else:
+            for d_, s_ in zip(static, (noisy_latents, control_img, t, ctx)):
+                d_.copy_(s_)
+            if g0 is not None:
+                g0.replay()
         graph.replay()
         # `borrow_output`: the caller consumes the prediction before the next replay (same stream) and does not keep it:
         # the graph's own output buffer is handed out instead of a copy
         return out if borrow_output else out.clone()
 
+    def _denoise_prologue_eager(self, control_img, t, ctx):
+        """(hint embedding, U-Net handle, ControlNet handle): see launch_denoise_prologue / networks._Encoder.prologue."""
+        dt = self.weights_dtype
+        c = ctx.to(dt)
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):
+            return (self.embed_control(control_img), self.unet.prologue(t, c, dt), self.controlnet.prologue(t, c, dt))
+
     def _forward_unet_eager(self, noisy_latents, control_img, t, encoder_hidden_states, use_pose_controlnet, control_embedding,
-                            replicas):
+                            replicas, pro=None):
         dt = self.weights_dtype
         x = noisy_latents.to(dt)
         ctx = encoder_hidden_states.to(dt)
@@ -312,15 +371,18 @@ class StableDiffusionGuidance:
             side = self._side_stream(x.device)
             side.wait_stream(main)                     # x, ctx, the pose maps were produced on the main stream
             with torch.cuda.stream(side):
-                emb = self.embed_control(control_img) if control_embedding is None else control_embedding
-                down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=emb, replicas=replicas)
+                if pro is not None:             # hint stem and staging came out of the prologue graph
+                    down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=pro[0], replicas=replicas, pro=pro[2])
+                else:
+                    emb = self.embed_control(control_img) if control_embedding is None else control_embedding
+                    down, mid = self.controlnet(x, t, ctx, None, 1.0, cond_embedding=emb, replicas=replicas)
 
             def join():
                 main.wait_stream(side)
                 for r in list(down) + [mid]:
                     r.record_stream(main)              # allocated on the side stream, consumed (and freed) on the main one
                 return down, mid
-            return self.unet(x, t, ctx, join, None, replicas=replicas).to(noisy_latents.dtype)
+            return self.unet(x, t, ctx, join, None, replicas=replicas, pro=None if pro is None else pro[1]).to(noisy_latents.dtype)
 
     _side = None
 
@@ -482,21 +544,29 @@ class StableDiffusionGuidance:
         the diffusion noise), with the chains of ipa_guidance.py:612-614 / :524-531 / :395-431 / :645-653 as four launches."""
         B = rgb.shape[0]
         x = glue.image_prep(rgb.permute(0, 3, 1, 2), (512, 512))
-        moments = self._moments(x)
-        lat_shape = (moments.shape[1] // 2,) + tuple(moments.shape[2:])
-        draw = lambda k, g: torch.randn((k,) + lat_shape, device=moments.device, dtype=moments.dtype, generator=g)  # noqa: E731
+        # The three random draws (same generator order as the op chain: VAE sample noise, timesteps, diffusion noise) and the prompt
+        # table do not depend on the VAE encoder: they are enqueued in front of it, so that the latents-independent head of the
+        # denoise (hint stem, time embeddings, prompt-token keys / values) can start on the side stream beside it (round 6)
+        lat_shape = (self.vae.conv_out.out_channels // 2, x.shape[2] // 8, x.shape[3] // 8)
+        draw = lambda k, g: torch.randn((k,) + lat_shape, device=x.device, dtype=self.weights_dtype, generator=g)  # noqa: E731
         eps = sds.per_sample(draw, B, generator)                     # VAEEncoder.sample's draw
         t = self.schedule.sample(step, B, self.device, generator)
         noise = sds.per_sample(draw, B, generator)                   # compute_grad_anpg's draw
-        if not glue.latent_sample_supported(moments, eps, noise, t, self.alphas):
-            raise RuntimeError("fused guidance glue: unsupported tensors (set GIP_FUSED_GLUE=0 for the op-chain path)")
-        latents, latents_noisy = glue.latent_sample(moments, eps, noise, t, self.alphas, self.vae.scaling_factor, 3)
         embeds = self._prompt_embeds_anpg_table(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances)
         if embeds is None:
             embeds = self._prompt_embeds(prompt_utils, elevation, azimuth, center, all_vis_all, camera_distances, 3)
         assert embeds.shape[1] == TEXT_TOKENS + IP_TOKENS
+        t3 = t.repeat(3)
+        token = None
+        if use_pose_controlnet:
+            token = self.launch_denoise_prologue((3 * B,) + lat_shape, self.weights_dtype, control, t3, embeds, True, 3)
+        moments = self._moments(x)
+        assert tuple(moments.shape[1:]) == (2 * lat_shape[0],) + lat_shape[1:] and moments.dtype == self.weights_dtype
+        if not glue.latent_sample_supported(moments, eps, noise, t, self.alphas):
+            raise RuntimeError("fused guidance glue: unsupported tensors (set GIP_FUSED_GLUE=0 for the op-chain path)")
+        latents, latents_noisy = glue.latent_sample(moments, eps, noise, t, self.alphas, self.vae.scaling_factor, 3)
         with torch.no_grad():
-            noise_pred = self.forward_unet(latents_noisy, control, t.repeat(3), embeds, use_pose_controlnet, replicas=3, borrow_output=True)
+            noise_pred = self.forward_unet(latents_noisy, control, t3, embeds, use_pose_controlnet, replicas=3, borrow_output=True, prologue=token)
         clip = self.cfg.grad_clip_threshold if self.cfg.grad_clip_pixel else None
         loss_sds, grad, grad_norm = glue.anpg_loss(latents, noise_pred, t, self.alphas, self.cfg.guidance_scale,
                                                    self.cfg.weighting_strategy, clip)

@@ -381,6 +381,31 @@ class _Encoder(nn.Module):
 
     _temb_pack = None
 
+    def prologue(self, t, ctx, dtype):
+        """Everything of a forward that does not depend on the latents: the time embedding, every ResnetBlock2D's addend (one packed
+        projection) and every cross-attention's prompt-token keys / values (one or two packed projections).  Returns a handle for
+        `forward(..., pro=handle)`; the modules' staging slots are left empty.  The guidance runs this on its side stream while the
+        VAE encoder is still busy (ipa_guidance.launch_denoise_prologue); needs prepare_inference()."""
+        temb = self.temb(t, dtype)
+        self.stage_context(ctx)
+        blocks = self._temb_pack[0] if self._temb_pack is not None else []
+        cross = self._ctx_pack[0] if self._ctx_pack is not None else []
+        pro = (temb, [b.staged_addend for b in blocks], [a.staged_kv for a in cross])
+        for b in blocks:
+            b.staged_addend = None
+        for a in cross:
+            a.staged_kv = None
+        return pro
+
+    def install(self, pro):
+        """Puts a prologue()'s staged tensors where the blocks look for them; returns the time embedding."""
+        temb, adds, kvs = pro
+        for b, v in zip(self._temb_pack[0] if self._temb_pack is not None else [], adds):
+            b.staged_addend = v
+        for a, v in zip(self._ctx_pack[0] if self._ctx_pack is not None else [], kvs):
+            a.staged_kv = v
+        return temb
+
     @torch.no_grad()
     def prepare_inference(self):
         """Call once the (frozen) weights are final: packs every ResnetBlock2D's time_emb_proj into ONE [sum(C), 1280]
@@ -479,9 +504,12 @@ class UNet(_Encoder):
         self.norm_out = GroupNormAct(32, 320, act=True)
         self.conv_out = nn.Conv2d(320, 4, 3, padding=1)
 
-    def forward(self, x, t, ctx, down_residuals: Optional[List[torch.Tensor]] = None, mid_residual=None, replicas=1):
-        temb = self.temb(t, x.dtype)
-        self.stage_context(ctx)
+    def forward(self, x, t, ctx, down_residuals: Optional[List[torch.Tensor]] = None, mid_residual=None, replicas=1, pro=None):
+        if pro is not None:
+            temb = self.install(pro)
+        else:
+            temb = self.temb(t, x.dtype)
+            self.stage_context(ctx)
         b = x.shape[0] // replicas
         h, skips = self.encode(fused.conv3x3_latent_in(x[:b] if replicas > 1 else x, self.conv_in.weight, self.conv_in.bias), temb, ctx, replicas)
         h = self.mid(h, temb, ctx)
@@ -537,11 +565,14 @@ class ControlNet(_Encoder):
                 c = conv3x3(c, conv.weight, conv.bias)       # 256 -> 320 at 1/8 resolution: the MFMA kernel's shape
         return c
 
-    def forward(self, x, t, ctx, cond, conditioning_scale=1.0, cond_embedding=None, replicas=1) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    def forward(self, x, t, ctx, cond, conditioning_scale=1.0, cond_embedding=None, replicas=1, pro=None) -> Tuple[List[torch.Tensor], torch.Tensor]:
         """`cond` may hold fewer samples than x (B / k): the hint stem then runs once per distinct hint and its output
         is tiled k times — the three guidance branches of compute_grad_anpg share their pose maps (ipa_guidance.py:397-399)."""
-        temb = self.temb(t, x.dtype)
-        self.stage_context(ctx)
+        if pro is not None:
+            temb = self.install(pro)
+        else:
+            temb = self.temb(t, x.dtype)
+            self.stage_context(ctx)
         c = self.embed_condition(cond) if cond_embedding is None else cond_embedding
         b = x.shape[0] // replicas
         if replicas > 1:

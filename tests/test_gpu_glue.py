@@ -155,6 +155,58 @@ def test_guidance_call_with_fused_glue_equals_the_op_chain_call():
     assert torch.equal(res["fused"][2], res["fused again"][2])
 
 
+def test_denoise_prologue_on_the_side_stream_changes_nothing():
+    """Round 6: the latents-independent head of the denoise (ControlNet hint stem, both networks' time embeddings / ResnetBlock2D
+    addends / prompt-token keys and values) is its own captured graph, launched on the side stream before the VAE encoder is enqueued
+    (ipa_guidance.launch_denoise_prologue).  Same kernels on the same values: the plugin call's loss and image gradient are bitwise
+    those of the one-graph denoise, on the capturing call, on the replays that join a prologue already in flight, and when
+    forward_unet is called without one."""
+    from gaussianip_amd.guidance import GuidanceConfig, StableDiffusionGuidance, ipa_guidance
+    from gaussianip_amd.guidance.prompts import PromptProcessor
+    dev = torch.device(DEV)
+    g = _gen(2)
+    tokens = (torch.randn(1, 4, 768, device=dev, generator=g) * 0.1, torch.zeros(1, 4, 768, device=dev),
+              torch.randn(1, 4, 768, device=dev, generator=g) * 0.1)
+    gd = StableDiffusionGuidance(GuidanceConfig(), image_embeds_provider=lambda _: tokens)
+
+    def encode(texts):
+        gg = torch.Generator(device=dev).manual_seed(7)
+        return torch.randn(len(texts), 77, 768, device=dev, generator=gg).half() * 0.1
+    pp = PromptProcessor("a person wearing a coat", encode, negative_prompt="blurry")
+    gd.prepare_for_sds(pp.prompt, pp.negative_prompt, pp.null_prompt)
+    B = 4
+    base = torch.rand(B, 3, 1024, 1024, device=dev, generator=g)
+    pose = torch.rand(B, 512, 512, 3, device=dev, generator=g)
+    kw = dict(elevation=torch.zeros(B), azimuth=torch.tensor([0.0, 90.0, 180.0, -90.0]), center=torch.zeros(B),
+              camera_distances=torch.full((B,), 1.5))
+
+    def call():
+        img = base.clone().requires_grad_(True)
+        out = gd(1000, img.permute(0, 2, 3, 1), pose, pp(), True, torch.ones(B, dtype=torch.long), generator=_gen(5), **kw)
+        (out["loss_sds"] * 1024.0).backward()
+        return out["loss_sds"].detach().clone(), img.grad.clone()
+    launched = []
+    orig = gd.launch_denoise_prologue
+    gd.launch_denoise_prologue = lambda *a: (lambda tok: (launched.append(tok is not None), tok)[1])(orig(*a))
+    old = ipa_guidance._PROLOGUE_GRAPH
+    try:
+        ipa_guidance._PROLOGUE_GRAPH = False
+        one_graph = [call() for _ in range(3)]           # eager, capture, replay
+        assert not any(launched)
+        ipa_guidance._PROLOGUE_GRAPH = True
+        gd.invalidate_graphs()
+        del launched[:]
+        split = [call() for _ in range(5)]               # eager, capture (graph 0 + graph 1), three replays that join a prologue in flight
+        assert launched == [False, False, True, True, True], launched
+    finally:
+        ipa_guidance._PROLOGUE_GRAPH = old
+        gd.launch_denoise_prologue = orig
+    for i, (loss, grad) in enumerate(one_graph[1:] + split[1:]):
+        assert torch.equal(loss, one_graph[1][0]) and torch.equal(grad, one_graph[1][1]), i
+    # the eager first calls run the same kernels outside any graph
+    assert torch.equal(one_graph[0][1], one_graph[1][1]) and torch.equal(split[0][1], split[1][1])
+
+
 @pytest.mark.parametrize("case", ["random", "tied maxima", "all zero"])
 def test_sparsity_term_equals_the_reference_op_chain(case):
     """gip_sparsity_loss_* (include/gip_model.h) against max -> add -> div -> pow -> add -> sqrt -> mean and its autograd
