@@ -28,9 +28,9 @@ _TWO_STREAMS = __import__("os").environ.get("GIP_GUIDANCE_STREAMS", "2") != "1" 
 # GIP_GRAPH_VAE=0 restore the eager launches (same kernels, same values).
 _GRAPH_DENOISE = __import__("os").environ.get("GIP_GRAPH_DENOISE", "1") == "1"
 _GRAPH_VAE = __import__("os").environ.get("GIP_GRAPH_VAE", "1") == "1"
-# round 6: the latents-independent head of the denoise as its own graph on the side stream, beside the VAE encoder (launch_denoise_prologue);
-# 0 = one graph as in round 5 (temporary same-box A/B switch)
-_PROLOGUE_GRAPH = __import__("os").environ.get("GIP_DENOISE_PROLOGUE", "1") == "1"
+# round 6: the latents-independent head of the denoise as its own graph on the side stream, beside the VAE encoder (launch_denoise_prologue).
+# False = one graph as in round 5 (same-box A/B: 33.56 -> 33.45 ms with it; tests flip the attribute)
+_PROLOGUE_GRAPH = True
 
 
 @dataclass
