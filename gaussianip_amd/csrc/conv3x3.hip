@@ -696,7 +696,12 @@ template <int BM, int BN, int TAPS>
 __global__ void __launch_bounds__(CVB_THREADS, 2)
 conv_big_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                 const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
-                int m_tiles, int n_tiles, int Hin, int Win, int geom, float* __restrict__ chan_stats, GnBwdArgs gnb) {
+                int m_tiles, int n_tiles, int Hin, int Win, int geom, float* __restrict__ chan_stats, GnBwdArgs gnb,
+                long long bs_x = 0, long long bs_w = 0, long long bs_o = 0) {
+  // BATCHED GEMM (TAPS = 1, gip_linear_batched_f16 on the 256 x 256 tile, round 6): blockIdx.y = batch entry, as in conv3x3_kernel
+  if constexpr (TAPS == 1) {
+    x += (size_t)blockIdx.y * bs_x; w += (size_t)blockIdx.y * bs_w; out += (size_t)blockIdx.y * bs_o;
+  }
   const int cstride = geom & 0xff, pad_t = (geom >> 8) & 0xff, pad_l = (geom >> 16) & 0xff;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int WN = BN == 256 ? 4 : 2, WM = 8 / WN;      // wave grid: WM (pixel direction) x WN (channel direction)
@@ -1076,7 +1081,8 @@ static int env_int(const char* name, int dflt) {
 
 template <int BM, int BN, int TAPS>
 static int launch_big(const void* x, const void* w, const void* bias, const void* residual, void* out, int N, int H, int W, int Cin,
-                      int Cout, hipStream_t s, int Hin, int Win, int geom, float* chan_stats, const GnBwdArgs& gnb) {
+                      int Cout, hipStream_t s, int Hin, int Win, int geom, float* chan_stats, const GnBwdArgs& gnb, int batch = 1,
+                      long long bs_x = 0, long long bs_w = 0, long long bs_o = 0) {
   const long long M = (long long)N * H * W;
   const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (Cout + BN - 1) / BN;
   const size_t lds = 2 * ((size_t)BM + (size_t)((BN + 63) / 64) * 64) * 128;
@@ -1087,9 +1093,9 @@ static int launch_big(const void* x, const void* w, const void* bias, const void
     attr_set = true;
   }
   geom |= 1 << 29;                                  // residual rows requested before the epilogue staging
-  hipLaunchKernelGGL((conv_big_kernel<BM, BN, TAPS>), dim3(m_tiles * n_tiles), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
+  hipLaunchKernelGGL((conv_big_kernel<BM, BN, TAPS>), dim3(m_tiles * n_tiles, batch), dim3(CVB_THREADS), lds, s, (const _Float16*)x,
                      (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out, N, H, W, Cin, Cout,
-                     m_tiles, n_tiles, Hin, Win, geom, chan_stats, gnb);
+                     m_tiles, n_tiles, Hin, Win, geom, chan_stats, gnb, bs_x, bs_w, bs_o);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -1457,6 +1463,15 @@ extern "C" int gip_linear_batched_f16(const void* x, const void* w, void* out, i
   hipStream_t s = (hipStream_t)stream;
   const bool wide = Nout % 160 == 0 && Nout % 128 != 0;
   const int geom = 1 | (1 << 8) | (1 << 16);
+  // 256 x 256 tiles (one 8-wave workgroup per CU, half the operand bytes per MAC) where the batch of products fills the chip with
+  // them: the sixteen [768, K] x [K, 1280] products of a Winograd convolution at the 16 x 16 level are 3 x 5 x 16 = 240 tiles
+  if (!(Nout & 255) && gip_dbg_conv_big != 0) {
+    const long long tiles = ((M + 255) / 256) * (Nout / 256) * B;
+    if (tiles >= 224 && (M % 256 == 0 || M >= 2048)) {
+      GnBwdArgs none = {};
+      return launch_big<256, 256, 1>(x, w, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, 1, (int)M, geom, nullptr, none, B, bs_x, bs_w, bs_o);
+    }
+  }
   return wide ? launch<160, 2, 1, false>(x, w, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, 0x1ff,
                                          128, B, bs_x, bs_w, bs_o)
               : launch<128, 2, 1, false>(x, w, nullptr, nullptr, out, 1, 1, (int)M, K, Nout, s, nullptr, 0, 0, 0, geom, nullptr, nullptr, 0x1ff,

@@ -476,9 +476,17 @@ def _winograd_weight(w):
 _WINOGRAD_DEFAULT = "16:640:3072,16:1280:1536,16:1920:1536,16:2560:1536,32:960:3072,32:1280:3072,32:1920:3072"
 
 
-# "own": the sixteen Winograd products on this repo's batched MFMA GEMM; "lib": one batched hipBLASLt call (torch.bmm).  Same-box
-# A/B: tools/exp_winograd_gemm.py (profiles/r05_winograd_gemm_batched.txt)
-_WINOGRAD_GEMM_DEFAULT = "lib"
+# "own": the sixteen Winograd products on this repo's batched MFMA GEMM; "lib": one batched hipBLASLt call (torch.bmm); "auto" (round 6):
+# the own GEMM where it measures at or below the library's time under graph replay — its 256 x 256 tiles (one 8-wave workgroup per
+# CU; Cout % 256 == 0: the 16 x 16 level) at K <= 1280: 51.6 vs 52.3 us (1280 -> 1280, batch 12), 31.7 vs 32.0 (640 -> 1280), 0.77-0.99 at
+# batch 3 / 6; the library's stream-K tiles win at K >= 1920 (1.11-1.14x) and on the 640-wide products of the 32 x 32 level.
+# Same-box A/B: tools/exp_winograd_gemm.py (profiles/r06_winograd_gemm_256.txt, profiles/r05_winograd_gemm_batched.txt)
+_WINOGRAD_GEMM_DEFAULT = "auto"
+
+
+def _winograd_gemm_own(C, cout):
+    mode = os.environ.get("GIP_WINOGRAD_GEMM", _WINOGRAD_GEMM_DEFAULT)
+    return mode == "own" or (mode == "auto" and cout % 256 == 0 and C <= 1280)
 
 
 def _winograd_shapes():
@@ -528,7 +536,7 @@ def _winograd_conv(x, w, bias, residual, stats=None, gn_in=None):
     if rc != 0:
         raise RuntimeError("gip_winograd_input_f16 failed with status %d" % rc)
     U = _wt_cache.get("wino", w, _winograd_weight)
-    if os.environ.get("GIP_WINOGRAD_GEMM", _WINOGRAD_GEMM_DEFAULT) == "own" and C % 64 == 0 and cout % 4 == 0 and T * max(C, cout) * 2 < (1 << 31):
+    if _winograd_gemm_own(C, cout) and C % 64 == 0 and cout % 4 == 0 and T * max(C, cout) * 2 < (1 << 31):
         # the sixteen products in ONE launch of this repo's MFMA GEMM (blockIdx.y = product): gip_linear_batched_f16
         M = torch.empty((16, T, cout), dtype=x.dtype, device=x.device)
         rc = lib.gip_linear_batched_f16(_p(V), _p(U), _p(M), 16, T, C, cout, T * C, cout * C, T * cout, stream)
