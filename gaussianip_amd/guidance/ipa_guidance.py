@@ -33,6 +33,25 @@ _GRAPH_VAE = __import__("os").environ.get("GIP_GRAPH_VAE", "1") == "1"
 _PROLOGUE_GRAPH = True
 
 
+class _no_gc:
+    """No cyclic garbage collection while a HIP graph is being captured.  A collection that happens to run inside the capture can
+    finalise ANOTHER object that owns captured graphs (an earlier guidance instance of the same process): destroying a graph / its
+    memory pool is not permitted while a stream is capturing, the error surfaces in a destructor and aborts the process (seen once in
+    the GPU suite, round 6: "Fatal Python error: Aborted ... Garbage-collecting" under _forward_unet_graph).  torch.cuda.graph()
+    collects BEFORE the capture for the same reason; this closes the window during it."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self._was:
+            import gc
+            gc.enable()
+
+
 @dataclass
 class GuidanceConfig:
     # the subset of ipa_guidance.py:74-123 that the per-step path reads (values of configs/exp.yaml:78-120 as defaults)
@@ -320,10 +339,10 @@ class StableDiffusionGuidance:
                 # graph 0: hint stem + both networks' latents-independent staging (launch_denoise_prologue); its outputs live in
                 # its private pool and are read in place by graph 1
                 g0 = torch.cuda.CUDAGraph()
-                with fused.capture_owner(id(self)), torch.cuda.graph(g0):
+                with _no_gc(), fused.capture_owner(id(self)), torch.cuda.graph(g0):
                     pro = self._denoise_prologue_eager(static[1], static[2], static[3])
             graph = torch.cuda.CUDAGraph()
-            with fused.capture_owner(id(self)), torch.cuda.graph(graph):
+            with _no_gc(), fused.capture_owner(id(self)), torch.cuda.graph(graph):
                 out = self._forward_unet_eager(static[0], static[1], static[2], static[3], use_pose, None, replicas, pro=pro)
             ent = self._graphs[key] = (graph, static, out, g0, pro)
         graph, static, out, g0 = ent[:4]
@@ -436,7 +455,7 @@ class StableDiffusionGuidance:
             return self._vae_moments(x) if moments_only else self._vae_encode(x, generator)
         if ent == "warm":
             sample = torch.zeros_like(x, memory_format=torch.channels_last).requires_grad_(True)
-            with fused.capture_owner(id(self)):
+            with _no_gc(), fused.capture_owner(id(self)):
                 ent = self._vae_graphs[key] = torch.cuda.make_graphed_callables(lambda t_: self._vae_moments(t_), (sample,), num_warmup_iters=2)
         # make_graphed_callables keeps ONE set of static activations: a second forward before the first one's backward would
         # overwrite what that backward reads.  While an earlier output of this graph is still alive and has not been

@@ -200,7 +200,7 @@ def test_denoise_prologue_on_the_side_stream_changes_nothing():
         assert launched == [False, False, True, True, True], launched
     finally:
         ipa_guidance._PROLOGUE_GRAPH = old
-        gd.launch_denoise_prologue = orig
+        del gd.launch_denoise_prologue          # (the instance attribute: restoring the bound method would leave a reference cycle)
     for i, (loss, grad) in enumerate(one_graph[1:] + split[1:]):
         assert torch.equal(loss, one_graph[1][0]) and torch.equal(grad, one_graph[1][1]), i
     # the eager first calls run the same kernels outside any graph
