@@ -1,6 +1,9 @@
 #!/bin/bash
 # round 6, first GPU call: (1) cost of a dependent stage boundary: graph node vs grid barrier; (2) segment length 64 / 128 / 256 on the
-# headline step and on configs[4]; (3) HBM counters of the 1M-Gaussian render kernels by views per launch set
+# headline step and on configs[4]; (3) HBM counters of the 1M-Gaussian render kernels by views per launch set.
+# The segment-length variants are library builds, made beforehand (they are not kept in the tree):
+#   for S in 128 256; do make -C gaussianip_amd/csrc OUT=/tmp/seg$S HIPCC="/opt/rocm/bin/hipcc -DGIP_SEGMENT=$S" /tmp/seg$S/libgip_raster.so
+#   cp /tmp/seg$S/libgip_raster.so gaussianip_amd/lib/libgip_raster_seg$S.so; done
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r6a; mkdir -p $OUT
 timeout 120 tools/micro/grid_barrier 64 > $OUT/grid_barrier.txt 2>&1
