@@ -133,8 +133,15 @@ __device__ __forceinline__ void gnb_accumulate(const GnBwdArgs& a, const GnBwdLa
 // kernel is bound by its L2 -> LDS traffic (tools/exp_conv_ablate.py: the DMA stream alone = 70 % of the kernel).
 #define CVH_ROWS 184                      // halo rows held per channel block (180 used: 10 x 18; waves 0-2 of the sixth round)
 #define CVH_KC_BYTES (CVH_ROWS * 128)
-template <int BN, int STAGES, int TAPS, bool GEGLU, bool HALO = false>
-__global__ void __launch_bounds__(CV_THREADS, 2)
+// KG = 2 (round 6, TAPS = 1 GEMMs on grids of at most one workgroup per CU): TWO K groups of four waves inside one workgroup.  A lone
+// workgroup's K step is the issue of its LDS-DMA instructions + its MFMAs in series inside each wave (tools/experiments/
+// conv3x3_four_stage.diff.txt), which two co-resident workgroups interleave — but a small grid has no second workgroup.  Here group
+// g stages and multiplies its half of the K steps in its own pair of stage buffers, the halves run interleaved on the CU's four
+// SIMDs, group 1 hands its accumulators over through LDS and group 0 runs the (unchanged) epilogue: half the serial K steps per
+// tile, no split-K slabs, no reduce launch.  The sum is (first half) + (second half) instead of one chain: deterministic, not
+// bit-identical to KG = 1.
+template <int BN, int STAGES, int TAPS, bool GEGLU, bool HALO = false, int KG = 1>
+__global__ void __launch_bounds__(CV_THREADS * KG, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                const _Float16* __restrict__ residual, _Float16* __restrict__ out, int N, int H, int W, int Cin, int Cout,
                int m_tiles, int n_tiles, int ksplit, float* __restrict__ partial, int Hin, int Win, int geom,
@@ -169,9 +176,12 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int HALO_BYTES = HALO ? 2 * CVH_KC_BYTES : 0;       // [2 channel blocks][184 halo rows][128 B], in front of the stages
   static_assert(!HALO || (TAPS == 9 && !GEGLU), "halo mode: 3x3 convolution");
+  static_assert(KG == 1 || (KG == 2 && TAPS == 1 && !HALO && !GEGLU), "two K groups: plain GEMMs only");
   constexpr int B_ROUNDS = BN / 32;
   constexpr int NI = BN / 32;                   // 16-channel MFMA tiles per wave (its half of BN)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kg = KG > 1 ? (int)threadIdx.x / CV_THREADS : 0;           // K group of this wave (wave-uniform)
+  const int tid = KG > 1 ? (int)threadIdx.x % CV_THREADS : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  unsigned char* const gsm = smem + (KG > 1 ? kg * (STAGES * STAGE) : 0);      // this group's stage buffers
   const int wm = wave & 1, wn = wave >> 1;
 
   // tile of this workgroup (bijective XCD remap: ids congruent mod 8 share an XCD)
@@ -260,21 +270,24 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
 
   const int cblocks = Cin / CV_BK;
   const int KT_all = (TAPS == 9 ? __builtin_popcount(tapsel & 0x1ff) : TAPS) * cblocks;
-  const int kt_begin = (int)((long long)split * KT_all / ksplit), kt_end = (int)((long long)(split + 1) * KT_all / ksplit);
+  const int kpart = split * KG + kg, kparts = ksplit * KG;       // K range of this (split, group)
+  const int kt_begin = (int)((long long)kpart * KT_all / kparts), kt_end = (int)((long long)(kpart + 1) * KT_all / kparts);
   const int KT = kt_end - kt_begin;
+  // the groups of a workgroup share its barriers: both run the longer group's trip count (KG = 2: the second half has the odd step)
+  const int KT_loop = KG > 1 ? KT_all - (int)((long long)(KG - 1) * KT_all / KG) : KT;
 
   auto stage = [&](int tap, int cb, int buf) {
     const int dy = tap / 3, dx = tap - dy * 3;
     const unsigned tap_off = (unsigned)((TAPS == 9 ? (dy * Win + dx) * Cin : 0) + cb * CV_BK) * 2u;   // relative to the shifted base
     const unsigned wtap_off = (unsigned)(tap * Cin + cb * CV_BK) * 2u;
     if constexpr (!HALO) {
-      unsigned char* sa = smem + buf * STAGE + wave * 1024;
+      unsigned char* sa = gsm + buf * STAGE + wave * 1024;
       if (!((geom >> 26) & 1)) {
 #pragma unroll
         for (int i = 0; i < 4; i++) dma16(xr, ((a_mask[i] >> tap) & 1u) ? a_off[i] : CV_OOB, tap_off, sa + i * 4096);
       }
     }
-    unsigned char* sb = smem + HALO_BYTES + buf * STAGE + A_BYTES + wave * 1024;
+    unsigned char* sb = gsm + HALO_BYTES + buf * STAGE + A_BYTES + wave * 1024;
     if (!((geom >> 27) & 1)) {
 #pragma unroll
       for (int i = 0; i < B_ROUNDS; i++) dma16(wr, b_off[i], wtap_off, sb + i * 4096);
@@ -359,8 +372,10 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
     }
   }
   int tap_c = tap, cb_c = cb;                      // (tap, channel block) of the step being COMPUTED (stage() runs one ahead)
-  stage(tap, cb, 0);
-  advance();
+  if (KG == 1 || KT > 0) {
+    stage(tap, cb, 0);
+    advance();
+  }
   // the bias of this lane's output channels is requested here, under the first operand DMA, not at the head of the epilogue (where its
   // round trip was exposed once per tile: 1 us of a 22 us tile at the VAE's first level)
   [[maybe_unused]] f16x4 bias4[NI];
@@ -423,14 +438,34 @@ conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, c
       __syncthreads();
     }
   }
-  for (int kt = 0; kt < KT; kt++) {
+  for (int kt = 0; kt < KT_loop; kt++) {
     const int buf = kt & 1;
     const int tap_n = tap, cb_n = cb;
     if (kt + 1 < KT) { stage(tap, cb, buf ^ 1); advance(); }
-    if (!((geom >> 28) & 1)) compute(smem + HALO_BYTES + buf * STAGE, tap_c, cb_c);
+    if (!((geom >> 28) & 1) && (KG == 1 || kt < KT)) compute(gsm + HALO_BYTES + buf * STAGE, tap_c, cb_c);
     tap_c = tap_n; cb_c = cb_n;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if constexpr (KG == 2) {
+    // group 1's partial products -> LDS (every lane its own f32x4 slots: conflict-free), group 0 adds them and goes on alone
+    f32x4* red = (f32x4*)smem;                     // NI * 4 * 256 x 16 B <= the two groups' stage buffers (checked at the launch)
+    if (kg == 1) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) red[(ni * 4 + mi) * CV_THREADS + tid] = acc[ni][mi];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) {
+        const f32x4 o = red[(ni * 4 + mi) * CV_THREADS + tid];
+        acc[ni][mi][0] += o[0]; acc[ni][mi][1] += o[1]; acc[ni][mi][2] += o[2]; acc[ni][mi][3] += o[3];
+      }
+    asm volatile("s_barrier" ::: "memory");        // group 0's four waves: `red` is about to be reused by the epilogue's tile image
   }
 
   // ---- LayerNorm fold: (rstd, -rstd * mu) of the tile's 128 rows from the producer's per-row partial sums, kept in the last KB
@@ -1070,7 +1105,7 @@ conv_splitk_reduce_stats_kernel(const float* __restrict__ partial, const _Float1
 
 // Debug / A-B knobs (tools/exp_conv*.py set them through ctypes; -1 = the shape heuristic below decides)
 extern "C" { int gip_dbg_conv_order = -1; int gip_dbg_conv_epilogue = -1; int gip_dbg_conv_ksplit = 0; int gip_dbg_conv_ablate = 0;
-             int gip_dbg_conv_big = -1; int gip_dbg_linear_narrow = -1; }
+             int gip_dbg_conv_big = -1; int gip_dbg_linear_narrow = -1; int gip_dbg_linear_kg = -1; }
 // same-box A/B of a whole training step (tools/ab_ahds.sh); read once.  (Rounds 3-5 also had GIP_CONV_EPILOGUE / _RES_EARLY / _BIG /
 // _KSPLIT_R2: the per-lane 8-byte epilogue, residual rows requested late, no 256-row tile, the round-2 split-K factor — each measured
 // slower in DESIGN §4c and retired in round 6; the gip_dbg_* knobs above still reach them from tools/exp_conv*.py.)
@@ -1218,6 +1253,26 @@ static int launch(const void* x, const void* w, const void* bias, const void* re
   }
   geom |= (nmajor << 24) | (lds_epi << 25) | ((gip_dbg_conv_ablate & 7) << 26) | (1 << 29);   // bits 26-28: timing ablations (WRONG results)
   const int classes = (tapsel >> 12) & 1 ? 4 : 1;
+  if constexpr (TAPS == 1 && !GEGLU) {
+    // two K groups per workgroup (KG = 2, see conv3x3_kernel) where the grid leaves at most one workgroup per CU and the K loop is long
+    // enough to split: the GEMMs of the 8 x 8 level at batch 12, most GEMMs of a 1-view shard (batch 3)
+    const bool kg2 = gip_dbg_linear_kg >= 0 ? gip_dbg_linear_kg != 0 : true;
+    if (kg2 && ksplit == 1 && batch == 1 && tiles <= 256 && KT >= 8 && lds_epi) {
+      constexpr size_t lds2 = 2 * STAGES * (size_t)(CV_BM + BN) * 128;
+      static_assert((size_t)(BN / 32) * 4 * CV_THREADS * 16 <= lds2, "the handed-over accumulators must fit the stage buffers");
+      static bool attr2 = false;
+      if (!attr2) {
+        if (hipFuncSetAttribute((const void*)conv3x3_kernel<BN, STAGES, TAPS, GEGLU, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds2) != hipSuccess)
+          return 3;
+        attr2 = true;
+      }
+      hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU, false, 2>), dim3(tiles), dim3(CV_THREADS * 2), lds2, s,
+                         (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
+                         N, H, W, Cin, Cout, m_tiles, n_tiles, 1, (float*)nullptr, Hin, Win, geom, chan_stats, gnb, tapsel, bs_x, bs_w, bs_o);
+      return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
+  }
   hipLaunchKernelGGL((conv3x3_kernel<BN, STAGES, TAPS, GEGLU>), dim3(tiles * ksplit * classes, batch), dim3(CV_THREADS), lds, s,
                      (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (const _Float16*)residual, (_Float16*)out,
                      N, H, W, Cin, Cout, m_tiles, n_tiles, ksplit, (float*)workspace, Hin, Win, geom,

@@ -172,3 +172,38 @@ def test_narrow_channel_tiles_of_small_grids_are_bit_identical(M, K, N, monkeypa
         assert float((got.float() - ref).abs().max()) <= 8e-3 * max(1.0, float(ref.abs().max()))
     ref0 = torch.nn.functional.linear(x.float(), w.float(), b.float()) + r.float()
     assert float((narrow[0].float() - ref0).abs().max()) <= 4e-3 * max(1.0, float(ref0.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,N", [(768, 1280, 1280), (192, 5120, 1280), (3072, 1280, 320), (768, 2560, 640), (200, 1344, 320)])
+def test_two_k_groups_per_workgroup_equal_the_one_group_gemm(M, K, N):
+    """Round 6: on grids of at most one workgroup per CU the own GEMM runs TWO K groups of four waves per workgroup (conv3x3_kernel<...,
+    KG = 2>): each takes half of the K steps in its own stage buffers, group 1 hands its accumulators over through LDS.  Against the
+    one-group kernel (gip_dbg_linear_kg = 0): the sum is (first half) + (second half) instead of one chain — equal to the rounding of
+    two fp32 partial sums (<= one half ulp of the output after the final rounding) — same error against float32, bitwise reproducible;
+    an odd number of K steps (1344 = 21 x 64) gives the second group the extra step."""
+    import ctypes
+    from gaussianip_amd import _lib
+    lib = _lib.nn_lib()
+    knob = ctypes.c_int.in_dll(lib._lib, "gip_dbg_linear_kg")
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=g).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).half()
+    b = torch.randn(N, device="cuda", generator=g).half()
+    r = torch.randn(M, N, device="cuda", generator=g).half()
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    try:
+        for mode in (0, 1, 1):
+            knob.value = mode
+            o = torch.empty(M, N, device="cuda", dtype=torch.float16)
+            assert lib.gip_linear_f16(p_(x), p_(w), p_(b), p_(r), p_(o), M, K, N, 0, st) == 0
+            outs.append(o)
+    finally:
+        knob.value = -1
+    ref = (torch.addmm(b.float(), x.float(), w.float().t()).half().float() + r.float())
+    scale = float(ref.abs().max())
+    assert torch.equal(outs[1], outs[2])
+    assert float((outs[0].float() - outs[1].float()).abs().max()) <= 2.0 ** -9 * scale
+    e0, e1 = float((outs[0].float() - ref).abs().max()), float((outs[1].float() - ref).abs().max())
+    assert e1 <= 2.0 ** -8 * scale and e1 <= 1.5 * e0 + 2.0 ** -10 * scale, (e0, e1)
