@@ -139,7 +139,9 @@ __device__ __forceinline__ void gnb_accumulate(const GnBwdArgs& a, const GnBwdLa
 // g stages and multiplies its half of the K steps in its own pair of stage buffers, the halves run interleaved on the CU's four
 // SIMDs, group 1 hands its accumulators over through LDS and group 0 runs the (unchanged) epilogue: half the serial K steps per
 // tile, no split-K slabs, no reduce launch.  The sum is (first half) + (second half) instead of one chain: deterministic, not
-// bit-identical to KG = 1.
+// bit-identical to KG = 1.  (Extended to whole-K 3x3 convolutions of 171..256 tiles — the shared prefix at batch 4, a shard's
+// 64 x 64 level — in place of split-K = 2, it measured SLOWER in the step: full step 33.25 -> 33.38 ms, and it gave back 0.09 of the
+// shard's 0.22 ms: eight waves holding 147 KB of LDS keep the OTHER stream's workgroups off the CU in the two-stream denoise.)
 template <int BN, int STAGES, int TAPS, bool GEGLU, bool HALO = false, int KG = 1>
 __global__ void __launch_bounds__(CV_THREADS * KG, 2)
 conv3x3_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
