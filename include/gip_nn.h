@@ -251,7 +251,12 @@ int gip_linear_f16(const void* x, const void* w, const void* bias, const void* r
 /* B independent GEMMs in ONE launch: out[b] [M, Nout] = x[b] [M, K] . w[b]^T ([Nout, K]), entry b at x + b * bs_x, w + b * bs_w,
  * out + b * bs_o (element strides; bs_x, bs_w multiples of 8, bs_o of 4).  The sixteen products M[i] = V[i] U[i]^T of a Winograd
  * F(2x2, 3x3) convolution (csrc/winograd.hip) — round 4 ran them as one batched hipBLASLt call; sixteen separate launches of the
- * own kernel left the chip under-filled (60 tiles each).  K % 64 == 0, Nout % 4 == 0, no bias / residual / split-K. */
+ * own kernel left the chip under-filled (60 tiles each).  K % 64 == 0, Nout % 4 == 0, no bias / residual / split-K.  Round 6: where
+ * Nout % 256 == 0 and the batch of products fills the chip with 256 x 256 tiles (one 8-wave workgroup per CU) the launch takes those
+ * (the 16 x 16 level: 3 x 5 x 16 = 240 tiles): at or below the batched library call's time at K <= 1280.
+ * gip_linear_f16 and its variants (round 6): where the grid leaves at most one workgroup per CU (<= 256 tiles) and K >= 512, a
+ * workgroup runs TWO K groups of four waves (each half of the K steps in its own stage buffers, accumulators handed over through
+ * LDS): the result is (first half) + (second half) of the K sum — deterministic, same error against float32. */
 int gip_linear_batched_f16(const void* x, const void* w, void* out, int32_t B, int64_t M, int32_t K, int32_t Nout,
                            int64_t bs_x, int64_t bs_w, int64_t bs_o, void* stream);
 
